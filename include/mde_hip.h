@@ -1,0 +1,261 @@
+/*
+ * mde_hip.h -- C ABI of libmde_hip.so, the MI355X (gfx950 / CDNA4) implementation of
+ * the minimum-distortion-embedding hot path.
+ *
+ * Every entry point below replaces one seam of the reference (cvxgrp/pymde v0.2.1); the
+ * reference location it stands in for is cited as  [ref: file:line].  The reference has
+ * no native boundary of its own on this path (it is torch ops called from Python), so
+ * this header IS the FFI a maintainer binds with ctypes -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross the boundary.
+ *   - Every `*_dev` / unqualified data pointer is a DEVICE pointer on the device that
+ *     is current on the calling thread.  `mde_func`, `mde_lbfgs_coef` are HOST structs.
+ *   - All work is enqueued asynchronously on `stream` (a hipStream_t passed as void*);
+ *     nothing synchronises unless documented ("SYNC").
+ *   - The library borrows caller memory for the duration of the enqueued work and never
+ *     frees it.  Objects created here (mde_plan, mde_lbfgs) own their device memory.
+ *   - Return value: MDE_OK (0) or a negative MDE_E_* code.  No exceptions cross the ABI.
+ *     mde_last_error() returns a thread-local human-readable message for the last failure.
+ *   - Embeddings / gradients are contiguous row-major float32 [n, d].  Edge lists are
+ *     int64 [p, 2] at the boundary (the reference's dtype, problem.py:130-132) and int32
+ *     inside a plan.
+ */
+#ifndef MDE_HIP_H_
+#define MDE_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDE_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ error codes */
+#define MDE_OK 0
+#define MDE_E_INVALID (-1)     /* bad argument (null pointer, negative size, d out of range) */
+#define MDE_E_SELF_EDGE (-2)   /* an edge (i, i) was found        [ref: problem.py:134-140]  */
+#define MDE_E_RANGE (-3)       /* an endpoint is outside [0, n)                              */
+#define MDE_E_TOO_LARGE (-4)   /* n >= 2^31 or 2p >= 2^31 (int32 plan)                       */
+#define MDE_E_HIP (-5)         /* a HIP runtime call failed; see mde_last_error()            */
+#define MDE_E_UNSUPPORTED (-6) /* function kind / dimension not handled by the fused path    */
+
+const char* mde_last_error(void);
+int mde_abi_version(void);
+
+/* ------------------------------------------------------------------ distortion functions
+ * The per-edge distortion f_k(d_k) and its derivative are evaluated inside the kernels.
+ * `kind` selects the closed form; `a0` / `a1` are the per-edge parameter arrays
+ * (weights w_k for penalties, deviations delta_k for losses; a1 = weights of the
+ * weighted losses); s0..s2 are the scalar hyper-parameters.
+ * [ref: pymde/functions/penalties.py:112-400, pymde/functions/losses.py:61-239]
+ *
+ *   penalties (a0 = w)                          s0          s1      s2
+ *   MDE_F_LINEAR            w d
+ *   MDE_F_QUADRATIC         w d^2
+ *   MDE_F_CUBIC             w d^3
+ *   MDE_F_POWER             w d^e                e
+ *   MDE_F_HUBER             w d^2/2 | w t(d-t/2) t (threshold)     (strict <, :230)
+ *   MDE_F_LOGISTIC          w log(1+exp(a(d-t))) t          a
+ *   MDE_F_SIGMOID           w sigmoid(a(d-t))    t          a
+ *   MDE_F_HINGE             max(0,w(d-(t-sgn(w)s))) t       s (sigma)
+ *   MDE_F_LOG1P             w log1p(d^e)         e
+ *   MDE_F_LOG               w log(-expm1(-d^e))  e
+ *   MDE_F_INVPOWER          |w| / d^e            e
+ *   MDE_F_LOGRATIO          w log(d^e/(1+d^e))   e
+ *   MDE_F_DEADZONE_QUADRATIC  w (d<t ? 0 : d^2)  t
+ *   MDE_F_DEADZONE_CUBIC      w (d<t ? 0 : d^3)  t
+ *   MDE_F_CLIPPED_QUADRATIC   w min(d^2,(t+1)^2) t
+ *   losses (a0 = delta, r = |delta - d|)
+ *   MDE_F_L_QUADRATIC       (delta-d)^2
+ *   MDE_F_L_WEIGHTED_QUADRATIC  a1 (delta-d)^2
+ *   MDE_F_L_HUBER           r^2 | t(2r-t)        t                   (strict <, losses.py:122)
+ *   MDE_F_L_CUBIC           r^3
+ *   MDE_F_L_POWER           r^e                  e
+ *   MDE_F_L_WEIGHTED_POWER  a1 r^e               e
+ *   MDE_F_L_ABSOLUTE        r
+ *   MDE_F_L_LOGISTIC        log(1+exp(r))
+ *   MDE_F_L_FRACTIONAL      max(delta/d, d/delta) - 1
+ *   MDE_F_L_SOFT_FRACTIONAL (1/g)(lse(g delta/d, g d/delta) - log 2 - g)   s0 = g (gamma)
+ *   MDE_F_L_CLIPPED_QUADRATIC   min((delta-d)^2,(t+1)^2)  t
+ *
+ * PushAndPull [ref: penalties.py:372-400]: set `kind` to the attractive penalty and
+ * `kind_neg` to the repulsive one (with its scalars in n0..n2); an edge uses `kind` when
+ * w_k >= 0 and `kind_neg` when w_k < 0 (zero weight is attractive, penalties.py:390).
+ * kind_neg = MDE_F_NONE means a plain (single) function.
+ */
+enum {
+  MDE_F_NONE = 0,
+  MDE_F_LINEAR = 1,
+  MDE_F_QUADRATIC = 2,
+  MDE_F_CUBIC = 3,
+  MDE_F_POWER = 4,
+  MDE_F_HUBER = 5,
+  MDE_F_LOGISTIC = 6,
+  MDE_F_SIGMOID = 7,
+  MDE_F_HINGE = 8,
+  MDE_F_LOG1P = 9,
+  MDE_F_LOG = 10,
+  MDE_F_INVPOWER = 11,
+  MDE_F_LOGRATIO = 12,
+  MDE_F_DEADZONE_QUADRATIC = 13,
+  MDE_F_DEADZONE_CUBIC = 14,
+  MDE_F_CLIPPED_QUADRATIC = 15,
+  MDE_F_L_QUADRATIC = 32,
+  MDE_F_L_WEIGHTED_QUADRATIC = 33,
+  MDE_F_L_HUBER = 34,
+  MDE_F_L_CUBIC = 35,
+  MDE_F_L_POWER = 36,
+  MDE_F_L_WEIGHTED_POWER = 37,
+  MDE_F_L_ABSOLUTE = 38,
+  MDE_F_L_LOGISTIC = 39,
+  MDE_F_L_FRACTIONAL = 40,
+  MDE_F_L_SOFT_FRACTIONAL = 41,
+  MDE_F_L_CLIPPED_QUADRATIC = 42
+};
+
+typedef struct mde_func {
+  int32_t kind;      /* MDE_F_* (attractive branch for PushAndPull)                       */
+  int32_t kind_neg;  /* MDE_F_NONE, or the repulsive branch of a PushAndPull              */
+  const float* a0;   /* device; per-edge weights / deviations.  Order: see each call      */
+  const float* a1;   /* device; second per-edge array (weighted losses) or NULL           */
+  int32_t a0_scalar; /* 1: a0 points at ONE value broadcast to every edge (nelement()==1) */
+  int32_t a1_scalar;
+  float s0, s1, s2;  /* scalars of `kind`                                                 */
+  float n0, n1, n2;  /* scalars of `kind_neg`                                             */
+} mde_func;
+
+/* ------------------------------------------------------------------ the edge plan
+ * One-time device preprocessing of an edge list [ref: problem.py:129-170, the `edges`,
+ * `_lhs`, `_rhs` buffers].  The plan stores the SYMMETRISED incidence structure in CSR
+ * form: for every vertex v in [row_lo, row_hi) the list of its incident half-edges
+ * (neighbour u, original edge id k), so the gradient row of v is a pure gather
+ *      grad[v] = sum_{h in row v} g_h (x_v - x_{nbr[h]})
+ * with no atomics and a fixed summation order (bitwise reproducible).  Half-edges of a
+ * row keep the order of their original edge ids (stable sort).
+ *
+ * row_lo/row_hi select the vertex range this plan (rank) owns; pass 0, n for a
+ * single-GPU plan.  Validation (self edges, range) always covers the full edge list.
+ * SYNC: returns after the plan is built (it must read back counts).
+ */
+typedef struct mde_plan mde_plan;
+
+int mde_plan_create(int64_t n, int64_t p, const int64_t* edges, int64_t row_lo, int64_t row_hi,
+                    void* stream, mde_plan** out);
+int mde_plan_destroy(mde_plan* plan);
+int64_t mde_plan_n(const mde_plan* plan);
+int64_t mde_plan_p(const mde_plan* plan);           /* edges in the full problem           */
+int64_t mde_plan_half_edges(const mde_plan* plan);  /* half-edges stored (= 2p if full)    */
+int64_t mde_plan_row_lo(const mde_plan* plan);
+int64_t mde_plan_row_hi(const mde_plan* plan);
+const int32_t* mde_plan_rowptr(const mde_plan* plan); /* [row_hi-row_lo+1], offsets into nbr */
+const int32_t* mde_plan_nbr(const mde_plan* plan);    /* [half_edges] neighbour vertex      */
+const int32_t* mde_plan_eid(const mde_plan* plan);    /* [half_edges] original edge id      */
+
+/* Copy the plan arrays into caller buffers (rowptr [nloc+1], nbr [H], eid [H]; any may be NULL). */
+int mde_plan_export(const mde_plan* plan, int32_t* rowptr_out, int32_t* nbr_out, int32_t* eid_out,
+                    void* stream);
+
+/* Balanced vertex-range boundaries for `world` ranks: bounds[r]..bounds[r+1] holds about
+ * 2p/world half-edges.  `bounds_host` is a HOST array of world+1 int64.  SYNC. */
+int mde_shard_bounds(int64_t n, int64_t p, const int64_t* edges, int32_t world,
+                     int64_t* bounds_host, void* stream);
+
+/* out_half[h] = in_edge[eid[h]] : put a per-edge parameter array into plan order. */
+int mde_plan_expand(const mde_plan* plan, const float* in_edge, float* out_half, void* stream);
+
+/* ------------------------------------------------------------------ the hot kernel
+ * Fused forward + backward of the average distortion
+ *   E(X) = (1/p) sum_k f_k(||x_ik - x_jk||),  dE/dX          [ref: average_distortion.py:62-106]
+ * `f->a0/a1` are in PLAN (half-edge) order (mde_plan_expand) unless *_scalar is set.
+ * Writes rows [row_lo,row_hi) of grad (other rows untouched) when grad != NULL, and the
+ * plan's share of E into *loss_out (device float; full E for a full plan).  With
+ * grad == NULL this is the forward-only evaluation (average_distortion.py:90-91).
+ * g_k = f'_k(d_k)/(p d_k) with NaN -> 1, Inf -> 1 as in average_distortion.py:81-88.
+ * `grad_scale` multiplies the gradient (upstream grad_output, average_distortion.py:105).
+ */
+int mde_average_distortion(mde_plan* plan, const float* X, int32_t d, const mde_func* f,
+                           float grad_scale, float* grad, float* loss_out, void* stream);
+
+/* ------------------------------------------------------------------ edge-order evaluators
+ * [ref: problem.py:246-308 differences / distances / distortions; average_distortion.py:38-55]
+ * These work on the caller's ORIGINAL edge order and need no plan. */
+int mde_differences(int64_t n, int64_t p, const int64_t* edges, const float* X, int32_t d,
+                    float* diff_out /* [p,d] */, void* stream);
+int mde_distances(int64_t n, int64_t p, const int64_t* edges, const float* X, int32_t d,
+                  float* dist_out /* [p] */, void* stream);
+/* backward of distances: grad_X += sum_k gout_k (x_i - x_j)/d_k (+ to i, - to j), NaN -> 0
+ * (average_distortion.py:46-52).  Needs a full plan of the same edges; gout in edge order. */
+int mde_distances_backward(const mde_plan* plan, const float* X, int32_t d, const float* gout,
+                           float* grad /* [n,d], rows of the plan overwritten */, void* stream);
+/* out_k = f_k(dist_k) and, when dout != NULL, dout_k = f'_k(dist_k); parameters in EDGE order. */
+int mde_distortions(int64_t p, const float* dist, const mde_func* f, float* out, float* dout,
+                    void* stream);
+
+/* Unfused fallback for arbitrary Python callables (average_distortion.py:73-105):
+ * grad[v] = scale * sum_h gfix(gnorm[eid[h]] / dist[eid[h]]) (x_v - x_nbr), where
+ * gnorm = d(mean f)/d(dist) from torch autograd and gfix maps NaN/Inf to 1.0 (:81-88). */
+int mde_scatter(const mde_plan* plan, const float* X, int32_t d, const float* gnorm,
+                const float* dist, float scale, float* grad, void* stream);
+
+/* ------------------------------------------------------------------ constraints
+ * [ref: constraints.py:94-200, util.py:129-171] */
+/* Z -= column mean (Centered retraction, constraints.py:106-111). `work` >= mde_work_doubles(d). */
+int mde_center(int64_t n, int32_t d, float* Z, double* work, void* stream);
+/* Anchored (constraints.py:143-164): rows[anchors] = values (or 0 when values == NULL). */
+int mde_anchor_rows(int64_t n_anchors, int32_t d, const int64_t* anchors, const float* values,
+                    float* Z, void* stream);
+/* Standardized tangent projection Z -= (1/n) X (Z^T X)  (constraints.py:186-192). */
+int mde_std_tangent(int64_t n, int32_t d, const float* X, float* Z, double* work, void* stream);
+/* Standardized retraction: Z <- sqrt(n) * polar factor of (Z - mean)  (util.py:129-161),
+ * computed as sqrt(n) (Z-mean) C^{-1/2}, C = (Z-mean)^T (Z-mean) via a d x d
+ * eigendecomposition on device.  status_dev (device int32, may be NULL) is set non-zero
+ * when C is numerically singular.  demean = 0 skips the centring (util.py:130-134). */
+int mde_std_retract(int64_t n, int32_t d, float* Z, int32_t demean, double* work,
+                    int32_t* status_dev, void* stream);
+/* Gram matrix out[d_a, d_b] (double, device) = A^T B for A [n,d_a], B [n,d_b]; uses the
+ * f32 MFMA path when both widths are multiples of 32. */
+int mde_gram(int64_t n, int32_t da, int32_t db, const float* A, const float* B, double* out,
+             double* work, void* stream);
+/* Z = A M, M [d, d2] device double row-major (small). */
+int mde_right_multiply(int64_t n, int32_t d, int32_t d2, const float* A, const double* M,
+                       float* out, void* stream);
+/* number of doubles of scratch the constraint / gram / vector calls need for width d */
+int64_t mde_work_doubles(int32_t d);
+
+/* ------------------------------------------------------------------ vector kernels
+ * [ref: lbfgs.py:350-376, 461-530; optim.py:94-147]  flat float32 vectors of length N */
+/* out = y + alpha x  (lbfgs.py:350-357 `_add_grad`);  out may alias y */
+int mde_axpy(int64_t N, float alpha, const float* x, const float* y, float* out, void* stream);
+/* stats[0..7] (device doubles) = { g.d, g.g, sum|g|, max|g|, #non-finite(g), d.d, max|d|, x.x }
+ * (d and x may be NULL: their entries are 0).  One pass.  lbfgs.py:59, 82, 523, 527; optim.py:96, 130 */
+int mde_vec_stats(int64_t N, const float* g, const float* d, const float* x, double* stats,
+                  double* work, void* stream);
+
+/* ------------------------------------------------------------------ L-BFGS memory
+ * [ref: lbfgs.py:461-507]  Device-resident history of (s, y) pairs with one spare slot. */
+typedef struct mde_lbfgs mde_lbfgs;
+int mde_lbfgs_create(int64_t N, int32_t history, mde_lbfgs** out);
+int mde_lbfgs_destroy(mde_lbfgs* o);
+int mde_lbfgs_reset(mde_lbfgs* o);                   /* lbfgs.py:378-388 */
+int32_t mde_lbfgs_count(const mde_lbfgs* o);
+/* Stage the candidate pair y = g - g_prev, s = t d in the spare slot, set g_prev <- g, and
+ * compute every inner product the two-loop recursion needs.  dots (device doubles):
+ *   [0] y.s  [1] y.y  [2] s.g  [3] y.g
+ *   then for each stored pair j (oldest first): s_j.y*, y_j.y*, s*.y_j, s_j.g, y_j.g
+ * `dots` must hold 4 + 5*history doubles.  g_prev may be NULL on the first call (nothing is
+ * staged; only g_prev <- g is skipped too -- use mde_lbfgs_set_prev). */
+int mde_lbfgs_stage(mde_lbfgs* o, const float* g, float* g_prev, const float* d, float t,
+                    double* dots, double* work, void* stream);
+/* accept != 0: the staged pair becomes the newest pair (dropping the oldest when full). */
+int mde_lbfgs_commit(mde_lbfgs* o, int32_t accept);
+/* d_out = c_g g + sum_j (cs[j] s_j + cy[j] y_j) over stored pairs (oldest first); also
+ * stats as mde_vec_stats(g, d_out, NULL).  cs, cy: HOST arrays of mde_lbfgs_count floats. */
+int mde_lbfgs_combine(mde_lbfgs* o, const float* g, float c_g, const float* cs, const float* cy,
+                      float* d_out, double* stats, double* work, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDE_HIP_H_ */

@@ -1,0 +1,14 @@
+"""pymde_amd -- minimum-distortion embedding on AMD Instinct MI355X (gfx950 / CDNA4).
+
+A from-scratch, GPU-native implementation of the hot path of cvxgrp/pymde behind PyMDE's own
+object API: ``MDE``, ``penalties.*`` / ``losses.*``, ``Centered / Standardized / Anchored``.
+The average-distortion forward/backward, the constraint projections and the projected
+L-BFGS step are hand-written HIP kernels in ``libmde_hip.so`` (C ABI: ``include/mde_hip.h``).
+"""
+__version__ = "0.1.0"
+
+from pymde_amd.problem import MDE  # noqa: F401
+from pymde_amd.constraints import Centered, Anchored, Standardized  # noqa: F401
+from pymde_amd.functions import losses, penalties  # noqa: F401
+from pymde_amd.util import all_edges, center, seed  # noqa: F401
+from pymde_amd import quadratic  # noqa: F401

@@ -1,0 +1,531 @@
+// mde_distortion.hip -- the hot kernel: fused forward + backward of the average distortion
+//   E(X) = (1/p) sum_k f_k(||x_i - x_j||),   dE/dX
+// [ref: pymde/average_distortion.py:62-106 `_AverageDistortion.forward/backward`], plus the
+// edge-order evaluators behind MDE.differences/distances/distortions
+// [ref: pymde/problem.py:246-308, average_distortion.py:38-55] and the unfused fallback used
+// for arbitrary Python callables.
+//
+// Execution model (CDNA4, wave64): the plan is a symmetrised incidence CSR.  A group of G
+// lanes owns one vertex row v at a time; the lanes stride over the row's half-edges
+// (coalesced int32 neighbour + fp32 parameter streams), gather x_u (the only random access,
+// served by L2 / Infinity Cache: the table is n*d*4 bytes), evaluate f and f'/d in registers,
+// accumulate g (x_v - x_u) and reduce across the G lanes with xor butterflies (DPP).  There
+// are no atomics and no [p, d] temporaries; the reference materialises five of them.
+// Each edge is visited from both endpoints, so its loss term is counted with weight 1/2.
+#include "mde_common.h"
+#include "mde_functions.h"
+#define COMMA ,
+
+double* mde_plan_partials(mde_plan* p);
+float mde_plan_avg_degree(const mde_plan* p);
+
+// ---------------------------------------------------------------- small-d fused kernel
+// D in {1,2,3,4}: one lane per half-edge, G lanes per row.
+template <int D>
+struct VecD {
+  float v[D];
+};
+template <int D>
+MDE_DEV VecD<D> load_row(const float* __restrict__ X, int64_t r) {
+  VecD<D> o;
+  if constexpr (D == 2) {
+    const float2 t = reinterpret_cast<const float2*>(X)[r];
+    o.v[0] = t.x;
+    o.v[1] = t.y;
+  } else if constexpr (D == 4) {
+    const float4 t = reinterpret_cast<const float4*>(X)[r];
+    o.v[0] = t.x;
+    o.v[1] = t.y;
+    o.v[2] = t.z;
+    o.v[3] = t.w;
+  } else {
+#pragma unroll
+    for (int c = 0; c < D; ++c) o.v[c] = X[r * D + c];
+  }
+  return o;
+}
+
+template <int D, int G, bool INDIRECT, class Fn>
+__global__ __launch_bounds__(MDE_BLOCK) void k_fused_small(
+    int nrows, int row_lo, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ nbr,
+    const int32_t* __restrict__ eid, const float* __restrict__ a0, const float* __restrict__ a1,
+    int a0_scalar, int a1_scalar, const float* __restrict__ X, float* __restrict__ grad,
+    double* __restrict__ loss_partials, Fn fn, float inv_p, float grad_scale) {
+  __shared__ double smem[8];
+  const int lig = threadIdx.x & (G - 1);
+  const int group = (blockIdx.x * MDE_BLOCK + threadIdx.x) / G;
+  const int ngroups = (gridDim.x * MDE_BLOCK) / G;
+  float loss = 0.0f;
+  const float a0s = a0_scalar ? a0[0] : 0.0f;
+  const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
+
+  for (int r = group; r < nrows; r += ngroups) {
+    const int beg = rowptr[r], end = rowptr[r + 1];
+    const int64_t v = (int64_t)row_lo + r;
+    const VecD<D> xv = load_row<D>(X, v);
+    float acc[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.0f;
+#pragma unroll 2
+    for (int h = beg + lig; h < end; h += G) {
+      const int u = nbr[h];
+      float p0, p1 = a1s;
+      if constexpr (INDIRECT) {
+        const int k = eid[h];
+        p0 = a0[k];
+        p1 = a1[k];
+      } else {
+        p0 = a0_scalar ? a0s : a0[h];
+        if (a1 && !a1_scalar) p1 = a1[h];
+      }
+      const VecD<D> xu = load_row<D>(X, u);
+      float diff[D], ss = 0.0f;
+#pragma unroll
+      for (int c = 0; c < D; ++c) {
+        diff[c] = xv.v[c] - xu.v[c];
+        ss = fmaf(diff[c], diff[c], ss);
+      }
+      float f, gd;
+      fn.eval(ss, p0, p1, f, gd);
+      const float g = mde_fix_g(gd * inv_p);
+      loss += f;
+#pragma unroll
+      for (int c = 0; c < D; ++c) acc[c] = fmaf(g, diff[c], acc[c]);
+    }
+    if (grad) {
+#pragma unroll
+      for (int c = 0; c < D; ++c) acc[c] = mde_group_sum<G>(acc[c]);
+      if (lig == 0) {
+        if constexpr (D == 2) {
+          reinterpret_cast<float2*>(grad)[v] = make_float2(acc[0] * grad_scale, acc[1] * grad_scale);
+        } else if constexpr (D == 4) {
+          reinterpret_cast<float4*>(grad)[v] = make_float4(acc[0] * grad_scale, acc[1] * grad_scale,
+                                                           acc[2] * grad_scale, acc[3] * grad_scale);
+        } else {
+#pragma unroll
+          for (int c = 0; c < D; ++c) grad[v * D + c] = acc[c] * grad_scale;
+        }
+      }
+    }
+  }
+  const double bs = mde_block_sum((double)loss, smem);
+  if (threadIdx.x == 0) loss_partials[blockIdx.x] = bs;
+}
+
+// ---------------------------------------------------------------- general-d fused kernel
+// One wave owns a row.  GL lanes cooperate on one half-edge (64/GL half-edges in flight per
+// wave); lane `lig` holds components c = lig + j*GL, j < K (coalesced 4-byte lanes; rows of
+// d floats are contiguous so a half-edge gather is one or more full 128/256-byte segments).
+template <int GL, int K, bool INDIRECT, class Fn>
+__global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide(
+    int nrows, int row_lo, int d, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ nbr, const int32_t* __restrict__ eid, const float* __restrict__ a0,
+    const float* __restrict__ a1, int a0_scalar, int a1_scalar, const float* __restrict__ X,
+    float* __restrict__ grad, double* __restrict__ loss_partials, Fn fn, float inv_p,
+    float grad_scale) {
+  __shared__ double smem[8];
+  constexpr int E = 64 / GL;  // half-edges per wave iteration
+  const int lane = threadIdx.x & 63;
+  const int lig = lane & (GL - 1);
+  const int sub = lane / GL;  // which of the E half-edges this lane works on
+  const int wave = (blockIdx.x * MDE_BLOCK + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * MDE_BLOCK) >> 6;
+  float loss = 0.0f;
+  const float a0s = a0_scalar ? a0[0] : 0.0f;
+  const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
+
+  for (int r = wave; r < nrows; r += nwaves) {
+    const int beg = rowptr[r], end = rowptr[r + 1];
+    const int64_t v = (int64_t)row_lo + r;
+    float xv[K], acc[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int c = lig + j * GL;
+      xv[j] = (c < d) ? X[v * d + c] : 0.0f;
+      acc[j] = 0.0f;
+    }
+    for (int h0 = beg; h0 < end; h0 += E) {
+      const int h = h0 + sub;
+      const bool live = h < end;
+      const int hh = live ? h : beg;
+      const int64_t u = nbr[hh];
+      float p0, p1 = a1s;
+      if constexpr (INDIRECT) {
+        const int k = eid[hh];
+        p0 = a0[k];
+        p1 = a1[k];
+      } else {
+        p0 = a0_scalar ? a0s : a0[hh];
+        if (a1 && !a1_scalar) p1 = a1[hh];
+      }
+      float diff[K], ss = 0.0f;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const int c = lig + j * GL;
+        const float xu = (c < d) ? X[u * d + c] : 0.0f;
+        diff[j] = xv[j] - xu;
+        ss = fmaf(diff[j], diff[j], ss);
+      }
+      ss = mde_group_sum<GL>(ss);
+      float f, gd;
+      fn.eval(ss, p0, p1, f, gd);
+      float g = mde_fix_g(gd * inv_p);
+      if (!live) {
+        g = 0.0f;
+        f = 0.0f;
+      }
+      if (lig == 0) loss += f;
+#pragma unroll
+      for (int j = 0; j < K; ++j) acc[j] = fmaf(g, diff[j], acc[j]);
+    }
+    if (grad) {
+      // combine the E sub-groups (lanes with equal lig): xor over the sub index bits
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        float a = acc[j];
+#pragma unroll
+        for (int o = 32; o >= GL; o >>= 1) a += __shfl_xor(a, o, 64);
+        acc[j] = a;
+      }
+      if (sub == 0) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const int c = lig + j * GL;
+          if (c < d) grad[v * d + c] = acc[j] * grad_scale;
+        }
+      }
+    }
+  }
+  const double bs = mde_block_sum((double)loss, smem);
+  if (threadIdx.x == 0) loss_partials[blockIdx.x] = bs;
+}
+
+// loss = scale * sum(partials[0..nb)) in a fixed order (one block)
+__global__ void k_finalize_loss(const double* __restrict__ partials, int nb, double scale,
+                                float* __restrict__ loss_out) {
+  __shared__ double smem[8];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) s += partials[i];
+  const double t = mde_block_sum(s, smem);
+  if (threadIdx.x == 0) *loss_out = (float)(t * scale);
+}
+
+// ---------------------------------------------------------------- functors of the unfused paths
+struct FnScatter {  // a0 = d(mean f)/d(dist) from autograd, a1 = dist  (average_distortion.py:81)
+  MDE_DEV void eval(float ss, float a0, float a1, float& f, float& gd) const {
+    f = 0.0f;
+    gd = a0 / a1;
+  }
+};
+struct FnDistBackward {  // backward of the 2-norm, average_distortion.py:46-52
+  MDE_DEV void eval(float ss, float a0, float a1, float& f, float& gd) const {
+    f = 0.0f;
+    gd = a0 * mde_rcp(mde_sqrt(ss));
+  }
+};
+
+// ---------------------------------------------------------------- launch helpers
+struct FusedArgs {
+  const mde_plan* plan;
+  const float* X;
+  int d;
+  const float *a0, *a1;
+  int a0_scalar, a1_scalar;
+  float* grad;
+  double* partials;
+  float inv_p, grad_scale;
+  hipStream_t st;
+  int nblocks;  // out
+};
+
+static int g_group_override = 0;  // MDE_GROUP env (tuning experiments)
+static int pick_group(float avg_degree) {
+  if (g_group_override == 0) {
+    const char* e = getenv("MDE_GROUP");
+    g_group_override = e ? atoi(e) : -1;
+  }
+  if (g_group_override > 0) return g_group_override;
+  if (avg_degree >= 48.f) return 16;
+  if (avg_degree >= 20.f) return 8;
+  return 4;
+}
+
+template <int D, int G, bool IND, class Fn>
+static int launch_small_g(FusedArgs& A, const Fn& fn) {
+  const mde_plan* P = A.plan;
+  const int nrows = (int)(mde_plan_row_hi(P) - mde_plan_row_lo(P));
+  const int64_t threads = (int64_t)nrows * G;
+  const int nb = mde_grid(threads, MDE_BLOCK, 2048);
+  A.nblocks = nb;
+  hipLaunchKernelGGL((k_fused_small<D, G, IND, Fn>), dim3(nb), dim3(MDE_BLOCK), 0, A.st, nrows,
+                     (int)mde_plan_row_lo(P), mde_plan_rowptr(P), mde_plan_nbr(P), mde_plan_eid(P), A.a0,
+                     A.a1, A.a0_scalar, A.a1_scalar, A.X, A.grad, A.partials, fn, A.inv_p,
+                     A.grad_scale);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+template <int D, bool IND, class Fn>
+static int launch_small(FusedArgs& A, const Fn& fn) {
+  switch (pick_group(mde_plan_avg_degree(A.plan))) {
+    case 4: return launch_small_g<D, 4, IND, Fn>(A, fn);
+    case 8: return launch_small_g<D, 8, IND, Fn>(A, fn);
+    case 32: return launch_small_g<D, 32, IND, Fn>(A, fn);
+    case 64: return launch_small_g<D, 64, IND, Fn>(A, fn);
+    default: return launch_small_g<D, 16, IND, Fn>(A, fn);
+  }
+}
+template <int GL, int K, bool IND, class Fn>
+static int launch_wide_gk(FusedArgs& A, const Fn& fn) {
+  const mde_plan* P = A.plan;
+  const int nrows = (int)(mde_plan_row_hi(P) - mde_plan_row_lo(P));
+  const int nb = mde_grid((int64_t)nrows * 64, MDE_BLOCK, 2048);
+  A.nblocks = nb;
+  hipLaunchKernelGGL((k_fused_wide<GL, K, IND, Fn>), dim3(nb), dim3(MDE_BLOCK), 0, A.st, nrows,
+                     (int)mde_plan_row_lo(P), A.d, mde_plan_rowptr(P), mde_plan_nbr(P), mde_plan_eid(P),
+                     A.a0, A.a1, A.a0_scalar, A.a1_scalar, A.X, A.grad, A.partials, fn, A.inv_p,
+                     A.grad_scale);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+template <bool IND, class Fn>
+static int launch_wide(FusedArgs& A, const Fn& fn) {
+  const int d = A.d;
+  if (d <= 8) return launch_wide_gk<8, 1, IND, Fn>(A, fn);
+  if (d <= 16) return launch_wide_gk<16, 1, IND, Fn>(A, fn);
+  if (d <= 32) return launch_wide_gk<32, 1, IND, Fn>(A, fn);
+  if (d <= 64) return launch_wide_gk<64, 1, IND, Fn>(A, fn);
+  if (d <= 128) return launch_wide_gk<64, 2, IND, Fn>(A, fn);
+  if (d <= 256) return launch_wide_gk<64, 4, IND, Fn>(A, fn);
+  if (d <= 512) return launch_wide_gk<64, 8, IND, Fn>(A, fn);
+  if (d <= 1024) return launch_wide_gk<64, 16, IND, Fn>(A, fn);
+  if (d <= 2048) return launch_wide_gk<64, 32, IND, Fn>(A, fn);
+  mde_set_error("embedding dimension %d > 2048 is not supported by the fused kernel", d);
+  return MDE_E_UNSUPPORTED;
+}
+template <bool IND, class Fn>
+static int launch_any_d(FusedArgs& A, const Fn& fn) {
+  switch (A.d) {
+    case 1: return launch_small<1, IND, Fn>(A, fn);
+    case 2: return launch_small<2, IND, Fn>(A, fn);
+    case 3: return launch_small<3, IND, Fn>(A, fn);
+    case 4: return launch_small<4, IND, Fn>(A, fn);
+    default: return launch_wide<IND, Fn>(A, fn);
+  }
+}
+
+static MdeFuncArgs func_args(const mde_func* f) {
+  MdeFuncArgs a;
+  a.kind = f->kind;
+  a.kind_neg = f->kind_neg;
+  a.S = {f->s0, f->s1, f->s2};
+  a.N = {f->n0, f->n1, f->n2};
+  return a;
+}
+
+// dedicated instantiations for the functions the recipes use by default; everything else
+// goes through the universal run-time functor.
+static int dispatch_fused(FusedArgs& A, const mde_func* f) {
+  const MdeFuncArgs a = func_args(f);
+  if (A.d == 2 || A.d == 3) {
+    const int ea = mde_exp_class(f->s0), en = mde_exp_class(f->n0);
+#define SMALL(FN)                                       \
+  do {                                                  \
+    FN fn{a};                                           \
+    if (A.d == 2) return launch_small<2, false, FN>(A, fn); \
+    return launch_small<3, false, FN>(A, fn);           \
+  } while (0)
+    if (f->kind_neg == MDE_F_NONE) {
+      if (f->kind == MDE_F_QUADRATIC) SMALL(FnSingle<MDE_F_QUADRATIC COMMA 0>);
+      if (f->kind == MDE_F_LOG1P && ea == 2) SMALL(FnSingle<MDE_F_LOG1P COMMA 2>);
+      if (f->kind == MDE_F_L_QUADRATIC) SMALL(FnSingle<MDE_F_L_QUADRATIC COMMA 0>);
+      if (f->kind == MDE_F_L_ABSOLUTE) SMALL(FnSingle<MDE_F_L_ABSOLUTE COMMA 0>);
+      if (f->kind == MDE_F_L_HUBER) SMALL(FnSingle<MDE_F_L_HUBER COMMA 0>);
+    } else if (f->kind == MDE_F_LOG1P && ea == 2) {
+      if (f->kind_neg == MDE_F_LOG && en == 1)
+        SMALL(FnPushPull<MDE_F_LOG1P COMMA 2 COMMA MDE_F_LOG COMMA 1>);
+      if (f->kind_neg == MDE_F_LOGRATIO && en == 3)
+        SMALL(FnPushPull<MDE_F_LOG1P COMMA 2 COMMA MDE_F_LOGRATIO COMMA 3>);
+    }
+#undef SMALL
+  }
+  FnRuntime fn{a};
+  return launch_any_d<false, FnRuntime>(A, fn);
+}
+
+static int check_func(const mde_func* f) {
+  if (!f || !mde_kind_valid(f->kind) || (f->kind_neg != MDE_F_NONE && !mde_kind_valid(f->kind_neg))) {
+    mde_set_error("unknown distortion function kind");
+    return MDE_E_UNSUPPORTED;
+  }
+  if (!f->a0) {
+    mde_set_error("distortion function has no per-edge parameter array");
+    return MDE_E_INVALID;
+  }
+  const bool needs_a1 = f->kind == MDE_F_L_WEIGHTED_QUADRATIC || f->kind == MDE_F_L_WEIGHTED_POWER ||
+                        f->kind_neg == MDE_F_L_WEIGHTED_QUADRATIC ||
+                        f->kind_neg == MDE_F_L_WEIGHTED_POWER;
+  if (needs_a1 && !f->a1) {
+    mde_set_error("weighted loss needs the second per-edge array (a1)");
+    return MDE_E_INVALID;
+  }
+  return MDE_OK;
+}
+
+extern "C" int mde_average_distortion(mde_plan* plan, const float* X, int32_t d, const mde_func* f,
+                                      float grad_scale, float* grad, float* loss_out, void* stream) {
+  if (!plan || !X || d <= 0 || !loss_out) return MDE_E_INVALID;
+  int rc = check_func(f);
+  if (rc != MDE_OK) return rc;
+  const int64_t p = mde_plan_p(plan);
+  FusedArgs A;
+  A.plan = plan;
+  A.X = X;
+  A.d = d;
+  A.a0 = f->a0;
+  A.a1 = f->a1;
+  A.a0_scalar = f->a0_scalar;
+  A.a1_scalar = f->a1_scalar;
+  A.grad = grad;
+  A.partials = mde_plan_partials(plan);
+  A.inv_p = p > 0 ? (float)(1.0 / (double)p) : 0.0f;
+  A.grad_scale = grad_scale;
+  A.st = mde_stream(stream);
+  A.nblocks = 0;
+  rc = dispatch_fused(A, f);
+  if (rc != MDE_OK) return rc;
+  // every edge is seen from both endpoints: weight 1/2; mean over p edges
+  const double scale = p > 0 ? 0.5 / (double)p : 0.0;
+  hipLaunchKernelGGL(k_finalize_loss, dim3(1), dim3(MDE_BLOCK), 0, A.st, A.partials, A.nblocks, scale,
+                     loss_out);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+extern "C" int mde_scatter(const mde_plan* plan, const float* X, int32_t d, const float* gnorm,
+                           const float* dist, float scale, float* grad, void* stream) {
+  if (!plan || !X || d <= 0 || !gnorm || !dist || !grad) return MDE_E_INVALID;
+  FusedArgs A;
+  A.plan = plan;
+  A.X = X;
+  A.d = d;
+  A.a0 = gnorm;
+  A.a1 = dist;
+  A.a0_scalar = 0;
+  A.a1_scalar = 0;
+  A.grad = grad;
+  A.partials = mde_plan_partials(const_cast<mde_plan*>(plan));
+  A.inv_p = 1.0f;
+  A.grad_scale = scale;
+  A.st = mde_stream(stream);
+  FnScatter fn;
+  return launch_any_d<true, FnScatter>(A, fn);
+}
+
+extern "C" int mde_distances_backward(const mde_plan* plan, const float* X, int32_t d,
+                                      const float* gout, float* grad, void* stream) {
+  if (!plan || !X || d <= 0 || !gout || !grad) return MDE_E_INVALID;
+  FusedArgs A;
+  A.plan = plan;
+  A.X = X;
+  A.d = d;
+  A.a0 = gout;
+  A.a1 = gout;
+  A.a0_scalar = 0;
+  A.a1_scalar = 0;
+  A.grad = grad;
+  A.partials = mde_plan_partials(const_cast<mde_plan*>(plan));
+  A.inv_p = 1.0f;
+  A.grad_scale = 1.0f;
+  A.st = mde_stream(stream);
+  FnDistBackward fn;
+  return launch_any_d<true, FnDistBackward>(A, fn);
+}
+
+// ---------------------------------------------------------------- edge-order evaluators
+// GL lanes per edge, components strided over the lanes.
+template <int GL, bool WRITE_DIFF>
+__global__ __launch_bounds__(MDE_BLOCK) void k_edge_order(int64_t p, int d,
+                                                          const int64_t* __restrict__ edges,
+                                                          const float* __restrict__ X,
+                                                          float* __restrict__ out) {
+  const int lig = threadIdx.x & (GL - 1);
+  const int64_t g0 = ((int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x) / GL;
+  const int64_t ng = ((int64_t)gridDim.x * MDE_BLOCK) / GL;
+  for (int64_t k = g0; k < p; k += ng) {
+    const longlong2 e = reinterpret_cast<const longlong2*>(edges)[k];
+    float ss = 0.0f;
+    for (int c = lig; c < d; c += GL) {
+      const float df = X[e.x * d + c] - X[e.y * d + c];
+      if constexpr (WRITE_DIFF) out[k * d + c] = df;
+      ss = fmaf(df, df, ss);
+    }
+    if constexpr (!WRITE_DIFF) {
+      ss = mde_group_sum<GL>(ss);
+      // sqrt(sum of squares): correctly rounded sqrt, as torch's pow(2).sum().sqrt()
+      if (lig == 0) out[k] = sqrtf(ss);
+    }
+  }
+}
+
+template <bool WRITE_DIFF>
+static int launch_edge_order(int64_t n, int64_t p, const int64_t* edges, const float* X, int d,
+                             float* out, hipStream_t st) {
+  if (n <= 0 || p < 0 || d <= 0 || (p > 0 && (!edges || !X || !out))) return MDE_E_INVALID;
+  if (p == 0) return MDE_OK;
+#define EO(GLV)                                                                                   \
+  hipLaunchKernelGGL((k_edge_order<GLV, WRITE_DIFF>), dim3(mde_grid(p * GLV, MDE_BLOCK, 4096)),   \
+                     dim3(MDE_BLOCK), 0, st, p, d, edges, X, out)
+  if (d <= 4)
+    EO(1);
+  else if (d <= 16)
+    EO(4);
+  else if (d <= 64)
+    EO(16);
+  else
+    EO(64);
+#undef EO
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+extern "C" int mde_differences(int64_t n, int64_t p, const int64_t* edges, const float* X, int32_t d,
+                               float* diff_out, void* stream) {
+  return launch_edge_order<true>(n, p, edges, X, d, diff_out, mde_stream(stream));
+}
+extern "C" int mde_distances(int64_t n, int64_t p, const int64_t* edges, const float* X, int32_t d,
+                             float* dist_out, void* stream) {
+  return launch_edge_order<false>(n, p, edges, X, d, dist_out, mde_stream(stream));
+}
+
+__global__ __launch_bounds__(MDE_BLOCK) void k_distortions(int64_t p, const float* __restrict__ dist,
+                                                           const float* __restrict__ a0,
+                                                           const float* __restrict__ a1, int a0_scalar,
+                                                           int a1_scalar, FnRuntime fn,
+                                                           float* __restrict__ out,
+                                                           float* __restrict__ dout) {
+  const float a0s = a0_scalar ? a0[0] : 0.0f;
+  const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
+  for (int64_t k = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; k < p;
+       k += (int64_t)gridDim.x * MDE_BLOCK) {
+    const float dk = dist[k];
+    const float p0 = a0_scalar ? a0s : a0[k];
+    const float p1 = (a1 && !a1_scalar) ? a1[k] : a1s;
+    float f, gd;
+    fn.eval(dk * dk, p0, p1, f, gd);
+    out[k] = f;
+    if (dout) dout[k] = gd * dk;  // f'(d) = (f'(d)/d) d
+  }
+}
+
+extern "C" int mde_distortions(int64_t p, const float* dist, const mde_func* f, float* out,
+                               float* dout, void* stream) {
+  if (p < 0 || (p > 0 && (!dist || !out))) return MDE_E_INVALID;
+  int rc = check_func(f);
+  if (rc != MDE_OK) return rc;
+  if (p == 0) return MDE_OK;
+  FnRuntime fn{func_args(f)};
+  hipLaunchKernelGGL(k_distortions, dim3(mde_grid(p, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0,
+                     mde_stream(stream), p, dist, f->a0, f->a1, f->a0_scalar, f->a1_scalar, fn, out, dout);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}

@@ -1,0 +1,348 @@
+// mde_functions.h -- device-side distortion functions f_k(d) and f'_k(d)/d.
+//
+// Each kind restates one class of the reference's penalty / loss surface
+// [ref: pymde/functions/penalties.py:112-400, pymde/functions/losses.py:61-239]; the
+// derivative is the closed form of what torch autograd produces there.  Everything is
+// fp32, built from the gfx950 transcendental instructions (v_sqrt/v_rcp/v_log/v_exp, 1 ulp)
+// with cancellation-safe forms for log1p / expm1.
+//
+//   eval<KIND, ECLS>(ss, a0, a1, S, f, gd)
+//     ss  = squared distance, a0/a1 per-edge parameters, S scalars
+//     f   = f_k(d)                    (d = sqrt(ss))
+//     gd  = f'_k(d) / d               (may be NaN/Inf at d = 0; the caller applies the
+//                                      reference's NaN->1, Inf->1 rule, average_distortion.py:81-88)
+//   ECLS is a compile-time hint for the exponent: 0 = read S.s0 at run time,
+//   1 -> e=1, 2 -> e=1.5, 3 -> e=2, 4 -> e=3, 5 -> e=0.5.
+#pragma once
+#include "mde_common.h"
+
+struct MdeScalars {
+  float s0, s1, s2;
+};
+
+#define MDE_DEV __device__ __forceinline__
+
+MDE_DEV float mde_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+MDE_DEV float mde_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+MDE_DEV float mde_log2(float x) { return __builtin_amdgcn_logf(x); }
+MDE_DEV float mde_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+MDE_DEV float mde_log(float x) { return mde_log2(x) * 0.6931471805599453f; }
+MDE_DEV float mde_exp(float x) { return mde_exp2(x * 1.4426950408889634f); }
+
+// log(1+u) for u > -0.5, relative error ~1e-7 for all u (series below 1/16, compensated
+// log above).
+MDE_DEV float mde_log1p(float u) {
+  const float t = 1.0f + u;
+  const float c = u - (t - 1.0f);  // rounding error of 1+u
+  const float big = fmaf(c, mde_rcp(t), mde_log(t));
+  const float sm =
+      u * fmaf(u, fmaf(u, fmaf(u, fmaf(u, fmaf(u, -1.0f / 6.0f, 0.2f), -0.25f), 1.0f / 3.0f), -0.5f),
+               1.0f);
+  return fabsf(u) < 0.0625f ? sm : big;
+}
+// 1 - exp(-u) for u >= 0 and exp(-u)
+MDE_DEV float mde_one_minus_expneg(float u, float& em) {
+  em = mde_exp(-u);
+  const float direct = 1.0f - em;
+  const float ser = u * fmaf(u, fmaf(u, fmaf(u, fmaf(u, fmaf(u, -1.0f / 720.0f, 1.0f / 120.0f), -1.0f / 24.0f),
+                                               1.0f / 6.0f),
+                                     -0.5f),
+                             1.0f);
+  return u < 0.0625f ? ser : direct;
+}
+// numerically stable log(1 + exp(z)) and sigmoid(z)
+MDE_DEV float mde_softplus(float z) { return fmaxf(z, 0.0f) + mde_log1p(mde_exp(-fabsf(z))); }
+MDE_DEV float mde_sigmoid(float z) { return mde_rcp(1.0f + mde_exp(-z)); }
+MDE_DEV float mde_sign(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
+
+// x^e for x >= 0.  e = 0 -> 1 (torch.pow convention).
+template <int ECLS>
+MDE_DEV float mde_pow(float x, float e) {
+  if constexpr (ECLS == 1) return x;
+  if constexpr (ECLS == 2) return x * mde_sqrt(x);
+  if constexpr (ECLS == 3) return x * x;
+  if constexpr (ECLS == 4) return x * x * x;
+  if constexpr (ECLS == 5) return mde_sqrt(x);
+  // run-time exponent; the comparisons are wave-uniform (scalar branches)
+  if (e == 1.0f) return x;
+  if (e == 2.0f) return x * x;
+  if (e == 1.5f) return x * mde_sqrt(x);
+  if (e == 3.0f) return x * x * x;
+  if (e == 0.5f) return mde_sqrt(x);
+  if (e == 0.0f) return 1.0f;
+  return mde_exp2(e * mde_log2(x));
+}
+template <int ECLS>
+MDE_DEV float mde_expo(float e) {
+  if constexpr (ECLS == 1) return 1.0f;
+  if constexpr (ECLS == 2) return 1.5f;
+  if constexpr (ECLS == 3) return 2.0f;
+  if constexpr (ECLS == 4) return 3.0f;
+  if constexpr (ECLS == 5) return 0.5f;
+  return e;
+}
+
+template <int KIND, int ECLS>
+MDE_DEV void mde_eval(float ss, float a0, float a1, const MdeScalars& S, float& f, float& gd) {
+  // ---------------------------------------------------------------- penalties (a0 = w)
+  if constexpr (KIND == MDE_F_LINEAR) {  // penalties.py:112-120
+    const float d = mde_sqrt(ss);
+    f = a0 * d;
+    gd = a0 * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_QUADRATIC) {  // penalties.py:123-131
+    f = a0 * ss;
+    gd = 2.0f * a0;
+  } else if constexpr (KIND == MDE_F_CUBIC) {  // penalties.py:163-171
+    const float d = mde_sqrt(ss);
+    f = a0 * ss * d;
+    gd = 3.0f * a0 * d;
+  } else if constexpr (KIND == MDE_F_POWER) {  // penalties.py:191-202
+    const float d = mde_sqrt(ss);
+    const float e = mde_expo<ECLS>(S.s0);
+    const float pe = mde_pow<ECLS>(d, e);
+    f = a0 * pe;
+    gd = a0 * e * pe * mde_rcp(ss);
+  } else if constexpr (KIND == MDE_F_HUBER) {  // penalties.py:205-243 (strict <)
+    const float d = mde_sqrt(ss);
+    const float t = S.s0;
+    const bool lt = d < t;
+    f = lt ? a0 * 0.5f * ss : a0 * t * (d - 0.5f * t);
+    gd = lt ? a0 : a0 * t * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_LOGISTIC) {  // penalties.py:246-266
+    const float d = mde_sqrt(ss);
+    const float z = S.s1 * (d - S.s0);
+    f = a0 * mde_softplus(z);
+    gd = a0 * S.s1 * mde_sigmoid(z) * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_SIGMOID) {  // penalties.py:269-283
+    const float d = mde_sqrt(ss);
+    const float sg = mde_sigmoid(S.s1 * (d - S.s0));
+    f = a0 * sg;
+    gd = a0 * S.s1 * sg * (1.0f - sg) * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_HINGE) {  // penalties.py:286-307
+    const float d = mde_sqrt(ss);
+    const float v = a0 * (d - (S.s0 - mde_sign(a0) * S.s1));
+    f = fmaxf(0.0f, v);
+    const float sub = (v > 0.0f) ? 1.0f : ((v == 0.0f) ? 0.5f : 0.0f);  // torch.max tie -> 1/2
+    gd = sub * a0 * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_LOG1P) {  // penalties.py:310-321
+    const float d = mde_sqrt(ss);
+    const float e = mde_expo<ECLS>(S.s0);
+    const float pe = mde_pow<ECLS>(d, e);
+    f = a0 * mde_log1p(pe);
+    // f' / d = w e d^(e-2) / (1 + d^e)
+    gd = a0 * e * pe * mde_rcp(ss * (1.0f + pe));
+  } else if constexpr (KIND == MDE_F_LOG) {  // penalties.py:324-337
+    const float d = mde_sqrt(ss);
+    const float e = mde_expo<ECLS>(S.s0);
+    const float u = mde_pow<ECLS>(d, e);
+    float em;
+    const float A = mde_one_minus_expneg(u, em);  // -expm1(-u)
+    f = a0 * ((u > 1.0f) ? mde_log1p(-em) : mde_log(A));
+    // d/du log(1-exp(-u)) = exp(-u)/(1-exp(-u)) = 1/expm1(u)
+    gd = a0 * e * u * em * mde_rcp(A * ss);
+  } else if constexpr (KIND == MDE_F_INVPOWER) {  // penalties.py:340-353 (uses |w|)
+    const float d = mde_sqrt(ss);
+    const float e = mde_expo<ECLS>(S.s0);
+    const float pe = mde_pow<ECLS>(d, e);
+    const float aw = fabsf(a0);
+    const float ip = mde_rcp(pe);
+    f = aw * ip;
+    gd = -aw * e * ip * mde_rcp(ss);
+  } else if constexpr (KIND == MDE_F_LOGRATIO) {  // penalties.py:356-369
+    const float d = mde_sqrt(ss);
+    const float e = mde_expo<ECLS>(S.s0);
+    const float pe = mde_pow<ECLS>(d, e);
+    f = -a0 * mde_log1p(mde_rcp(pe));  // log(pe/(1+pe)) = -log1p(1/pe)
+    gd = a0 * e * mde_rcp(ss * (1.0f + pe));
+  } else if constexpr (KIND == MDE_F_DEADZONE_QUADRATIC) {  // penalties.py:134-148
+    const float d = mde_sqrt(ss);
+    const bool lt = d < S.s0;
+    f = lt ? 0.0f * a0 : a0 * ss;
+    gd = lt ? 0.0f * a0 : 2.0f * a0;
+  } else if constexpr (KIND == MDE_F_DEADZONE_CUBIC) {  // penalties.py:174-188
+    const float d = mde_sqrt(ss);
+    const bool lt = d < S.s0;
+    f = lt ? 0.0f * a0 : a0 * ss * d;
+    gd = lt ? 0.0f * a0 : 3.0f * a0 * d;
+  } else if constexpr (KIND == MDE_F_CLIPPED_QUADRATIC) {  // penalties.py:151-160
+    const float c = (S.s0 + 1.0f) * (S.s0 + 1.0f);
+    f = a0 * fminf(ss, c);
+    gd = (ss < c) ? 2.0f * a0 : ((ss == c) ? a0 : 0.0f);
+    // ---------------------------------------------------------------- losses (a0 = delta)
+  } else if constexpr (KIND == MDE_F_L_QUADRATIC) {  // losses.py:61-69
+    const float d = mde_sqrt(ss);
+    const float r = a0 - d;
+    f = r * r;
+    gd = -2.0f * r * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_L_WEIGHTED_QUADRATIC) {  // losses.py:72-87
+    const float d = mde_sqrt(ss);
+    const float r = a0 - d;
+    f = a1 * r * r;
+    gd = -2.0f * a1 * r * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_L_CLIPPED_QUADRATIC) {  // losses.py:90-98
+    const float d = mde_sqrt(ss);
+    const float r = a0 - d;
+    const float c = (S.s0 + 1.0f) * (S.s0 + 1.0f);
+    const float r2 = r * r;
+    f = fminf(r2, c);
+    gd = ((r2 < c) ? 1.0f : ((r2 == c) ? 0.5f : 0.0f)) * -2.0f * r * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_L_HUBER) {  // losses.py:101-125 (strict <)
+    const float d = mde_sqrt(ss);
+    const float r = fabsf(a0 - d);
+    const float sg = mde_sign(d - a0);
+    const float t = S.s0;
+    const bool lt = r < t;
+    f = lt ? r * r : t * (2.0f * r - t);
+    gd = (lt ? 2.0f * r : 2.0f * t) * sg * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_L_CUBIC) {  // losses.py:128-136
+    const float d = mde_sqrt(ss);
+    const float r = fabsf(a0 - d);
+    f = r * r * r;
+    gd = 3.0f * r * r * mde_sign(d - a0) * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_L_POWER) {  // losses.py:139-148
+    const float d = mde_sqrt(ss);
+    const float r = fabsf(a0 - d);
+    const float e = mde_expo<ECLS>(S.s0);
+    const float pe = mde_pow<ECLS>(r, e);
+    f = pe;
+    // e r^(e-1) sign(d - delta); at r == 0 autograd gives e*0^(e-1)*sign(0) = 0 for e >= 1
+    const float rp = (r > 0.0f) ? pe * mde_rcp(r) : ((e >= 1.0f) ? 0.0f : __builtin_nanf(""));
+    gd = e * rp * mde_sign(d - a0) * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_L_WEIGHTED_POWER) {  // losses.py:151-163
+    const float d = mde_sqrt(ss);
+    const float r = fabsf(a0 - d);
+    const float e = mde_expo<ECLS>(S.s0);
+    const float pe = mde_pow<ECLS>(r, e);
+    f = a1 * pe;
+    const float rp = (r > 0.0f) ? pe * mde_rcp(r) : ((e >= 1.0f) ? 0.0f : __builtin_nanf(""));
+    gd = a1 * e * rp * mde_sign(d - a0) * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_L_ABSOLUTE) {  // losses.py:166-174
+    const float d = mde_sqrt(ss);
+    f = fabsf(a0 - d);
+    gd = mde_sign(d - a0) * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_L_LOGISTIC) {  // losses.py:177-186
+    const float d = mde_sqrt(ss);
+    const float r = fabsf(a0 - d);
+    f = mde_softplus(r);
+    gd = mde_sigmoid(r) * mde_sign(d - a0) * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_L_FRACTIONAL) {  // losses.py:189-200
+    const float d = mde_sqrt(ss);
+    const float q1 = a0 * mde_rcp(d), q2 = d * mde_rcp(a0);
+    f = fmaxf(q1, q2) - 1.0f;
+    const float g1 = -a0 * mde_rcp(ss), g2 = mde_rcp(a0);
+    const float fp = (q1 > q2) ? g1 : ((q1 < q2) ? g2 : 0.5f * (g1 + g2));
+    gd = fp * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_L_SOFT_FRACTIONAL) {  // losses.py:203-229
+    const float d = mde_sqrt(ss);
+    const float gm = S.s0;
+    const float q1 = gm * a0 * mde_rcp(d), q2 = gm * d * mde_rcp(a0);
+    const float mx = fmaxf(q1, q2), mn = fminf(q1, q2);
+    const float ex = mde_exp(mn - mx);
+    f = mde_rcp(gm) * (mx + mde_log1p(ex) - (0.6931471805599453f + gm));
+    const float wmx = mde_rcp(1.0f + ex), wmn = ex * wmx;  // softmax weights
+    const float w1 = (q1 >= q2) ? wmx : wmn, w2 = (q1 >= q2) ? wmn : wmx;
+    const float fp = w1 * (-a0 * mde_rcp(ss)) + w2 * mde_rcp(a0);
+    gd = fp * mde_rcp(d);
+  } else {
+    f = 0.0f;
+    gd = 0.0f;
+  }
+}
+
+// run-time dispatch over every kind (used by the universal kernels and by PushAndPull
+// combinations that have no dedicated instantiation)
+MDE_DEV void mde_eval_rt(int kind, float ss, float a0, float a1, const MdeScalars& S, float& f,
+                         float& gd) {
+  switch (kind) {
+#define MDE_CASE(K)                        \
+  case K:                                  \
+    mde_eval<K, 0>(ss, a0, a1, S, f, gd);  \
+    break;
+    MDE_CASE(MDE_F_LINEAR)
+    MDE_CASE(MDE_F_QUADRATIC)
+    MDE_CASE(MDE_F_CUBIC)
+    MDE_CASE(MDE_F_POWER)
+    MDE_CASE(MDE_F_HUBER)
+    MDE_CASE(MDE_F_LOGISTIC)
+    MDE_CASE(MDE_F_SIGMOID)
+    MDE_CASE(MDE_F_HINGE)
+    MDE_CASE(MDE_F_LOG1P)
+    MDE_CASE(MDE_F_LOG)
+    MDE_CASE(MDE_F_INVPOWER)
+    MDE_CASE(MDE_F_LOGRATIO)
+    MDE_CASE(MDE_F_DEADZONE_QUADRATIC)
+    MDE_CASE(MDE_F_DEADZONE_CUBIC)
+    MDE_CASE(MDE_F_CLIPPED_QUADRATIC)
+    MDE_CASE(MDE_F_L_QUADRATIC)
+    MDE_CASE(MDE_F_L_WEIGHTED_QUADRATIC)
+    MDE_CASE(MDE_F_L_HUBER)
+    MDE_CASE(MDE_F_L_CUBIC)
+    MDE_CASE(MDE_F_L_POWER)
+    MDE_CASE(MDE_F_L_WEIGHTED_POWER)
+    MDE_CASE(MDE_F_L_ABSOLUTE)
+    MDE_CASE(MDE_F_L_LOGISTIC)
+    MDE_CASE(MDE_F_L_FRACTIONAL)
+    MDE_CASE(MDE_F_L_SOFT_FRACTIONAL)
+    MDE_CASE(MDE_F_L_CLIPPED_QUADRATIC)
+#undef MDE_CASE
+    default:
+      f = 0.0f;
+      gd = 0.0f;
+  }
+}
+
+static inline bool mde_kind_valid(int kind) {
+  return (kind >= MDE_F_LINEAR && kind <= MDE_F_CLIPPED_QUADRATIC) ||
+         (kind >= MDE_F_L_QUADRATIC && kind <= MDE_F_L_CLIPPED_QUADRATIC);
+}
+
+// ---------------------------------------------------------------- functors used by the kernels
+// A functor carries the scalars and evaluates one edge.  `Fn::eval(ss, a0, a1, f, gd)`.
+struct MdeFuncArgs {
+  int kind, kind_neg;
+  MdeScalars S, N;
+};
+
+// universal: every kind, PushAndPull by sign of the weight (penalties.py:390: w >= 0 attractive)
+struct FnRuntime {
+  MdeFuncArgs A;
+  MDE_DEV void eval(float ss, float a0, float a1, float& f, float& gd) const {
+    if (A.kind_neg != MDE_F_NONE && a0 < 0.0f)
+      mde_eval_rt(A.kind_neg, ss, a0, a1, A.N, f, gd);
+    else
+      mde_eval_rt(A.kind, ss, a0, a1, A.S, f, gd);
+  }
+};
+// one kind, exponent class fixed at compile time
+template <int KIND, int ECLS>
+struct FnSingle {
+  MdeFuncArgs A;
+  MDE_DEV void eval(float ss, float a0, float a1, float& f, float& gd) const {
+    mde_eval<KIND, ECLS>(ss, a0, a1, A.S, f, gd);
+  }
+};
+// PushAndPull with both branches fixed at compile time
+template <int KA, int EA, int KR, int ER>
+struct FnPushPull {
+  MdeFuncArgs A;
+  MDE_DEV void eval(float ss, float a0, float a1, float& f, float& gd) const {
+    if (a0 >= 0.0f)
+      mde_eval<KA, EA>(ss, a0, a1, A.S, f, gd);
+    else
+      mde_eval<KR, ER>(ss, a0, a1, A.N, f, gd);
+  }
+};
+
+MDE_DEV float mde_fix_g(float g) {
+  // average_distortion.py:85-88: NaN -> 1.0, Inf -> 1.0
+  return (fabsf(g) <= 3.402823466e+38f) ? g : 1.0f;
+}
+
+static inline int mde_exp_class(float e) {
+  if (e == 1.0f) return 1;
+  if (e == 1.5f) return 2;
+  if (e == 2.0f) return 3;
+  if (e == 3.0f) return 4;
+  if (e == 0.5f) return 5;
+  return 0;
+}

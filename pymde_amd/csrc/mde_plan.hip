@@ -1,0 +1,356 @@
+// mde_plan.hip -- one-time device preprocessing of an edge list into the symmetrised
+// incidence CSR the hot kernel streams.  Replaces the reference's `edges/_lhs/_rhs`
+// buffers and their validation [ref: pymde/problem.py:129-170,
+// pymde/average_distortion.py:58-59].
+//
+// Layout produced (all int32, device):
+//   rowptr[nloc+1]   offsets of the local rows v = row_lo + r
+//   nbr[H]           neighbour vertex of each half-edge
+//   eid[H]           original edge id of each half-edge (param expansion, fallback path)
+// Half-edges of a row are ordered by original edge id (stable radix sort), so every
+// per-row sum has a fixed order: results are bitwise reproducible.
+#include <hipcub/hipcub.hpp>
+
+#include <stdarg.h>
+
+#include "mde_common.h"
+
+// ---------------------------------------------------------------- error plumbing
+static thread_local std::string g_last_error;
+
+void mde_set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+int mde_hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  mde_set_error("HIP error %d (%s) in `%s` at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+  return MDE_E_HIP;
+}
+extern "C" const char* mde_last_error(void) { return g_last_error.c_str(); }
+extern "C" int mde_abi_version(void) { return MDE_ABI_VERSION; }
+
+// ---------------------------------------------------------------- plan object
+struct mde_plan {
+  int64_t n = 0, p = 0, H = 0, row_lo = 0, row_hi = 0;
+  int32_t* rowptr = nullptr;
+  int32_t* nbr = nullptr;
+  int32_t* eid = nullptr;
+  double* partials = nullptr;  // [MDE_MAX_PARTIALS] loss partial sums of the fused kernel
+  float avg_degree = 0.f;
+};
+
+extern "C" int64_t mde_plan_n(const mde_plan* p) { return p ? p->n : 0; }
+extern "C" int64_t mde_plan_p(const mde_plan* p) { return p ? p->p : 0; }
+extern "C" int64_t mde_plan_half_edges(const mde_plan* p) { return p ? p->H : 0; }
+extern "C" int64_t mde_plan_row_lo(const mde_plan* p) { return p ? p->row_lo : 0; }
+extern "C" int64_t mde_plan_row_hi(const mde_plan* p) { return p ? p->row_hi : 0; }
+extern "C" const int32_t* mde_plan_rowptr(const mde_plan* p) { return p ? p->rowptr : nullptr; }
+extern "C" const int32_t* mde_plan_nbr(const mde_plan* p) { return p ? p->nbr : nullptr; }
+extern "C" const int32_t* mde_plan_eid(const mde_plan* p) { return p ? p->eid : nullptr; }
+
+// internal accessor used by the kernel translation unit
+double* mde_plan_partials(mde_plan* p) { return p->partials; }
+float mde_plan_avg_degree(const mde_plan* p) { return p->avg_degree; }
+
+extern "C" int mde_plan_destroy(mde_plan* plan) {
+  if (!plan) return MDE_OK;
+  if (plan->rowptr) (void)hipFree(plan->rowptr);
+  if (plan->nbr) (void)hipFree(plan->nbr);
+  if (plan->eid) (void)hipFree(plan->eid);
+  if (plan->partials) (void)hipFree(plan->partials);
+  delete plan;
+  return MDE_OK;
+}
+
+// ---------------------------------------------------------------- kernels
+// flags[0] = #self edges, flags[1] = #out-of-range endpoints     [ref: problem.py:134-140]
+__global__ void k_validate(int64_t n, int64_t p, const int64_t* __restrict__ edges, int* flags) {
+  int self = 0, oor = 0;
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < p;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const longlong2 e = reinterpret_cast<const longlong2*>(edges)[k];
+    self += (e.x == e.y);
+    oor += (e.x < 0 || e.x >= n || e.y < 0 || e.y >= n);
+  }
+  self = mde_wave_sum(self);
+  oor = mde_wave_sum(oor);
+  if ((threadIdx.x & 63) == 0) {
+    if (self) atomicAdd(&flags[0], self);
+    if (oor) atomicAdd(&flags[1], oor);
+  }
+}
+
+// half-edge h = 2k + side: side 0 lives in row i (neighbour j), side 1 in row j (neighbour i).
+// key = local row index, or nloc for rows another rank owns.
+__global__ void k_make_keys(int64_t p, const int64_t* __restrict__ edges, int64_t row_lo,
+                            int64_t row_hi, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t nloc = (uint32_t)(row_hi - row_lo);
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < p;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const longlong2 e = reinterpret_cast<const longlong2*>(edges)[k];
+    const uint32_t k0 = (e.x >= row_lo && e.x < row_hi) ? (uint32_t)(e.x - row_lo) : nloc;
+    const uint32_t k1 = (e.y >= row_lo && e.y < row_hi) ? (uint32_t)(e.y - row_lo) : nloc;
+    reinterpret_cast<uint2*>(keys)[k] = make_uint2(k0, k1);
+    reinterpret_cast<uint2*>(vals)[k] = make_uint2((uint32_t)(2 * k), (uint32_t)(2 * k + 1));
+  }
+}
+
+// rowptr[r] = first sorted position whose key >= r, for r = 0..nloc
+__global__ void k_rowptr(int64_t H2, uint32_t nloc, const uint32_t* __restrict__ keys,
+                         int32_t* __restrict__ rowptr) {
+  for (int64_t h = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; h <= H2;
+       h += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t prev = (h == 0) ? -1 : (int64_t)keys[h - 1];
+    int64_t cur = (h == H2) ? (int64_t)nloc : (int64_t)keys[h];
+    if (cur > (int64_t)nloc) cur = nloc;
+    for (int64_t r = prev + 1; r <= cur; ++r) rowptr[r] = (int32_t)h;
+  }
+}
+
+__global__ void k_fill_half_edges(int64_t H, const uint32_t* __restrict__ vals,
+                                  const int64_t* __restrict__ edges, int32_t* __restrict__ nbr,
+                                  int32_t* __restrict__ eid) {
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < H;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t h = vals[q];
+    const uint32_t k = h >> 1;
+    // side 0 -> neighbour is edges[k][1]; side 1 -> neighbour is edges[k][0]
+    const int64_t u = edges[2 * (int64_t)k + (1 - (h & 1))];
+    nbr[q] = (int32_t)u;
+    eid[q] = (int32_t)k;
+  }
+}
+
+__global__ void k_degree(int64_t p, const int64_t* __restrict__ edges, int32_t* __restrict__ deg) {
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < p;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const longlong2 e = reinterpret_cast<const longlong2*>(edges)[k];
+    atomicAdd(&deg[e.x], 1);
+    atomicAdd(&deg[e.y], 1);
+  }
+}
+
+// bounds[r] = smallest v with cum_incl[v-1] >= r * total / world (cum_incl inclusive scan of deg)
+__global__ void k_bounds(int64_t n, int32_t world, const int32_t* __restrict__ cum_incl,
+                         int64_t* __restrict__ bounds) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > world) return;
+  if (r == 0) {
+    bounds[0] = 0;
+    return;
+  }
+  if (r == world) {
+    bounds[world] = n;
+    return;
+  }
+  const int64_t total = cum_incl[n - 1];
+  const int64_t target = (total * r) / world;
+  int64_t lo = 0, hi = n;  // first v with cum_incl[v] >= target
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)cum_incl[mid] >= target)
+      hi = mid;
+    else
+      lo = mid + 1;
+  }
+  bounds[r] = lo + 1 > n ? n : lo + 1;
+}
+
+__global__ void k_expand(int64_t H, const int32_t* __restrict__ eid, const float* __restrict__ in,
+                         float* __restrict__ out) {
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < H;
+       q += (int64_t)gridDim.x * blockDim.x)
+    out[q] = in[eid[q]];
+}
+
+// ---------------------------------------------------------------- host side
+static int validate_edges(int64_t n, int64_t p, const int64_t* edges, hipStream_t st) {
+  int* flags = nullptr;
+  MDE_HIP(hipMalloc(&flags, 2 * sizeof(int)));
+  hipError_t e = hipMemsetAsync(flags, 0, 2 * sizeof(int), st);
+  if (e == hipSuccess && p > 0) {
+    hipLaunchKernelGGL(k_validate, dim3(mde_grid(p, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, n, p, edges,
+                       flags);
+    e = hipGetLastError();
+  }
+  int h[2] = {0, 0};
+  if (e == hipSuccess) e = hipMemcpyAsync(h, flags, sizeof(h), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(flags);
+  if (e != hipSuccess) return mde_hip_fail(e, "validate_edges", __FILE__, __LINE__);
+  if (h[1]) {
+    mde_set_error("%d edge endpoints are outside [0, %lld)", h[1], (long long)n);
+    return MDE_E_RANGE;
+  }
+  if (h[0]) {
+    mde_set_error("The edge list must not contain self edges (%d found)", h[0]);
+    return MDE_E_SELF_EDGE;
+  }
+  return MDE_OK;
+}
+
+static int bits_for(uint64_t maxval) {
+  int b = 1;
+  while (b < 32 && (maxval >> b)) ++b;
+  return b;
+}
+
+extern "C" int mde_plan_create(int64_t n, int64_t p, const int64_t* edges, int64_t row_lo,
+                               int64_t row_hi, void* stream, mde_plan** out) {
+  if (!out) return MDE_E_INVALID;
+  *out = nullptr;
+  if (n <= 0 || p < 0 || (p > 0 && !edges) || row_lo < 0 || row_hi > n || row_lo > row_hi) {
+    mde_set_error("mde_plan_create: invalid arguments (n=%lld p=%lld rows=[%lld,%lld))", (long long)n,
+                  (long long)p, (long long)row_lo, (long long)row_hi);
+    return MDE_E_INVALID;
+  }
+  if (n >= (int64_t)1 << 31 || 2 * p >= ((int64_t)1 << 31) - 1) {
+    mde_set_error("mde_plan_create: n=%lld / p=%lld exceed the int32 plan (n < 2^31, 2p < 2^31)",
+                  (long long)n, (long long)p);
+    return MDE_E_TOO_LARGE;
+  }
+  hipStream_t st = mde_stream(stream);
+  int rc = validate_edges(n, p, edges, st);
+  if (rc != MDE_OK) return rc;
+
+  mde_plan* plan = new mde_plan();
+  plan->n = n;
+  plan->p = p;
+  plan->row_lo = row_lo;
+  plan->row_hi = row_hi;
+  const int64_t nloc = row_hi - row_lo;
+  const int64_t H2 = 2 * p;
+
+  uint32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;
+  void* tmp = nullptr;
+  auto cleanup = [&]() {
+    if (keys) (void)hipFree(keys);
+    if (vals) (void)hipFree(vals);
+    if (keys2) (void)hipFree(keys2);
+    if (vals2) (void)hipFree(vals2);
+    if (tmp) (void)hipFree(tmp);
+  };
+#define PLAN_HIP(call)                                            \
+  do {                                                            \
+    hipError_t e__ = (call);                                      \
+    if (e__ != hipSuccess) {                                      \
+      cleanup();                                                  \
+      mde_plan_destroy(plan);                                     \
+      return mde_hip_fail(e__, #call, __FILE__, __LINE__);        \
+    }                                                             \
+  } while (0)
+
+  PLAN_HIP(hipMalloc(&plan->rowptr, (nloc + 1) * sizeof(int32_t)));
+  PLAN_HIP(hipMalloc(&plan->partials, MDE_MAX_PARTIALS * sizeof(double)));
+  int32_t Hlocal = 0;
+  if (H2 > 0) {
+    const size_t bytes = (size_t)H2 * sizeof(uint32_t);
+    PLAN_HIP(hipMalloc(&keys, bytes));
+    PLAN_HIP(hipMalloc(&vals, bytes));
+    PLAN_HIP(hipMalloc(&keys2, bytes));
+    PLAN_HIP(hipMalloc(&vals2, bytes));
+    hipLaunchKernelGGL(k_make_keys, dim3(mde_grid(p, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, p, edges,
+                       row_lo, row_hi, keys, vals);
+    PLAN_HIP(hipGetLastError());
+    size_t tmp_bytes = 0;
+    const int end_bit = bits_for((uint64_t)nloc);
+    PLAN_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)H2,
+                                                0, end_bit, st));
+    PLAN_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    PLAN_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)H2, 0,
+                                                end_bit, st));
+    hipLaunchKernelGGL(k_rowptr, dim3(mde_grid(H2 + 1, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, H2,
+                       (uint32_t)nloc, keys2, plan->rowptr);
+    PLAN_HIP(hipGetLastError());
+    PLAN_HIP(hipMemcpyAsync(&Hlocal, plan->rowptr + nloc, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    PLAN_HIP(hipStreamSynchronize(st));
+  } else {
+    PLAN_HIP(hipMemsetAsync(plan->rowptr, 0, (nloc + 1) * sizeof(int32_t), st));
+    PLAN_HIP(hipStreamSynchronize(st));
+  }
+  plan->H = Hlocal;
+  plan->avg_degree = nloc > 0 ? (float)((double)Hlocal / (double)nloc) : 0.f;
+  const size_t hb = (size_t)(Hlocal > 0 ? Hlocal : 1) * sizeof(int32_t);
+  PLAN_HIP(hipMalloc(&plan->nbr, hb));
+  PLAN_HIP(hipMalloc(&plan->eid, hb));
+  if (Hlocal > 0) {
+    hipLaunchKernelGGL(k_fill_half_edges, dim3(mde_grid(Hlocal, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st,
+                       (int64_t)Hlocal, vals2, edges, plan->nbr, plan->eid);
+    PLAN_HIP(hipGetLastError());
+  }
+  PLAN_HIP(hipStreamSynchronize(st));
+  cleanup();
+#undef PLAN_HIP
+  *out = plan;
+  return MDE_OK;
+}
+
+extern "C" int mde_shard_bounds(int64_t n, int64_t p, const int64_t* edges, int32_t world,
+                                int64_t* bounds_host, void* stream) {
+  if (n <= 0 || p < 0 || world <= 0 || !bounds_host || (p > 0 && !edges)) return MDE_E_INVALID;
+  if (n >= (int64_t)1 << 31 || 2 * p >= ((int64_t)1 << 31) - 1) return MDE_E_TOO_LARGE;
+  hipStream_t st = mde_stream(stream);
+  int rc = validate_edges(n, p, edges, st);
+  if (rc != MDE_OK) return rc;
+  int32_t *deg = nullptr, *cum = nullptr;
+  int64_t* bounds = nullptr;
+  void* tmp = nullptr;
+  size_t tmp_bytes = 0;
+  hipError_t e = hipMalloc(&deg, n * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&cum, n * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&bounds, (world + 1) * sizeof(int64_t));
+  if (e == hipSuccess) e = hipMemsetAsync(deg, 0, n * sizeof(int32_t), st);
+  if (e == hipSuccess && p > 0) {
+    hipLaunchKernelGGL(k_degree, dim3(mde_grid(p, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, p, edges, deg);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(nullptr, tmp_bytes, deg, cum, (int)n, st);
+  if (e == hipSuccess) e = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+  if (e == hipSuccess) e = hipcub::DeviceScan::InclusiveSum(tmp, tmp_bytes, deg, cum, (int)n, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_bounds, dim3((world + 1 + 63) / 64), dim3(64), 0, st, n, world, cum, bounds);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(bounds_host, bounds, (world + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (deg) (void)hipFree(deg);
+  if (cum) (void)hipFree(cum);
+  if (bounds) (void)hipFree(bounds);
+  if (tmp) (void)hipFree(tmp);
+  if (e != hipSuccess) return mde_hip_fail(e, "mde_shard_bounds", __FILE__, __LINE__);
+  // monotone clean-up (degenerate graphs)
+  for (int r = 1; r <= world; ++r)
+    if (bounds_host[r] < bounds_host[r - 1]) bounds_host[r] = bounds_host[r - 1];
+  bounds_host[world] = n;
+  return MDE_OK;
+}
+
+extern "C" int mde_plan_expand(const mde_plan* plan, const float* in_edge, float* out_half,
+                               void* stream) {
+  if (!plan || !in_edge || !out_half) return MDE_E_INVALID;
+  if (plan->H == 0) return MDE_OK;
+  hipLaunchKernelGGL(k_expand, dim3(mde_grid(plan->H, MDE_BLOCK)), dim3(MDE_BLOCK), 0,
+                     mde_stream(stream), plan->H, plan->eid, in_edge, out_half);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+extern "C" int mde_plan_export(const mde_plan* plan, int32_t* rowptr_out, int32_t* nbr_out,
+                               int32_t* eid_out, void* stream) {
+  if (!plan) return MDE_E_INVALID;
+  hipStream_t st = mde_stream(stream);
+  const int64_t nloc = plan->row_hi - plan->row_lo;
+  if (rowptr_out)
+    MDE_HIP(hipMemcpyAsync(rowptr_out, plan->rowptr, (nloc + 1) * sizeof(int32_t),
+                           hipMemcpyDeviceToDevice, st));
+  if (nbr_out && plan->H > 0)
+    MDE_HIP(hipMemcpyAsync(nbr_out, plan->nbr, plan->H * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  if (eid_out && plan->H > 0)
+    MDE_HIP(hipMemcpyAsync(eid_out, plan->eid, plan->H * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  return MDE_OK;
+}

@@ -1,0 +1,840 @@
+// mde_vec.hip -- the solver-side kernels: constraint projections/retractions, small Gram
+// matrices (f32 MFMA when the widths allow), fused vector statistics, and the device-resident
+// L-BFGS memory.
+//   constraints  [ref: pymde/constraints.py:94-200, pymde/util.py:129-171]
+//   vector ops   [ref: pymde/lbfgs.py:350-376, 461-530; pymde/optim.py:94-147]
+// All reductions are two-stage (block partials in double, one fixed-order final pass): no
+// atomics, bitwise reproducible.
+#include "mde_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------- work buffer layout
+// [0, 4096)                    small scalars / staging
+// [4096, 4096 + 8 d^2)         d x d matrices (Gram result, Newton-Schulz iterates, M)
+// [4096 + 8 d^2, ...)          reduction partials (<= MDE_PARTIAL_DOUBLES)
+#define MDE_SMALL_DOUBLES 4096
+#define MDE_PARTIAL_DOUBLES (4 << 20)
+#define MDE_RED_BLOCKS 256
+
+extern "C" int64_t mde_work_doubles(int32_t d) {
+  const int64_t dd = (int64_t)(d > 0 ? d : 1);
+  return MDE_SMALL_DOUBLES + 8 * dd * dd + MDE_PARTIAL_DOUBLES;
+}
+static inline double* work_mats(double* work) { return work + MDE_SMALL_DOUBLES; }
+static inline double* work_partials(double* work, int d) {
+  return work + MDE_SMALL_DOUBLES + 8 * (int64_t)d * d;
+}
+
+// ---------------------------------------------------------------- generic row reduction
+// out[q] = reduce_b partial[q * nb + b]; mode_mask bit q set -> max, else sum
+__global__ void k_reduce_rows(int nq, int nb, const double* __restrict__ partial,
+                              unsigned long long max_mask, double* __restrict__ out) {
+  __shared__ double smem[8];
+  const int q = blockIdx.x;
+  if (q >= nq) return;
+  const bool is_max = (q < 64) && ((max_mask >> q) & 1ull);
+  double s = is_max ? -1.0e308 : 0.0;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+    const double v = partial[(int64_t)q * nb + b];
+    s = is_max ? (v > s ? v : s) : s + v;
+  }
+  const double r = is_max ? mde_block_max(s, smem) : mde_block_sum(s, smem);
+  if (threadIdx.x == 0) out[q] = r;
+}
+
+// ---------------------------------------------------------------- axpy
+__global__ __launch_bounds__(MDE_BLOCK) void k_axpy(int64_t N, float alpha,
+                                                    const float* __restrict__ x,
+                                                    const float* __restrict__ y,
+                                                    float* __restrict__ out) {
+  const int64_t stride = (int64_t)gridDim.x * MDE_BLOCK;
+  const int64_t N4 = N >> 2;
+  const bool al = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) |
+                    reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  if (al) {
+    for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N4; i += stride) {
+      const float4 a = reinterpret_cast<const float4*>(x)[i];
+      const float4 b = reinterpret_cast<const float4*>(y)[i];
+      reinterpret_cast<float4*>(out)[i] = make_float4(fmaf(alpha, a.x, b.x), fmaf(alpha, a.y, b.y),
+                                                      fmaf(alpha, a.z, b.z), fmaf(alpha, a.w, b.w));
+    }
+    for (int64_t i = (N4 << 2) + (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N; i += stride)
+      out[i] = fmaf(alpha, x[i], y[i]);
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N; i += stride)
+      out[i] = fmaf(alpha, x[i], y[i]);
+  }
+}
+
+extern "C" int mde_axpy(int64_t N, float alpha, const float* x, const float* y, float* out,
+                        void* stream) {
+  if (N < 0 || (N > 0 && (!x || !y || !out))) return MDE_E_INVALID;
+  if (N == 0) return MDE_OK;
+  hipLaunchKernelGGL(k_axpy, dim3(mde_grid((N + 3) / 4, MDE_BLOCK)), dim3(MDE_BLOCK), 0,
+                     mde_stream(stream), N, alpha, x, y, out);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+// ---------------------------------------------------------------- vector statistics
+// partial[q * nb + b], q: 0 g.d 1 g.g 2 sum|g| 3 max|g| 4 #nonfinite 5 d.d 6 max|d| 7 x.x
+__global__ __launch_bounds__(MDE_BLOCK) void k_vec_stats(int64_t N, const float* __restrict__ g,
+                                                         const float* __restrict__ d,
+                                                         const float* __restrict__ x,
+                                                         double* __restrict__ partial) {
+  __shared__ double smem[8];
+  double gd = 0, gg = 0, g1 = 0, gm = 0, nf = 0, dd = 0, dm = 0, xx = 0;
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N;
+       i += (int64_t)gridDim.x * MDE_BLOCK) {
+    const float gv = g[i];
+    const double gvd = gv;
+    gg += gvd * gvd;
+    const double ag = fabs(gvd);
+    g1 += ag;
+    gm = ag > gm ? ag : gm;  // NaN never wins; counted below
+    nf += (fabsf(gv) <= 3.402823466e+38f) ? 0.0 : 1.0;
+    if (d) {
+      const double dv = d[i];
+      gd += gvd * dv;
+      dd += dv * dv;
+      const double ad = fabs(dv);
+      dm = ad > dm ? ad : dm;
+    }
+    if (x) {
+      const double xv = x[i];
+      xx += xv * xv;
+    }
+  }
+  const int nb = gridDim.x, b = blockIdx.x;
+  double r;
+  r = mde_block_sum(gd, smem);
+  if (threadIdx.x == 0) partial[0 * nb + b] = r;
+  r = mde_block_sum(gg, smem);
+  if (threadIdx.x == 0) partial[1 * nb + b] = r;
+  r = mde_block_sum(g1, smem);
+  if (threadIdx.x == 0) partial[2 * nb + b] = r;
+  r = mde_block_max(gm, smem);
+  if (threadIdx.x == 0) partial[3 * nb + b] = r;
+  r = mde_block_sum(nf, smem);
+  if (threadIdx.x == 0) partial[4 * nb + b] = r;
+  r = mde_block_sum(dd, smem);
+  if (threadIdx.x == 0) partial[5 * nb + b] = r;
+  r = mde_block_max(dm, smem);
+  if (threadIdx.x == 0) partial[6 * nb + b] = r;
+  r = mde_block_sum(xx, smem);
+  if (threadIdx.x == 0) partial[7 * nb + b] = r;
+}
+
+static int vec_stats_impl(int64_t N, const float* g, const float* d, const float* x, double* stats,
+                          double* partial, hipStream_t st) {
+  const int nb = mde_grid(N, MDE_BLOCK * 4, MDE_RED_BLOCKS * 4);
+  hipLaunchKernelGGL(k_vec_stats, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, d, x, partial);
+  MDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_reduce_rows, dim3(8), dim3(MDE_BLOCK), 0, st, 8, nb, partial,
+                     (1ull << 3) | (1ull << 6), stats);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+extern "C" int mde_vec_stats(int64_t N, const float* g, const float* d, const float* x,
+                             double* stats, double* work, void* stream) {
+  if (N <= 0 || !g || !stats || !work) return MDE_E_INVALID;
+  return vec_stats_impl(N, g, d, x, stats, work + MDE_SMALL_DOUBLES, mde_stream(stream));
+}
+
+// ---------------------------------------------------------------- column sums / centring
+// threads are laid out (rows_per_pass x dp), dp = pow2 >= min(d,256); coalesced over columns
+__global__ __launch_bounds__(MDE_BLOCK) void k_colsum(int64_t n, int d, int dp,
+                                                      const float* __restrict__ Z,
+                                                      double* __restrict__ partial /* [nb][d] */) {
+  __shared__ double sm[MDE_BLOCK];
+  const int tc = threadIdx.x & (dp - 1);
+  const int tr = threadIdx.x / dp;
+  const int rpp = MDE_BLOCK / dp;
+  for (int c0 = 0; c0 < d; c0 += dp) {
+    const int c = c0 + tc;
+    double s = 0.0;
+    if (c < d)
+      for (int64_t r = (int64_t)blockIdx.x * rpp + tr; r < n; r += (int64_t)gridDim.x * rpp)
+        s += (double)Z[r * d + c];
+    __syncthreads();
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    if (tr == 0 && c < d) {
+      double t = 0.0;
+      for (int k = 0; k < rpp; ++k) t += sm[k * dp + tc];
+      partial[(int64_t)blockIdx.x * d + c] = t;
+    }
+  }
+}
+// mean[c] = (sum_b partial[b][c]) / n
+__global__ void k_colsum_final(int nb, int d, int64_t n, const double* __restrict__ partial,
+                               double* __restrict__ mean) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d) return;
+  double s = 0.0;
+  for (int b = 0; b < nb; ++b) s += partial[(int64_t)b * d + c];
+  mean[c] = s / (double)n;
+}
+__global__ __launch_bounds__(MDE_BLOCK) void k_sub_mean(int64_t N, int d, float* __restrict__ Z,
+                                                        const double* __restrict__ mean) {
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N;
+       i += (int64_t)gridDim.x * MDE_BLOCK)
+    Z[i] = (float)((double)Z[i] - mean[i % d]);
+}
+
+static int pow2_ge(int x) {
+  int p = 1;
+  while (p < x) p <<= 1;
+  return p;
+}
+
+static int center_impl(int64_t n, int d, float* Z, double* work, hipStream_t st) {
+  double* mean = work;  // d doubles (d <= 2048 fits the small area)
+  double* partial = work_partials(work, d);
+  int dp = pow2_ge(d);
+  if (dp > MDE_BLOCK) dp = MDE_BLOCK;
+  const int rpp = MDE_BLOCK / dp;
+  int nb = mde_grid(n, rpp * 8, MDE_RED_BLOCKS);
+  hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(MDE_BLOCK), 0, st, n, d, dp, Z, partial);
+  MDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_colsum_final, dim3((d + 63) / 64), dim3(64), 0, st, nb, d, n, partial, mean);
+  MDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sub_mean, dim3(mde_grid(n * d, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, n * d, d, Z,
+                     mean);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+extern "C" int mde_center(int64_t n, int32_t d, float* Z, double* work, void* stream) {
+  if (n <= 0 || d <= 0 || d > 2048 || !Z || !work) return MDE_E_INVALID;
+  return center_impl(n, d, Z, work, mde_stream(stream));
+}
+
+// ---------------------------------------------------------------- anchors
+__global__ void k_anchor_rows(int64_t na, int d, const int64_t* __restrict__ anchors,
+                              const float* __restrict__ values, float* __restrict__ Z) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na * d;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t a = i / d;
+    const int c = (int)(i % d);
+    Z[anchors[a] * d + c] = values ? values[i] : 0.0f;
+  }
+}
+extern "C" int mde_anchor_rows(int64_t n_anchors, int32_t d, const int64_t* anchors,
+                               const float* values, float* Z, void* stream) {
+  if (n_anchors < 0 || d <= 0 || (n_anchors > 0 && (!anchors || !Z))) return MDE_E_INVALID;
+  if (n_anchors == 0) return MDE_OK;
+  hipLaunchKernelGGL(k_anchor_rows, dim3(mde_grid(n_anchors * d, MDE_BLOCK)), dim3(MDE_BLOCK), 0,
+                     mde_stream(stream), n_anchors, d, anchors, values, Z);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+// ---------------------------------------------------------------- Gram matrices  out = A^T B
+// (a) tiny widths: one thread per row, da*db register accumulators in double
+template <int DA, int DB>
+__global__ __launch_bounds__(MDE_BLOCK) void k_gram_tiny(int64_t n, const float* __restrict__ A,
+                                                         const float* __restrict__ B,
+                                                         double* __restrict__ partial /*[m][nb]*/) {
+  __shared__ double smem[8];
+  double acc[DA * DB];
+#pragma unroll
+  for (int i = 0; i < DA * DB; ++i) acc[i] = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; r < n;
+       r += (int64_t)gridDim.x * MDE_BLOCK) {
+    double a[DA], b[DB];
+#pragma unroll
+    for (int i = 0; i < DA; ++i) a[i] = A[r * DA + i];
+#pragma unroll
+    for (int j = 0; j < DB; ++j) b[j] = B[r * DB + j];
+#pragma unroll
+    for (int i = 0; i < DA; ++i)
+#pragma unroll
+      for (int j = 0; j < DB; ++j) acc[i * DB + j] = fma(a[i], b[j], acc[i * DB + j]);
+  }
+#pragma unroll
+  for (int q = 0; q < DA * DB; ++q) {
+    const double r = mde_block_sum(acc[q], smem);
+    if (threadIdx.x == 0) partial[(int64_t)q * gridDim.x + blockIdx.x] = r;
+  }
+}
+
+// (b) any widths: 16x16 output tile per block, rows split into chunks (grid.y)
+__global__ __launch_bounds__(MDE_BLOCK) void k_gram_generic(int64_t n, int da, int db,
+                                                            const float* __restrict__ A,
+                                                            const float* __restrict__ B,
+                                                            int64_t rows_per_chunk, int tiles_j,
+                                                            double* __restrict__ partial /*[m][nc]*/) {
+  const int ti = blockIdx.x / tiles_j, tj = blockIdx.x % tiles_j;
+  const int i = ti * 16 + (threadIdx.x >> 4), j = tj * 16 + (threadIdx.x & 15);
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+  int64_t r1 = r0 + rows_per_chunk;
+  if (r1 > n) r1 = n;
+  double acc = 0.0;
+  if (i < da && j < db)
+    for (int64_t r = r0; r < r1; ++r) acc = fma((double)A[r * da + i], (double)B[r * db + j], acc);
+  if (i < da && j < db) partial[((int64_t)i * db + j) * gridDim.y + blockIdx.y] = acc;
+}
+
+// (c) widths that are multiples of 32: f32 MFMA (v_mfma_f32_32x32x2_f32), one 32x32 output tile
+// per wave, k = rows of the chunk.  A-operand lane l: A[r + (l>>5)][ti*32 + (l&31)], B alike:
+// both are fully coalesced 128-byte row segments.  C/D map: col = l&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  Accumulates in f32 over <= 4096 rows per chunk, the
+// chunk partials are then summed in double.
+__global__ __launch_bounds__(MDE_BLOCK) void k_gram_mfma(int64_t n, int da, int db,
+                                                         const float* __restrict__ A,
+                                                         const float* __restrict__ B,
+                                                         int64_t rows_per_chunk, int tiles_j,
+                                                         int ntiles,
+                                                         double* __restrict__ partial /*[m][nc]*/) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  const int ti = tile / tiles_j, tj = tile % tiles_j;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+  int64_t r1 = r0 + rows_per_chunk;
+  if (r1 > n) r1 = n;
+  const int kk = lane >> 5, cc = lane & 31;
+  const float* pa = A + (int64_t)ti * 32 + cc;
+  const float* pb = B + (int64_t)tj * 32 + cc;
+  f32x16 acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+  for (int64_t r = r0; r < r1; r += 2) {
+    const int64_t rr = r + kk;
+    const bool ok = rr < r1;
+    const float a = ok ? pa[rr * da] : 0.0f;
+    const float b = ok ? pb[rr * db] : 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int row = (q & 3) + 8 * (q >> 2) + 4 * kk;
+    const int i = ti * 32 + row, j = tj * 32 + cc;
+    partial[((int64_t)i * db + j) * gridDim.y + blockIdx.y] = (double)acc[q];
+  }
+}
+
+// out[q] = sum_c partial[q * nc + c]
+__global__ void k_gram_final(int64_t m, int nc, const double* __restrict__ partial,
+                             double* __restrict__ out) {
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < m;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int c = 0; c < nc; ++c) s += partial[q * nc + c];
+    out[q] = s;
+  }
+}
+
+static int g_no_mfma = -1;
+static int gram_impl(int64_t n, int da, int db, const float* A, const float* B, double* out,
+                     double* partial, hipStream_t st) {
+  const int64_t m = (int64_t)da * db;
+  if (g_no_mfma < 0) {
+    const char* e = getenv("MDE_NO_MFMA");
+    g_no_mfma = (e && atoi(e)) ? 1 : 0;
+  }
+#define TINY(DA_, DB_)                                                                              \
+  if (da == DA_ && db == DB_) {                                                                     \
+    const int nb = mde_grid(n, MDE_BLOCK * 2, MDE_RED_BLOCKS);                                      \
+    hipLaunchKernelGGL((k_gram_tiny<DA_, DB_>), dim3(nb), dim3(MDE_BLOCK), 0, st, n, A, B, partial); \
+    MDE_LAUNCH_CHECK();                                                                             \
+    hipLaunchKernelGGL(k_gram_final, dim3(1), dim3(64), 0, st, m, nb, partial, out);                \
+    MDE_LAUNCH_CHECK();                                                                             \
+    return MDE_OK;                                                                                  \
+  }
+  TINY(1, 1) TINY(2, 2) TINY(3, 3) TINY(4, 4)
+#undef TINY
+  // chunking: as many row chunks as the partial area holds, at most 256, >= 2 rows each
+  int64_t nc = MDE_PARTIAL_DOUBLES / m;
+  if (nc > 256) nc = 256;
+  if (nc < 1) {
+    mde_set_error("gram: %d x %d output does not fit the work buffer", da, db);
+    return MDE_E_UNSUPPORTED;
+  }
+  int64_t rpc = (n + nc - 1) / nc;
+  if (rpc < 64) rpc = 64;
+  const bool mfma = !g_no_mfma && (da % 32 == 0) && (db % 32 == 0);
+  if (mfma) {
+    if (rpc > 4096) rpc = 4096;  // bound the f32 accumulation length
+    rpc = (rpc + 1) & ~(int64_t)1;
+  }
+  nc = (n + rpc - 1) / rpc;
+  if (mfma && nc * m > MDE_PARTIAL_DOUBLES) {
+    // too many chunks for the partial area: lengthen chunks
+    nc = MDE_PARTIAL_DOUBLES / m;
+    rpc = ((n + nc - 1) / nc + 1) & ~(int64_t)1;
+    nc = (n + rpc - 1) / rpc;
+  }
+  if (mfma) {
+    const int tiles_j = db / 32, ntiles = (da / 32) * tiles_j;
+    hipLaunchKernelGGL(k_gram_mfma, dim3((ntiles + 3) / 4, (unsigned)nc), dim3(MDE_BLOCK), 0, st, n, da,
+                       db, A, B, rpc, tiles_j, ntiles, partial);
+  } else {
+    const int tiles_i = (da + 15) / 16, tiles_j = (db + 15) / 16;
+    hipLaunchKernelGGL(k_gram_generic, dim3(tiles_i * tiles_j, (unsigned)nc), dim3(MDE_BLOCK), 0, st, n,
+                       da, db, A, B, rpc, tiles_j, partial);
+  }
+  MDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_gram_final, dim3(mde_grid(m, 256, 256)), dim3(256), 0, st, m, (int)nc, partial,
+                     out);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+extern "C" int mde_gram(int64_t n, int32_t da, int32_t db, const float* A, const float* B, double* out,
+                        double* work, void* stream) {
+  if (n <= 0 || da <= 0 || db <= 0 || !A || !B || !out || !work) return MDE_E_INVALID;
+  const int dm = da > db ? da : db;
+  return gram_impl(n, da, db, A, B, out, work_partials(work, dm), mde_stream(stream));
+}
+
+// ---------------------------------------------------------------- Z (+)= alpha * A M
+// out[r][j] = (base ? base[r][j] : 0) + alpha * sum_c A[r][c] M[c][j].   out may alias A or base.
+template <int D>
+__global__ __launch_bounds__(MDE_BLOCK) void k_rmul_tiny(int64_t n, const float* __restrict__ A,
+                                                         const double* __restrict__ M, float alpha,
+                                                         const float* base, float* out) {
+  float m[D * D];
+#pragma unroll
+  for (int i = 0; i < D * D; ++i) m[i] = (float)(M[i] * (double)alpha);
+  for (int64_t r = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; r < n;
+       r += (int64_t)gridDim.x * MDE_BLOCK) {
+    float a[D], o[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) a[c] = A[r * D + c];
+#pragma unroll
+    for (int j = 0; j < D; ++j) o[j] = base ? base[r * D + j] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+#pragma unroll
+      for (int j = 0; j < D; ++j) o[j] = fmaf(a[c], m[c * D + j], o[j]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) out[r * D + j] = o[j];
+  }
+}
+
+__global__ __launch_bounds__(MDE_BLOCK) void k_rmul_generic(int64_t n, int d, int d2, int rows_tile,
+                                                            const float* __restrict__ A,
+                                                            const double* __restrict__ M, float alpha,
+                                                            const float* base, float* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sa = reinterpret_cast<float*>(smem_raw);  // [rows_tile][d]
+  for (int64_t t0 = (int64_t)blockIdx.x * rows_tile; t0 < n; t0 += (int64_t)gridDim.x * rows_tile) {
+    int64_t rows = n - t0;
+    if (rows > rows_tile) rows = rows_tile;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < rows * d; i += MDE_BLOCK) sa[i] = A[t0 * d + i];
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < rows * d2; i += MDE_BLOCK) {
+      const int64_t r = i / d2;
+      const int j = (int)(i % d2);
+      float acc = 0.0f;
+      for (int c = 0; c < d; ++c) acc = fmaf(sa[r * d + c], (float)M[(int64_t)c * d2 + j], acc);
+      const float b = base ? base[(t0 + r) * d2 + j] : 0.0f;
+      out[(t0 + r) * d2 + j] = fmaf(alpha, acc, b);
+    }
+  }
+}
+
+static int rmul_impl(int64_t n, int d, int d2, const float* A, const double* M, float alpha,
+                     const float* base, float* out, hipStream_t st) {
+#define RT(D_)                                                                                     \
+  if (d == D_ && d2 == D_) {                                                                       \
+    hipLaunchKernelGGL((k_rmul_tiny<D_>), dim3(mde_grid(n, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, n, A, \
+                       M, alpha, base, out);                                                       \
+    MDE_LAUNCH_CHECK();                                                                            \
+    return MDE_OK;                                                                                 \
+  }
+  RT(1) RT(2) RT(3) RT(4)
+#undef RT
+  int rows_tile = 8192 / d;
+  if (rows_tile < 1) rows_tile = 1;
+  if (rows_tile > 64) rows_tile = 64;
+  const size_t lds = (size_t)rows_tile * d * sizeof(float);
+  hipLaunchKernelGGL(k_rmul_generic, dim3(mde_grid(n, rows_tile, 2048)), dim3(MDE_BLOCK), lds, st, n, d,
+                     d2, rows_tile, A, M, alpha, base, out);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+extern "C" int mde_right_multiply(int64_t n, int32_t d, int32_t d2, const float* A, const double* M,
+                                  float* out, void* stream) {
+  if (n <= 0 || d <= 0 || d2 <= 0 || d > 8192 || !A || !M || !out) return MDE_E_INVALID;
+  if (A == out && d != d2) return MDE_E_INVALID;
+  return rmul_impl(n, d, d2, A, M, 1.0f, nullptr, out, mde_stream(stream));
+}
+
+// ---------------------------------------------------------------- Standardized: tangent space
+// Z -= (1/n) X (Z^T X)                                    [ref: constraints.py:186-192]
+extern "C" int mde_std_tangent(int64_t n, int32_t d, const float* X, float* Z, double* work,
+                               void* stream) {
+  if (n <= 0 || d <= 0 || d > 2048 || !X || !Z || !work) return MDE_E_INVALID;
+  hipStream_t st = mde_stream(stream);
+  double* G = work_mats(work);  // d x d : G[i][j] = sum_r Z[r][i] X[r][j]
+  int rc = gram_impl(n, d, d, Z, X, G, work_partials(work, d), st);
+  if (rc != MDE_OK) return rc;
+  return rmul_impl(n, d, d, X, G, (float)(-1.0 / (double)n), Z, Z, st);
+}
+
+// ---------------------------------------------------------------- C^{-1/2} of a small SPD matrix
+// One workgroup.  d = 1, 2: closed form.  d >= 3: coupled Newton-Schulz iteration in double
+//   Y0 = C/s, Z0 = I;  T = (3I - Z Y)/2;  Y <- Y T;  Z <- T Z;   Z -> (C/s)^{-1/2}
+// with s = ||C||_F.  M = out_scale * C^{-1/2}.  status != 0: C not numerically SPD.
+__global__ __launch_bounds__(MDE_BLOCK) void k_invsqrt(int d, const double* __restrict__ C,
+                                                       double out_scale, double* __restrict__ M,
+                                                       double* __restrict__ scratch /* 5 d^2 */,
+                                                       int32_t* __restrict__ status) {
+  __shared__ double smem[8];
+  __shared__ double sh_val;
+  __shared__ int sh_done;
+  const int tid = threadIdx.x;
+  const int m = d * d;
+  if (d == 1) {
+    if (tid == 0) {
+      const double c = C[0];
+      const bool ok = c > 0.0 && c < 1e300;
+      M[0] = ok ? out_scale / sqrt(c) : 0.0;
+      if (status && !ok) *status = 1;
+    }
+    return;
+  }
+  if (d == 2) {
+    if (tid == 0) {
+      const double a = C[0], b = 0.5 * (C[1] + C[2]), c = C[3];
+      const double det = a * c - b * b, tr = a + c;
+      const bool ok = det > 0.0 && tr > 0.0 && det < 1e300;
+      if (ok) {
+        const double s = sqrt(det), t = sqrt(tr + 2.0 * s);
+        const double k = out_scale / (s * t);
+        M[0] = (c + s) * k;
+        M[1] = -b * k;
+        M[2] = -b * k;
+        M[3] = (a + s) * k;
+      } else {
+        M[0] = M[1] = M[2] = M[3] = 0.0;
+        if (status) *status = 1;
+      }
+    }
+    return;
+  }
+  double* Y = scratch;
+  double* Z = scratch + m;
+  double* T = scratch + 2 * (int64_t)m;
+  double* Yn = scratch + 3 * (int64_t)m;
+  double* Zn = scratch + 4 * (int64_t)m;
+  // s = ||C||_F
+  double ss = 0.0;
+  for (int i = tid; i < m; i += MDE_BLOCK) ss += C[i] * C[i];
+  const double tot = mde_block_sum(ss, smem);
+  if (tid == 0) sh_val = sqrt(tot);
+  __syncthreads();
+  const double s = sh_val;
+  if (!(s > 0.0) || !(s < 1e300)) {
+    for (int i = tid; i < m; i += MDE_BLOCK) M[i] = 0.0;
+    if (tid == 0 && status) *status = 1;
+    return;
+  }
+  for (int i = tid; i < m; i += MDE_BLOCK) {
+    const int r = i / d, c = i % d;
+    Y[i] = 0.5 * (C[i] + C[c * d + r]) / s;  // symmetrise
+    Z[i] = (r == c) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  bool converged = false;
+  for (int it = 0; it < 200; ++it) {
+    // T = (3I - Z Y)/2, residual = max |I - Z Y|
+    double res = 0.0;
+    for (int i = tid; i < m; i += MDE_BLOCK) {
+      const int r = i / d, c = i % d;
+      double acc = 0.0;
+      for (int k = 0; k < d; ++k) acc = fma(Z[r * d + k], Y[k * d + c], acc);
+      const double e = ((r == c) ? 1.0 : 0.0) - acc;
+      res = fabs(e) > res ? fabs(e) : res;
+      T[i] = ((r == c) ? 1.0 : 0.0) + 0.5 * e;
+    }
+    const double rmax = mde_block_max(res, smem);
+    if (tid == 0) sh_done = (rmax < 1e-13) ? 1 : ((rmax == rmax && rmax < 1e300) ? 0 : 2);
+    __syncthreads();
+    if (sh_done == 1) {
+      converged = true;
+      break;
+    }
+    if (sh_done == 2) break;
+    for (int i = tid; i < m; i += MDE_BLOCK) {
+      const int r = i / d, c = i % d;
+      double ay = 0.0, az = 0.0;
+      for (int k = 0; k < d; ++k) {
+        ay = fma(Y[r * d + k], T[k * d + c], ay);
+        az = fma(T[r * d + k], Z[k * d + c], az);
+      }
+      Yn[i] = ay;
+      Zn[i] = az;
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += MDE_BLOCK) {
+      Y[i] = Yn[i];
+      Z[i] = Zn[i];
+    }
+    __syncthreads();
+  }
+  const double k = out_scale / sqrt(s);
+  for (int i = tid; i < m; i += MDE_BLOCK) M[i] = converged ? Z[i] * k : 0.0;
+  if (tid == 0 && status && !converged) *status = 1;
+}
+
+// Z <- sqrt(n) (Z - mean) C^{-1/2},  C = (Z-mean)^T (Z-mean)          [ref: util.py:129-161]
+// (= sqrt(n) U V^T of the thin SVD Z - mean = U S V^T, the reference's formula.)
+extern "C" int mde_std_retract(int64_t n, int32_t d, float* Z, int32_t demean, double* work,
+                               int32_t* status_dev, void* stream) {
+  if (n <= 0 || d <= 0 || d > 2048 || !Z || !work) return MDE_E_INVALID;
+  hipStream_t st = mde_stream(stream);
+  int rc = MDE_OK;
+  if (demean) {
+    rc = center_impl(n, d, Z, work, st);
+    if (rc != MDE_OK) return rc;
+  }
+  double* mats = work_mats(work);
+  const int64_t m = (int64_t)d * d;
+  double* C = mats;
+  double* M = mats + m;
+  double* scratch = mats + 2 * m;  // 5 m
+  rc = gram_impl(n, d, d, Z, Z, C, work_partials(work, d), st);
+  if (rc != MDE_OK) return rc;
+  hipLaunchKernelGGL(k_invsqrt, dim3(1), dim3(MDE_BLOCK), 0, st, d, C, sqrt((double)n), M, scratch,
+                     status_dev);
+  MDE_LAUNCH_CHECK();
+  return rmul_impl(n, d, d, Z, M, 1.0f, nullptr, Z, st);
+}
+
+// ---------------------------------------------------------------- L-BFGS memory
+#define MDE_LB_GROUP 8
+struct LbPtrs {
+  const float* s[MDE_LB_GROUP];
+  const float* y[MDE_LB_GROUP];
+  float cs[MDE_LB_GROUP];
+  float cy[MDE_LB_GROUP];
+  int count;
+};
+
+struct mde_lbfgs {
+  int64_t N = 0;
+  int history = 0;
+  float* buf = nullptr;  // 2 (history+1) N floats
+  int order[64];         // slot ids, oldest first
+  int count = 0;
+  int spare = 0;
+  bool staged = false;
+  float* S(int slot) const { return buf + (int64_t)(2 * slot) * N; }
+  float* Y(int slot) const { return buf + (int64_t)(2 * slot + 1) * N; }
+};
+
+extern "C" int mde_lbfgs_create(int64_t N, int32_t history, mde_lbfgs** out) {
+  if (!out || N <= 0 || history <= 0 || history > 63) return MDE_E_INVALID;
+  mde_lbfgs* o = new mde_lbfgs();
+  o->N = N;
+  o->history = history;
+  hipError_t e = hipMalloc(&o->buf, sizeof(float) * 2 * (size_t)(history + 1) * (size_t)N);
+  if (e != hipSuccess) {
+    delete o;
+    return mde_hip_fail(e, "hipMalloc(lbfgs history)", __FILE__, __LINE__);
+  }
+  o->count = 0;
+  o->spare = 0;
+  *out = o;
+  return MDE_OK;
+}
+extern "C" int mde_lbfgs_destroy(mde_lbfgs* o) {
+  if (!o) return MDE_OK;
+  if (o->buf) (void)hipFree(o->buf);
+  delete o;
+  return MDE_OK;
+}
+extern "C" int mde_lbfgs_reset(mde_lbfgs* o) {
+  if (!o) return MDE_E_INVALID;
+  o->count = 0;
+  o->spare = 0;
+  o->staged = false;
+  return MDE_OK;
+}
+extern "C" int32_t mde_lbfgs_count(const mde_lbfgs* o) { return o ? o->count : 0; }
+
+// first launch (FIRST): forms y* = g - g_prev, s* = t d, writes them to the spare slot, sets
+// g_prev <- g, and accumulates the 4 base dots; every launch accumulates, for its <= 8 stored
+// pairs, the 5 dots against (y*, s*, g).  partial[q * nb + b].
+template <bool FIRST>
+__global__ __launch_bounds__(MDE_BLOCK) void k_lbfgs_stage(int64_t N, const float* __restrict__ g,
+                                                           float* __restrict__ g_prev,
+                                                           const float* __restrict__ d, float t,
+                                                           float* __restrict__ s_new,
+                                                           float* __restrict__ y_new, LbPtrs P,
+                                                           int qbase, double* __restrict__ partial) {
+  __shared__ double smem[8];
+  double base[4] = {0, 0, 0, 0};
+  double acc[MDE_LB_GROUP][5];
+#pragma unroll
+  for (int j = 0; j < MDE_LB_GROUP; ++j)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) acc[j][q] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N;
+       i += (int64_t)gridDim.x * MDE_BLOCK) {
+    const float gv = g[i];
+    float yv, sv;
+    if constexpr (FIRST) {
+      yv = gv - g_prev[i];
+      sv = t * d[i];
+      y_new[i] = yv;
+      s_new[i] = sv;
+      g_prev[i] = gv;
+      base[0] = fma((double)yv, (double)sv, base[0]);
+      base[1] = fma((double)yv, (double)yv, base[1]);
+      base[2] = fma((double)sv, (double)gv, base[2]);
+      base[3] = fma((double)yv, (double)gv, base[3]);
+    } else {
+      yv = y_new[i];
+      sv = s_new[i];
+    }
+#pragma unroll
+    for (int j = 0; j < MDE_LB_GROUP; ++j) {
+      if (j < P.count) {
+        const double sj = P.s[j][i], yj = P.y[j][i];
+        acc[j][0] = fma(sj, (double)yv, acc[j][0]);  // s_j . y*
+        acc[j][1] = fma(yj, (double)yv, acc[j][1]);  // y_j . y*
+        acc[j][2] = fma((double)sv, yj, acc[j][2]);  // s* . y_j
+        acc[j][3] = fma(sj, (double)gv, acc[j][3]);  // s_j . g
+        acc[j][4] = fma(yj, (double)gv, acc[j][4]);  // y_j . g
+      }
+    }
+  }
+  const int nb = gridDim.x, b = blockIdx.x;
+  if constexpr (FIRST) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double r = mde_block_sum(base[q], smem);
+      if (threadIdx.x == 0) partial[(int64_t)q * nb + b] = r;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < MDE_LB_GROUP; ++j) {
+    if (j < P.count) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const double r = mde_block_sum(acc[j][q], smem);
+        if (threadIdx.x == 0) partial[(int64_t)(qbase + 5 * j + q) * nb + b] = r;
+      }
+    }
+  }
+}
+
+extern "C" int mde_lbfgs_stage(mde_lbfgs* o, const float* g, float* g_prev, const float* d, float t,
+                               double* dots, double* work, void* stream) {
+  if (!o || !g || !g_prev || !d || !dots || !work) return MDE_E_INVALID;
+  hipStream_t st = mde_stream(stream);
+  const int64_t N = o->N;
+  const int nb = mde_grid(N, MDE_BLOCK * 4, 512);
+  double* partial = work + MDE_SMALL_DOUBLES;
+  float* s_new = o->S(o->spare);
+  float* y_new = o->Y(o->spare);
+  int done = 0;
+  bool first = true;
+  do {
+    LbPtrs P;
+    P.count = o->count - done;
+    if (P.count > MDE_LB_GROUP) P.count = MDE_LB_GROUP;
+    for (int j = 0; j < MDE_LB_GROUP; ++j) {
+      const int slot = (j < P.count) ? o->order[done + j] : 0;
+      P.s[j] = o->S(slot);
+      P.y[j] = o->Y(slot);
+      P.cs[j] = P.cy[j] = 0.f;
+    }
+    const int qbase = 4 + 5 * done;
+    if (first)
+      hipLaunchKernelGGL((k_lbfgs_stage<true>), dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t,
+                         s_new, y_new, P, qbase, partial);
+    else
+      hipLaunchKernelGGL((k_lbfgs_stage<false>), dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t,
+                         s_new, y_new, P, qbase, partial);
+    MDE_LAUNCH_CHECK();
+    first = false;
+    done += P.count;
+  } while (done < o->count);
+  const int nq = 4 + 5 * o->count;
+  hipLaunchKernelGGL(k_reduce_rows, dim3(nq), dim3(MDE_BLOCK), 0, st, nq, nb, partial, 0ull, dots);
+  MDE_LAUNCH_CHECK();
+  o->staged = true;
+  return MDE_OK;
+}
+
+extern "C" int mde_lbfgs_commit(mde_lbfgs* o, int32_t accept) {
+  if (!o) return MDE_E_INVALID;
+  if (!o->staged) {
+    mde_set_error("mde_lbfgs_commit without a staged pair");
+    return MDE_E_INVALID;
+  }
+  o->staged = false;
+  if (!accept) return MDE_OK;
+  const int new_slot = o->spare;
+  if (o->count == o->history) {
+    // drop the oldest: its slot becomes the spare   (lbfgs.py:474-478)
+    o->spare = o->order[0];
+    for (int i = 1; i < o->count; ++i) o->order[i - 1] = o->order[i];
+    o->order[o->count - 1] = new_slot;
+  } else {
+    o->order[o->count++] = new_slot;
+    // next unused slot id
+    bool used[64] = {false};
+    for (int i = 0; i < o->count; ++i) used[o->order[i]] = true;
+    int sp = 0;
+    while (used[sp]) ++sp;
+    o->spare = sp;
+  }
+  return MDE_OK;
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(MDE_BLOCK) void k_lbfgs_combine(int64_t N, const float* __restrict__ g,
+                                                             float c_g, LbPtrs P,
+                                                             float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N;
+       i += (int64_t)gridDim.x * MDE_BLOCK) {
+    float v = FIRST ? c_g * g[i] : out[i];
+#pragma unroll
+    for (int j = 0; j < MDE_LB_GROUP; ++j)
+      if (j < P.count) v = fmaf(P.cy[j], P.y[j][i], fmaf(P.cs[j], P.s[j][i], v));
+    out[i] = v;
+  }
+}
+
+extern "C" int mde_lbfgs_combine(mde_lbfgs* o, const float* g, float c_g, const float* cs,
+                                 const float* cy, float* d_out, double* stats, double* work,
+                                 void* stream) {
+  if (!o || !g || !d_out || !stats || !work || (o->count > 0 && (!cs || !cy))) return MDE_E_INVALID;
+  hipStream_t st = mde_stream(stream);
+  const int64_t N = o->N;
+  const int nb = mde_grid(N, MDE_BLOCK * 2, 2048);
+  int done = 0;
+  bool first = true;
+  do {
+    LbPtrs P;
+    P.count = o->count - done;
+    if (P.count > MDE_LB_GROUP) P.count = MDE_LB_GROUP;
+    for (int j = 0; j < MDE_LB_GROUP; ++j) {
+      const int slot = (j < P.count) ? o->order[done + j] : 0;
+      P.s[j] = o->S(slot);
+      P.y[j] = o->Y(slot);
+      P.cs[j] = (j < P.count) ? cs[done + j] : 0.f;
+      P.cy[j] = (j < P.count) ? cy[done + j] : 0.f;
+    }
+    if (first)
+      hipLaunchKernelGGL((k_lbfgs_combine<true>), dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, c_g, P, d_out);
+    else
+      hipLaunchKernelGGL((k_lbfgs_combine<false>), dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, c_g, P,
+                         d_out);
+    MDE_LAUNCH_CHECK();
+    first = false;
+    done += P.count;
+  } while (done < o->count);
+  return vec_stats_impl(N, g, d_out, nullptr, stats, work + MDE_SMALL_DOUBLES, st);
+}

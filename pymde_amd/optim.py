@@ -1,0 +1,389 @@
+"""The projected quasi-Newton solve loop on the GPU.
+
+``lbfgs(...)`` keeps the signature and semantics of the reference's ``pymde.optim.lbfgs``
+[ref: pymde/optim.py:69-184] (driven by ``MDE.embed``, problem.py:497-510) and
+``SolveStats`` is the same record [ref: optim.py:11-66]; the implementation is not a
+torch.optim optimizer: iterate, trial point, gradient, direction and the L-BFGS history
+live in device buffers, every vector operation is a kernel of ``csrc/mde_vec.hip``, and the
+host receives ONE small read-back per objective evaluation (loss, g.d, |g|, finiteness) plus
+one per iteration (the inner products of the history update) -- the reference synchronises
+>= 12 times per iteration.
+
+Behaviours reproduced from the reference: retraction inside every
+line-search trial and after the accepted step; the L-BFGS pair uses the unprojected
+s = t d; the gradient seen at the next step is that of the LAST EVALUATED trial while the
+loss is that of the accepted one (lbfgs.py:434 vs :550); convergence is tested on the
+gradient recorded at the start of the step; first step t = min(1, 1/|g|_1); ``t == 0``
+resets the memory.
+"""
+import ctypes
+import math
+import time
+
+import numpy as np
+import torch
+
+from pymde_amd import _lib
+from pymde_amd import constraints as _constraints
+from pymde_amd import lbfgs as _host
+from pymde_amd import util
+
+
+class SolveStats(object):
+    """Summary statistics for a solve.
+
+    Attributes: ``average_distortions``, ``residual_norms``, ``step_size_percents`` (one entry
+    per iteration), ``solve_time`` (s), ``iterations``, ``times``, ``snapshots``,
+    ``snapshot_every``.
+    """
+
+    def __init__(self, average_distortions, residual_norms, step_size_percents, solve_time, times,
+                 snapshots, snapshot_every):
+        self.average_distortions = average_distortions
+        self.residual_norms = residual_norms
+        self.step_size_percents = step_size_percents
+        self.solve_time = solve_time
+        self.iterations = len(average_distortions)
+        self.times = times
+        self.snapshots = snapshots
+        self.snapshot_every = snapshot_every
+
+    def __str__(self):
+        return ("SolveStats:\n\taverage distortion {0:.3g}\n\tresidual norm {1:.3g}\n"
+                "\tsolve_time (s) {2:.3g}\n\titerations {3}".format(
+                    self.average_distortions[-1], self.residual_norms[-1], self.solve_time,
+                    self.iterations))
+
+    def _repr_pretty_(self, p, cycle):
+        del cycle
+        p.text(self.__str__())
+
+
+# indices into the statistics board (mde_vec_stats)
+_GD, _GG, _G1, _GMAX, _NONFINITE, _DD, _DMAX, _XX, _LOSS = range(9)
+
+
+class _Engine(object):
+    """Device state of one solve and the kernels that act on it."""
+
+    def __init__(self, X, memory_size):
+        self.lib = _lib.load()
+        self.device = util.require_cuda_device(X.device)
+        if X.dtype != torch.float32:
+            raise ValueError("pymde_amd computes in float32; got X of dtype %s" % X.dtype)
+        self.n, self.d = X.shape
+        self.N = self.n * self.d
+        dev = self.device
+        self.X = X.detach().clone().contiguous()
+        self.X_trial = torch.empty_like(self.X)
+        # gradient buffer with one trailing float: [grad | loss] is what a multi-GPU
+        # evaluation all-reduces in a single collective
+        self.gbuf = torch.zeros(self.N + 1, dtype=torch.float32, device=dev)
+        self.g = self.gbuf[:self.N].view(self.n, self.d)
+        self.loss_dev = self.gbuf[self.N:]
+        self.g_prev = torch.empty_like(self.X)
+        self.dir = torch.empty_like(self.X)
+        self.work = util.work_buffer(dev, self.d)
+        self.board = torch.zeros(512, dtype=torch.float64, device=dev)
+        self.host = torch.zeros(512, dtype=torch.float64).pin_memory()
+        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.host_loss = torch.zeros(1, dtype=torch.float32).pin_memory()
+        self.host_status = torch.zeros(1, dtype=torch.int32).pin_memory()
+        handle = ctypes.c_void_p()
+        _lib.check(self.lib.mde_lbfgs_create(self.N, int(memory_size), ctypes.byref(handle)))
+        self.lbfgs = handle
+        self.memory = _host.LbfgsMemory(memory_size)
+
+    def close(self):
+        if self.lbfgs is not None:
+            self.lib.mde_lbfgs_destroy(self.lbfgs)
+            self.lbfgs = None
+
+    def stream(self):
+        return _lib.stream_ptr(self.device)
+
+    # ---- vector kernels
+    def axpy(self, alpha, x, y, out):
+        _lib.check(self.lib.mde_axpy(self.N, float(alpha), _lib.ptr(x), _lib.ptr(y), _lib.ptr(out),
+                                     self.stream()))
+
+    def stats(self, g, d, x):
+        _lib.check(self.lib.mde_vec_stats(self.N, _lib.ptr(g), _lib.ptr(d), _lib.ptr(x),
+                                          _lib.ptr(self.board), _lib.ptr(self.work), self.stream()))
+
+    def read_board(self, count):
+        """One device->host read-back of the first ``count`` doubles plus the loss."""
+        self.host[:count].copy_(self.board[:count], non_blocking=True)
+        self.host_loss.copy_(self.loss_dev, non_blocking=True)
+        self.host_status.copy_(self.status, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        vals = self.host[:count].numpy().copy()
+        return vals, float(self.host_loss[0])
+
+    # ---- L-BFGS memory
+    def reset_memory(self):
+        self.lib.mde_lbfgs_reset(self.lbfgs)
+        self.memory.reset()
+
+    def update_direction(self, t_prev):
+        """Stage (y, s), decide acceptance, form the new direction; returns stats of (g, d)."""
+        c = self.memory.count
+        ndots = 4 + 5 * c
+        _lib.check(self.lib.mde_lbfgs_stage(self.lbfgs, _lib.ptr(self.g), _lib.ptr(self.g_prev),
+                                            _lib.ptr(self.dir), float(t_prev), _lib.ptr(self.board),
+                                            _lib.ptr(self.work), self.stream()))
+        dots, _ = self.read_board(ndots)
+        accepted, Sg, Yg = self.memory.absorb(dots)
+        _lib.check(self.lib.mde_lbfgs_commit(self.lbfgs, 1 if accepted else 0))
+        c_g, cs, cy = self.memory.direction_coefficients(Sg, Yg)
+        m = self.memory.count
+        cs_arr = (ctypes.c_float * max(m, 1))(*[float(v) for v in cs])
+        cy_arr = (ctypes.c_float * max(m, 1))(*[float(v) for v in cy])
+        _lib.check(self.lib.mde_lbfgs_combine(self.lbfgs, _lib.ptr(self.g), float(c_g), cs_arr, cy_arr,
+                                              _lib.ptr(self.dir), _lib.ptr(self.board),
+                                              _lib.ptr(self.work), self.stream()))
+        vals, _ = self.read_board(8)
+        return vals
+
+
+class _NativeProblem(object):
+    """Objective + constraint evaluated entirely by libmde_hip (built-in constraint, function
+    bound to an edge plan).  ``evaluate(X, retract)`` leaves the projected gradient in the
+    engine's g buffer and E(X) in loss_dev."""
+
+    def __init__(self, engine, binding, constraint, reducer=None):
+        self.e = engine
+        self.binding = binding
+        self.constraint = constraint
+        self.reducer = reducer  # multi-GPU: all-reduce of [grad | loss]
+        if isinstance(constraint, _constraints._Standardized):
+            self.kind = "standardized"
+        elif isinstance(constraint, _constraints._Centered):
+            self.kind = "centered"
+        elif isinstance(constraint, _constraints.Anchored):
+            self.kind = "anchored"
+            self.anchors, self.values = constraint._device_args(engine.device)
+        else:
+            raise TypeError("not a built-in constraint")
+
+    def retract(self, X):
+        e, lib = self.e, self.e.lib
+        if self.kind == "centered":
+            _lib.check(lib.mde_center(e.n, e.d, _lib.ptr(X), _lib.ptr(e.work), e.stream()))
+        elif self.kind == "standardized":
+            _lib.check(lib.mde_std_retract(e.n, e.d, _lib.ptr(X), 1, _lib.ptr(e.work),
+                                           _lib.ptr(e.status), e.stream()))
+        else:
+            _lib.check(lib.mde_anchor_rows(self.anchors.numel(), e.d, _lib.ptr(self.anchors),
+                                           _lib.ptr(self.values), _lib.ptr(X), e.stream()))
+
+    def value_and_grad(self, X):
+        from pymde_amd import average_distortion as ad
+        e, lib = self.e, self.e.lib
+        if self.reducer is not None:
+            e.gbuf.zero_()
+        if self.binding.fused:
+            ad.fused_evaluate(self.binding, X, e.g, e.loss_dev)
+        else:
+            grad, value = ad._unfused(self.binding, X, True)
+            e.g.copy_(grad)
+            e.loss_dev.copy_(value.reshape(1))
+        if self.reducer is not None:
+            self.reducer(e.gbuf)
+        if self.kind == "standardized":
+            _lib.check(lib.mde_std_tangent(e.n, e.d, _lib.ptr(X), _lib.ptr(e.g), _lib.ptr(e.work),
+                                           e.stream()))
+        elif self.kind == "anchored":
+            _lib.check(lib.mde_anchor_rows(self.anchors.numel(), e.d, _lib.ptr(self.anchors), None,
+                                           _lib.ptr(e.g), e.stream()))
+
+    def check_status(self):
+        # the status word travels with every read-back of the statistics board
+        if self.kind == "standardized" and int(self.e.host_status[0]) != 0:
+            raise util.SolverError("Standardized retraction failed: X^T X is singular")
+
+
+class _GenericProblem(object):
+    """Arbitrary ``objective_fn`` (torch autograd) and/or custom ``Constraint`` object: the
+    callbacks run in Python exactly as in the reference's closure (optim.py:100-105); vectors
+    and the optimizer state still live in the engine."""
+
+    def __init__(self, engine, objective_fn, constraint):
+        self.e = engine
+        self.objective_fn = objective_fn
+        self.constraint = constraint
+
+    def retract(self, X):
+        with torch.no_grad():
+            self.constraint.project_onto_constraint(X, inplace=True)
+
+    def value_and_grad(self, X):
+        e = self.e
+        Xg = X.detach().requires_grad_(True)
+        with torch.enable_grad():
+            value = self.objective_fn(Xg)
+            (grad,) = torch.autograd.grad(value, Xg)
+        grad = grad.detach().to(torch.float32).contiguous()
+        with torch.no_grad():
+            grad = self.constraint.project_onto_tangent_space(X, grad, inplace=True)
+            e.g.copy_(grad)
+            e.loss_dev.copy_(value.detach().to(torch.float32).reshape(1))
+
+    def check_status(self):
+        pass
+
+
+def _make_problem(engine, objective_fn, constraint):
+    """Pick the native path when ``objective_fn`` is ``MDE.average_distortion`` of a problem
+    with a built-in constraint; otherwise the generic (callback) path."""
+    owner = getattr(objective_fn, "__self__", None)
+    builtin = isinstance(constraint, (_constraints._Standardized, _constraints._Centered,
+                                      _constraints.Anchored))
+    if (builtin and owner is not None and hasattr(owner, "_binding")
+            and getattr(objective_fn, "__name__", "") == "average_distortion"):
+        reducer = getattr(owner, "_reducer", None)
+        return _NativeProblem(engine, owner._binding(), constraint, reducer)
+    return _GenericProblem(engine, objective_fn, constraint)
+
+
+def lbfgs(X, objective_fn, constraint, eps, max_iter, memory_size, use_line_search, use_cached_loss,
+          verbose, print_every, snapshot_every, logger):
+    """Minimise ``objective_fn`` over the constraint set, starting from ``X``.
+
+    Returns ``(X_final, SolveStats)``.  See the module docstring for the semantics kept from
+    the reference.  ``use_line_search=False`` takes fixed steps t (lbfgs.py:552-554).
+    """
+    start_time = time.time()
+    average_distortions, grad_norms, step_size_percents, times, snapshots = [], [], [], [], []
+
+    engine = _Engine(X, memory_size)
+    try:
+        with torch.cuda.device(engine.device), torch.no_grad():
+            problem = _make_problem(engine, objective_fn, constraint)
+            _solve(engine, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
+                   print_every, snapshot_every, logger, average_distortions, grad_norms,
+                   step_size_percents, times, snapshots)
+        X_final = engine.X
+    finally:
+        engine.close()
+    if isinstance(X, torch.Tensor) and X.shape == X_final.shape and X.device == X_final.device \
+            and X.is_contiguous() and not X.requires_grad:
+        X.copy_(X_final)  # the reference updates the caller's tensor in place
+        X_final = X
+    stats = SolveStats(average_distortions, grad_norms, step_size_percents,
+                       time.time() - start_time, times, snapshots, snapshot_every)
+    return X_final, stats
+
+
+def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose, print_every,
+           snapshot_every, logger, average_distortions, grad_norms, step_size_percents, times,
+           snapshots):
+    digits = len(str(max_iter))
+    start = time.time()
+
+    n_iter = 0          # L-BFGS steps since the last reset (state["n_iter"])
+    cached_loss = None  # loss of the accepted point (self._cached_loss)
+    last_gg = 0.0       # ||g||^2 of the last evaluated gradient (X.grad)
+    norm_X = None       # ||X||_F of the current iterate (None: not known yet)
+    t = 0.0
+
+    def evaluate_at_current():
+        """closure() at X: no move, no retraction (lbfgs.py:426)."""
+        problem.value_and_grad(e.X)
+        e.stats(e.g, None, e.X)
+        vals, loss = e.read_board(8)
+        return loss, vals
+
+    for iteration in range(max_iter):
+        if snapshot_every is not None and iteration % snapshot_every == 0:
+            snapshots.append(e.X.detach().cpu().clone())
+
+        # ---- opt.step(value_and_grad)  [lbfgs.py:390-590 with max_iter = 1]
+        if use_cached_loss and n_iter > 0 and use_line_search and cached_loss is not None:
+            loss = cached_loss
+        else:
+            loss, vals = evaluate_at_current()
+            last_gg = vals[_GG]
+            norm_X = math.sqrt(vals[_XX])
+        if norm_X is None:                        # ||X||_F before the step (optim.py:129-130)
+            e.stats(e.X, None, None)
+            vals, _ = e.read_board(8)
+            norm_X = math.sqrt(vals[_GG])
+        average_distortions.append(loss)          # callback(loss, X.grad), optim.py:94-96
+        grad_norms.append(math.sqrt(last_gg))
+
+        n_iter += 1
+        if n_iter == 1:
+            # d = -g, empty history, H_diag = 1     (lbfgs.py:461-466)
+            e.reset_memory()
+            e.axpy(-2.0, e.g, e.g, e.dir)           # dir = g - 2 g = -g (exact)
+            e.axpy(0.0, e.g, e.g, e.g_prev)         # g_prev <- g
+            e.stats(e.g, e.dir, None)
+            vals, _ = e.read_board(8)
+        else:
+            vals = e.update_direction(t)
+        gtd = vals[_GD]
+        d_norm2 = math.sqrt(vals[_DD])
+        d_max = vals[_DMAX]
+        # initial step (lbfgs.py:521-524), lr = 1
+        if n_iter == 1:
+            g1 = vals[_G1]
+            t = min(1.0, 1.0 / g1) if g1 > 0 else 1.0
+        else:
+            t = 1.0
+
+        last_eval = {"t": None}
+
+        def phi(tt):
+            e.axpy(tt, e.dir, e.X, e.X_trial)
+            problem.retract(e.X_trial)
+            problem.value_and_grad(e.X_trial)
+            e.stats(e.g, e.dir, e.X_trial)
+            v, f = e.read_board(8)
+            last_eval["t"] = tt
+            last_eval["gg"] = v[_GG]
+            last_eval["xx"] = v[_XX]
+            return f, v[_GD], v[_NONFINITE] == 0
+
+        if use_line_search:
+            try:
+                loss_new, t, _ = _host.strong_wolfe(phi, t, loss, gtd, d_max)
+            except _host.LineSearchError as err:
+                raise util.SolverError(str(err))
+            cached_loss = loss_new
+            last_gg = last_eval["gg"]
+        else:
+            cached_loss = None
+
+        # X <- retract(X + t d)    (lbfgs.py:551 + optim.py:135-136)
+        if use_line_search and last_eval["t"] == t:
+            e.X, e.X_trial = e.X_trial, e.X
+            new_xx = last_eval["xx"]
+        else:
+            e.axpy(t, e.dir, e.X, e.X_trial)
+            problem.retract(e.X_trial)
+            e.X, e.X_trial = e.X_trial, e.X
+            new_xx = None
+        problem.check_status()
+
+        times.append(time.time() - start)
+        h = t
+        percent_change = 100.0 * h * d_norm2 / norm_X if norm_X > 0 else 0.0
+        step_size_percents.append(float(percent_change))
+        norm_X = math.sqrt(new_xx) if new_xx is not None else None
+
+        norm_grad = grad_norms[-1]
+        if verbose and ((iteration % print_every == 0) or (iteration == max_iter - 1)):
+            logger.info(
+                "iteration %0*d | distortion %6f | residual norm %g | "
+                "step length %g | percent change %g"
+                % (digits, iteration, average_distortions[-1], norm_grad, h, percent_change))
+        if norm_grad <= eps:
+            if verbose:
+                logger.info("Converged in %03d iterations, with residual norm %g"
+                            % (iteration + 1, norm_grad))
+            break
+        elif h == 0:
+            n_iter = 0  # opt.reset(): drop the memory, re-evaluate next step (optim.py:172-173)
+            cached_loss = None
+            e.reset_memory()

@@ -1,0 +1,306 @@
+"""Generate golden vectors by RUNNING THE REFERENCE (cvxgrp/pymde) on the CPU.
+
+Run in the build container (it reads /root/reference, which does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+It copies the reference to a scratch directory, builds its one Cython extension, stubs the two
+imports that are not installed here (torchvision, pynndescent), imports it as ``pymde`` and
+writes small ``.npz`` fixtures next to this file.  Everything is seeded; torch runs with one
+thread so the reference's own fp32 summation order is fixed.
+
+Fixtures
+  functions.npz     (loss, grad, distortions) of every public penalty / loss, d in {1,2,3,8},
+                    incl. coincident points (d_k = 0)         -> pins average_distortion.py:62-106
+  constraints.npz   Centered / Standardized / Anchored maps   -> pins constraints.py, util.py:129-171
+  trajectories.npz  per-iteration SolveStats of short embed() runs (optim.py / lbfgs.py)
+  spectral.npz      quadratic.spectral on small graphs         -> pins quadratic.py
+  cycle.npz         BASELINE config 1 scaled down: preserve_distances on a cycle graph,
+                    losses.Quadratic, all pairs
+"""
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFERENCE = "/root/reference"
+
+
+def import_reference():
+    scratch = os.path.join(tempfile.gettempdir(), "pymde_reference_scratch")
+    if not os.path.exists(os.path.join(scratch, "pymde")):
+        os.makedirs(scratch, exist_ok=True)
+        for item in ("pymde", "setup.py", "README.md"):
+            src = os.path.join(REFERENCE, item)
+            dst = os.path.join(scratch, item)
+            if os.path.isdir(src):
+                shutil.copytree(src, dst)
+            else:
+                shutil.copy(src, dst)
+        subprocess.check_call(["chmod", "-R", "u+w", scratch])
+        subprocess.check_call([sys.executable, "setup.py", "build_ext", "--inplace"], cwd=scratch,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    for name in ("torchvision", "torchvision.datasets", "torchvision.datasets.utils", "pynndescent"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision"].datasets = sys.modules["torchvision.datasets"]
+    sys.modules["torchvision.datasets"].utils = sys.modules["torchvision.datasets.utils"]
+    sys.path.insert(0, scratch)
+    import pymde
+    return pymde
+
+
+def random_graph(rng, n, p):
+    """p distinct edges (i < j) of a random graph on n vertices."""
+    all_pairs = np.stack(np.triu_indices(n, 1), axis=1)
+    idx = rng.choice(all_pairs.shape[0], size=p, replace=False)
+    return all_pairs[np.sort(idx)].astype(np.int64)
+
+
+# name -> (constructor from (pymde, weights/deviations tensors), kind, per-edge array role,
+#          scalars, kind_neg, scalars_neg)
+def function_cases(pymde, torch, rng, p):
+    pen, los = pymde.penalties, pymde.losses
+    w_pos = torch.tensor(rng.uniform(0.5, 2.0, p).astype(np.float32))
+    w_neg = -w_pos
+    w_mix = torch.tensor(np.where(rng.random(p) < 0.4, -1.0, rng.uniform(0.5, 2.0, p)).astype(np.float32))
+    dev = torch.tensor(rng.uniform(0.3, 2.5, p).astype(np.float32))
+    w2 = torch.tensor(rng.uniform(0.2, 1.5, p).astype(np.float32))
+    cases = [
+        ("pen_linear", pen.Linear(w_pos), "LINEAR", w_pos, None, (), "NONE", ()),
+        ("pen_quadratic", pen.Quadratic(w_pos), "QUADRATIC", w_pos, None, (), "NONE", ()),
+        ("pen_cubic", pen.Cubic(w_pos), "CUBIC", w_pos, None, (), "NONE", ()),
+        ("pen_power_2p5", pen.Power(w_pos, 2.5), "POWER", w_pos, None, (2.5,), "NONE", ()),
+        ("pen_power_1", pen.Power(w_pos, 1.0), "POWER", w_pos, None, (1.0,), "NONE", ()),
+        ("pen_huber", pen.Huber(w_pos, 0.5), "HUBER", w_pos, None, (0.5,), "NONE", ()),
+        ("pen_logistic", pen.Logistic(w_pos, 0.2, 3.0), "LOGISTIC", w_pos, None, (0.2, 3.0), "NONE", ()),
+        ("pen_sigmoid", pen.Sigmoid(w_pos, 0.5, 2.0), "SIGMOID", w_pos, None, (0.5, 2.0), "NONE", ()),
+        ("pen_hinge", pen.Hinge(w_mix, 1.0, 0.25), "HINGE", w_mix, None, (1.0, 0.25), "NONE", ()),
+        ("pen_log1p", pen.Log1p(w_pos), "LOG1P", w_pos, None, (1.5,), "NONE", ()),
+        ("pen_log1p_e2", pen.Log1p(w_pos, 2.0), "LOG1P", w_pos, None, (2.0,), "NONE", ()),
+        ("pen_log1p_e0p7", pen.Log1p(w_pos, 0.7), "LOG1P", w_pos, None, (0.7,), "NONE", ()),
+        ("pen_log", pen.Log(w_neg), "LOG", w_neg, None, (1.0,), "NONE", ()),
+        ("pen_log_e2", pen.Log(w_neg, 2.0), "LOG", w_neg, None, (2.0,), "NONE", ()),
+        ("pen_invpower", pen.InvPower(w_neg), "INVPOWER", w_neg, None, (1.0,), "NONE", ()),
+        ("pen_invpower_e2", pen.InvPower(w_neg, 2), "INVPOWER", w_neg, None, (2.0,), "NONE", ()),
+        ("pen_logratio", pen.LogRatio(w_neg), "LOGRATIO", w_neg, None, (2.0,), "NONE", ()),
+        ("pen_pushpull_default", pen.PushAndPull(w_mix), "LOG1P", w_mix, None, (1.5,), "LOGRATIO", (2.0,)),
+        ("pen_pushpull_log", pen.PushAndPull(w_mix, pen.Log1p, pen.Log), "LOG1P", w_mix, None, (1.5,),
+         "LOG", (1.0,)),
+        ("pen_pushpull_quad_invpower", pen.PushAndPull(w_mix, pen.Quadratic, pen.InvPower), "QUADRATIC",
+         w_mix, None, (), "INVPOWER", (1.0,)),
+        ("loss_quadratic", los.Quadratic(dev), "L_QUADRATIC", dev, None, (), "NONE", ()),
+        ("loss_weighted_quadratic", los.WeightedQuadratic(dev), "L_WEIGHTED_QUADRATIC", dev,
+         1.0 / dev.pow(2), (), "NONE", ()),
+        ("loss_weighted_quadratic_w", los.WeightedQuadratic(dev, w2), "L_WEIGHTED_QUADRATIC", dev, w2,
+         (), "NONE", ()),
+        ("loss_huber", los.Huber(dev, 0.4), "L_HUBER", dev, None, (0.4,), "NONE", ()),
+        ("loss_cubic", los.Cubic(dev), "L_CUBIC", dev, None, (), "NONE", ()),
+        ("loss_power", los.Power(dev, 1.7), "L_POWER", dev, None, (1.7,), "NONE", ()),
+        ("loss_absolute", los.Absolute(dev), "L_ABSOLUTE", dev, None, (), "NONE", ()),
+        ("loss_logistic", los.Logistic(dev), "L_LOGISTIC", dev, None, (), "NONE", ()),
+        ("loss_fractional", los.Fractional(dev), "L_FRACTIONAL", dev, None, (), "NONE", ()),
+        ("loss_soft_fractional", los.SoftFractional(dev, 5.0), "L_SOFT_FRACTIONAL", dev, None, (5.0,),
+         "NONE", ()),
+    ]
+    return cases
+
+
+def gen_functions(pymde, torch):
+    rng = np.random.default_rng(1234)
+    n, p = 40, 160
+    edges = random_graph(rng, n, p)
+    out = {"edges": edges, "n": n}
+    names = []
+    for d in (1, 2, 3, 8):
+        X = rng.standard_normal((n, d)).astype(np.float32)
+        out["X_d%d" % d] = X
+    # a variant with coincident points (rows 0..3 equal -> some d_k = 0 exactly)
+    Xz = rng.standard_normal((n, 2)).astype(np.float32)
+    Xz[edges[:6, 1]] = Xz[edges[:6, 0]]
+    out["X_zero"] = Xz
+    cases = function_cases(pymde, torch, np.random.default_rng(99), p)
+    for name, f, kind, a0, a1, sc, kind_neg, sc_neg in cases:
+        names.append(name)
+        out[name + "__kind"] = np.array(kind)
+        out[name + "__kind_neg"] = np.array(kind_neg)
+        out[name + "__a0"] = a0.numpy()
+        if a1 is not None:
+            out[name + "__a1"] = a1.numpy()
+        out[name + "__scalars"] = np.array(sc, dtype=np.float64)
+        out[name + "__scalars_neg"] = np.array(sc_neg, dtype=np.float64)
+        for tag in ("d1", "d2", "d3", "d8", "zero"):
+            X = out["X_zero"] if tag == "zero" else out["X_" + tag]
+            d = X.shape[1]
+            mde = pymde.MDE(n, d, torch.tensor(edges), f)
+            Xt = torch.tensor(X, requires_grad=True)
+            E = mde.average_distortion(Xt)
+            E.backward()
+            out["%s__%s__loss" % (name, tag)] = np.array(E.item(), dtype=np.float64)
+            out["%s__%s__grad" % (name, tag)] = Xt.grad.numpy().copy()
+            with torch.no_grad():
+                out["%s__%s__distortions" % (name, tag)] = mde.distortions(torch.tensor(X)).numpy()
+                if name == "pen_quadratic":
+                    out["%s__distances" % tag] = mde.distances(torch.tensor(X)).numpy()
+                    out["%s__differences" % tag] = mde.differences(torch.tensor(X)).numpy()
+    out["names"] = np.array(names)
+    # the reference's own known-answer test (pymde/test_optim.py:75-93): 62/3
+    e3 = np.array([[0, 1], [0, 2], [1, 2]])
+    mde = pymde.MDE(3, 2, e3, pymde.penalties.Quadratic(torch.tensor([1.0, 2.0, 3.0])),
+                    constraint=pymde.Standardized())
+    out["kat_62_3"] = np.array(
+        mde.average_distortion(torch.tensor([[0.0, 0.0], [1.0, 1.0], [3.0, 3.0]])).item())
+    # distances backward at coincident points (test_optim.py:57-71)
+    Xo = torch.ones((3, 3), requires_grad=True)
+    mde = pymde.MDE(3, 3, np.array([[0, 1]]), pymde.penalties.Quadratic(torch.ones(1)))
+    mde.distances(Xo).backward()
+    out["norm_grad_zero"] = Xo.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "functions.npz"), **out)
+    print("functions.npz:", len(names), "functions")
+
+
+def gen_constraints(pymde, torch):
+    rng = np.random.default_rng(7)
+    out = {}
+    shapes = [(5, 3), (10, 3), (100, 3), (500, 2), (300, 8), (400, 32), (200, 40)]
+    out["shapes"] = np.array(shapes)
+    for (n, d) in shapes:
+        X = rng.standard_normal((n, d)).astype(np.float32) * rng.uniform(0.5, 2.0, d).astype(np.float32)
+        X += rng.uniform(-1, 1, d).astype(np.float32)
+        Z = rng.standard_normal((n, d)).astype(np.float32)
+        tag = "%dx%d" % (n, d)
+        out["X_" + tag] = X
+        out["Z_" + tag] = Z
+        P = pymde.Standardized().project_onto_constraint(torch.tensor(X), inplace=False)
+        out["std_retract_" + tag] = P.numpy()
+        out["std_tangent_" + tag] = pymde.Standardized().project_onto_tangent_space(
+            P, torch.tensor(Z), inplace=False).numpy()
+        out["centered_" + tag] = pymde.Centered().project_onto_constraint(
+            torch.tensor(X), inplace=False).numpy()
+    n, d = 50, 2
+    anchors = torch.tensor(rng.choice(n, 7, replace=False))
+    values = torch.tensor(rng.standard_normal((7, d)).astype(np.float32))
+    Z = rng.standard_normal((n, d)).astype(np.float32)
+    c = pymde.Anchored(anchors, values)
+    out["anchors"] = anchors.numpy()
+    out["anchor_values"] = values.numpy()
+    out["anchor_Z"] = Z
+    out["anchor_tangent"] = c.project_onto_tangent_space(None, torch.tensor(Z), inplace=False).numpy()
+    out["anchor_retract"] = c.project_onto_constraint(torch.tensor(Z), inplace=False).numpy()
+    np.savez_compressed(os.path.join(HERE, "constraints.npz"), **out)
+    print("constraints.npz written")
+
+
+def gen_trajectories(pymde, torch):
+    rng = np.random.default_rng(2024)
+    pen, los = pymde.penalties, pymde.losses
+    n, p = 300, 3000
+    edges = random_graph(rng, n, p)
+    w_pos = rng.uniform(0.5, 2.0, p).astype(np.float32)
+    w_mix = np.where(np.arange(p) < 2 * p // 3, w_pos, -1.0).astype(np.float32)
+    dev = rng.uniform(0.5, 2.0, p).astype(np.float32)
+    anchors = rng.choice(n, 20, replace=False)
+    anchor_vals = rng.standard_normal((20, 2)).astype(np.float32)
+    out = {"edges": edges, "n": n, "w_pos": w_pos, "w_mix": w_mix, "dev": dev, "anchors": anchors,
+           "anchor_values": anchor_vals}
+    problems = [
+        ("quad_std", 2, "QUADRATIC", lambda: pen.Quadratic(torch.tensor(w_pos)), "standardized"),
+        ("log1p_centered", 2, "LOG1P", lambda: pen.Log1p(torch.tensor(w_pos)), "centered"),
+        ("pushpull_std", 2, "LOG1P|LOG", lambda: pen.PushAndPull(torch.tensor(w_mix), pen.Log1p, pen.Log),
+         "standardized"),
+        ("pushpull_centered_d3", 3, "LOG1P|LOGRATIO", lambda: pen.PushAndPull(torch.tensor(w_mix)), "centered"),
+        ("absolute_centered", 2, "L_ABSOLUTE", lambda: los.Absolute(torch.tensor(dev)), "centered"),
+        ("huber_std", 2, "L_HUBER", lambda: los.Huber(torch.tensor(dev), 0.5), "standardized"),
+        ("quadloss_anchored", 2, "L_QUADRATIC", lambda: los.Quadratic(torch.tensor(dev)), "anchored"),
+    ]
+    names = []
+    for name, d, kinds, make_f, cname in problems:
+        torch.manual_seed(0)
+        if cname == "standardized":
+            c = pymde.Standardized()
+        elif cname == "centered":
+            c = pymde.Centered()
+        else:
+            c = pymde.Anchored(torch.tensor(anchors), torch.tensor(anchor_vals))
+        mde = pymde.MDE(n, d, torch.tensor(edges), make_f(), constraint=c)
+        X0 = c.initialization(n, d)
+        mde.embed(X=X0, max_iter=12, eps=1e-9, memory_size=5)
+        s = mde.solve_stats
+        names.append(name)
+        out[name + "__d"] = d
+        out[name + "__kinds"] = np.array(kinds)
+        out[name + "__constraint"] = np.array(cname)
+        out[name + "__X0"] = X0.numpy()
+        out[name + "__distortions"] = np.array(s.average_distortions)
+        out[name + "__residuals"] = np.array(s.residual_norms)
+        out[name + "__steps"] = np.array(s.step_size_percents)
+        out[name + "__X_final"] = mde.X.numpy()
+        # a longer run for the end-of-solve tolerance tier
+        mde2 = pymde.MDE(n, d, torch.tensor(edges), make_f(), constraint=c)
+        mde2.embed(X=X0, max_iter=150, eps=1e-6, memory_size=10)
+        out[name + "__final_value_150"] = np.array(mde2.value)
+        out[name + "__final_iters_150"] = np.array(mde2.solve_stats.iterations)
+    out["names"] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, "trajectories.npz"), **out)
+    print("trajectories.npz:", names)
+
+
+def gen_spectral(pymde, torch):
+    from pymde import quadratic
+    out = {}
+    # the reference's own test problem (pymde/test_quadratic.py:67-109): n = 12, d = 3
+    torch.manual_seed(0)
+    np.random.seed(0)
+    n, m = 12, 3
+    edges = pymde.all_edges(n)
+    weights = torch.tensor(np.random.default_rng(5).uniform(0.1, 1.0, edges.shape[0]).astype(np.float32))
+    emb = quadratic.spectral(n, m, edges, weights)
+    out["small_edges"], out["small_weights"], out["small_emb"] = edges.numpy(), weights.numpy(), emb.numpy()
+    rng = np.random.default_rng(11)
+    n, m = 400, 2
+    e = random_graph(rng, n, 3200)
+    w = rng.uniform(0.5, 1.5, e.shape[0]).astype(np.float32)
+    emb = quadratic.spectral(n, m, torch.tensor(e), torch.tensor(w))
+    out["mid_edges"], out["mid_weights"], out["mid_emb"] = e, w, emb.numpy()
+    mde = pymde.MDE(n, m, torch.tensor(e), pymde.penalties.Quadratic(torch.tensor(w)),
+                    constraint=pymde.Standardized())
+    out["mid_value"] = np.array(mde.average_distortion(emb).item())
+    np.savez_compressed(os.path.join(HERE, "spectral.npz"), **out)
+    print("spectral.npz written")
+
+
+def gen_cycle(pymde, torch):
+    """BASELINE config 1 scaled down (n = 300 instead of 5000 so the fixture stays small):
+    preserve_distances on a cycle graph, Quadratic loss, all pairs, d = 2."""
+    n = 300
+    cyc = np.array([[i, (i + 1) % n] for i in range(n)])
+    graph = pymde.Graph.from_edges(torch.tensor(cyc))
+    torch.manual_seed(0)
+    mde = pymde.preserve_distances(graph, embedding_dim=2, loss=pymde.losses.Quadratic)
+    X0 = mde.constraint.initialization(n, 2)
+    mde.embed(X=X0, max_iter=40, eps=1e-8)
+    out = {"n": n, "edges": mde.edges.numpy(), "deviations": mde.distortion_function.deviations.numpy(),
+           "X0": X0.numpy(), "distortions": np.array(mde.solve_stats.average_distortions),
+           "residuals": np.array(mde.solve_stats.residual_norms), "final_value": np.array(mde.value)}
+    np.savez_compressed(os.path.join(HERE, "cycle.npz"), **out)
+    print("cycle.npz: p =", out["edges"].shape[0], "final", float(out["final_value"]))
+
+
+def main():
+    pymde = import_reference()
+    import torch
+    torch.set_num_threads(1)
+    gen_functions(pymde, torch)
+    gen_constraints(pymde, torch)
+    gen_trajectories(pymde, torch)
+    gen_spectral(pymde, torch)
+    gen_cycle(pymde, torch)
+
+
+if __name__ == "__main__":
+    main()
