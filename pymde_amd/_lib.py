@@ -93,8 +93,9 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
-        if not os.path.exists(LIB_PATH) or os.environ.get("PYMDE_AMD_REBUILD"):
-            from pymde_amd import _build
+        from pymde_amd import _build
+        if (not os.path.exists(LIB_PATH) or os.environ.get("PYMDE_AMD_REBUILD")
+                or (_build._stale() and _build._hipcc() is not None)):
             _build.build(verbose=bool(os.environ.get("PYMDE_AMD_VERBOSE")))
         if not os.path.exists(LIB_PATH):
             raise ImportError(

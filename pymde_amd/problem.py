@@ -87,14 +87,14 @@ class MDE(torch.nn.Module):
         edges = edges.to(torch.int64).contiguous()
         p = torch.tensor(edges.shape[0], device=self.device)
 
+        # validates (self edges raise ValueError as in problem.py:134-140) and builds the plan
+        self._plan = self._make_plan(edges)
+
         complete_graph_edges = (self._n * (self._n - 1)) // 2
         if int(p) > complete_graph_edges:
             raise ValueError(
                 "Your graph has more than (n_items choose 2) edges."
                 "(p: {0}, n_items choose 2: {1})".format(int(p), complete_graph_edges))
-
-        # validates (self edges raise ValueError as in problem.py:134-140) and builds the plan
-        self._plan = self._make_plan(edges)
 
         self.register_buffer("edges", edges)
         self.register_buffer("p", p)

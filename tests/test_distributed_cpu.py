@@ -1,0 +1,66 @@
+"""N > 1 path on CPU: two gloo ranks each own a vertex range; their [grad | loss] buffers,
+all-reduced by the product's reducer, equal the unsharded oracle result (world_size 2)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    from pymde_amd import distributed
+    rng = np.random.default_rng(5)
+    n, p, d = 200, 1500, 2
+    pairs = np.stack(np.triu_indices(n, 1), axis=1)
+    edges = pairs[np.sort(rng.choice(len(pairs), p, replace=False))]
+    w = rng.uniform(0.5, 2.0, p).astype(np.float32)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    fd = oracle.func("LOG1P", w, None, (1.5,))
+    E_full, grad_full = oracle.average_distortion(edges, X, fd)
+    # owner-computes share of this rank: its gradient rows are final, its loss share counts
+    # every incident half-edge with weight 1/2
+    bounds = oracle.shard_bounds(n, edges, world)
+    lo, hi = distributed.shard_range(bounds, rank)
+    f_edge = oracle.distortions(oracle.distances(edges, X), fd).astype(np.float64)
+    own_i = (edges[:, 0] >= lo) & (edges[:, 0] < hi)
+    own_j = (edges[:, 1] >= lo) & (edges[:, 1] < hi)
+    share = (0.5 * f_edge * own_i + 0.5 * f_edge * own_j).sum() / p
+    buf = torch.zeros(n * d + 1, dtype=torch.float32)
+    buf[lo * d:hi * d] = torch.from_numpy(grad_full[lo:hi].reshape(-1))
+    buf[-1] = share
+    distributed.all_reduce_grad_loss(buf)
+    np.testing.assert_allclose(buf[:-1].numpy().reshape(n, d), grad_full, rtol=0, atol=0)
+    assert abs(float(buf[-1]) - E_full) < 1e-5 * abs(E_full)
+    # both ranks hold the identical reduced buffer
+    gathered = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf)
+    assert all(torch.equal(gathered[0], g) for g in gathered)
+    # plan shards tile the full plan
+    full = oracle.plan_csr(n, edges)
+    mine = oracle.plan_csr(n, edges, lo, hi)
+    np.testing.assert_array_equal(mine[1], full[1][full[0][lo]:full[0][hi]])
+    ret[rank] = 1
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_allreduce_matches_unsharded():
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert len(ret) == world

@@ -1,0 +1,399 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference's golden
+vectors -- plan, fused kernel, edge-order evaluators, constraints.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import LOSS_RTOL, assert_grad_close, func_from_golden
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _native_loaded():
+    from pymde_amd import _lib
+    _lib.load()
+    maps = open("/proc/self/maps").read()
+    assert "libmde_hip.so" in maps, "the HIP extension is not loaded in this process"
+
+
+def _make_function(fd, device=DEV):
+    """Build the pymde_amd function object equivalent to an oracle descriptor."""
+    import pymde_amd
+    pen, los = pymde_amd.penalties, pymde_amd.losses
+    a0 = torch.tensor(fd["a0"], device=device)
+    a1 = None if fd.get("a1") is None else torch.tensor(fd["a1"], device=device)
+    s, sn = fd["scalars"], fd["scalars_neg"]
+    single = {
+        "LINEAR": lambda w, sc: pen.Linear(w), "QUADRATIC": lambda w, sc: pen.Quadratic(w),
+        "CUBIC": lambda w, sc: pen.Cubic(w), "POWER": lambda w, sc: pen.Power(w, sc[0]),
+        "HUBER": lambda w, sc: pen.Huber(w, sc[0]),
+        "LOGISTIC": lambda w, sc: pen.Logistic(w, sc[0], sc[1]),
+        "SIGMOID": lambda w, sc: pen.Sigmoid(w, sc[0], sc[1]),
+        "HINGE": lambda w, sc: pen.Hinge(w, sc[0], sc[1]),
+        "LOG1P": lambda w, sc: pen.Log1p(w, sc[0]), "LOG": lambda w, sc: pen.Log(w, sc[0]),
+        "INVPOWER": lambda w, sc: pen.InvPower(w, sc[0]),
+        "LOGRATIO": lambda w, sc: pen.LogRatio(w, sc[0]),
+    }
+    kind, kind_neg = fd["kind"], fd.get("kind_neg", "NONE")
+    if kind_neg != "NONE":
+        import functools
+
+        def mk(k, sc):
+            return lambda w: single[k](w, sc)
+        return pen.PushAndPull(a0, mk(kind, s), mk(kind_neg, sn))
+    if kind in single:
+        return single[kind](a0, s)
+    losses = {
+        "L_QUADRATIC": lambda: los.Quadratic(a0), "L_WEIGHTED_QUADRATIC": lambda: los.WeightedQuadratic(a0, a1),
+        "L_HUBER": lambda: los.Huber(a0, s[0]), "L_CUBIC": lambda: los.Cubic(a0),
+        "L_POWER": lambda: los.Power(a0, s[0]), "L_ABSOLUTE": lambda: los.Absolute(a0),
+        "L_LOGISTIC": lambda: los.Logistic(a0), "L_FRACTIONAL": lambda: los.Fractional(a0),
+        "L_SOFT_FRACTIONAL": lambda: los.SoftFractional(a0, s[0]),
+    }
+    return losses[kind]()
+
+
+def _hip_eval(n, d, edges, f, X):
+    import pymde_amd
+    mde = pymde_amd.MDE(n, d, torch.tensor(edges, device=DEV), f)
+    Xt = torch.tensor(X, device=DEV, requires_grad=True)
+    E = mde.average_distortion(Xt)
+    E.backward()
+    return mde, float(E), Xt.grad.cpu().numpy()
+
+
+def test_native_library_is_the_path():
+    _native_loaded()
+
+
+# ---------------------------------------------------------------- plan (integer work: bit exact)
+@pytest.mark.parametrize("n,p,seed", [(5, 4, 0), (64, 500, 1), (1000, 20000, 2), (4097, 60001, 3)])
+def test_plan_matches_oracle_bit_exact(n, p, seed):
+    from pymde_amd.average_distortion import EdgePlan
+    rng = np.random.default_rng(seed)
+    pairs = np.stack(np.triu_indices(n, 1), axis=1)
+    edges = pairs[rng.choice(len(pairs), p, replace=False)]  # unsorted on purpose
+    flip = rng.random(p) < 0.5
+    edges[flip] = edges[flip][:, ::-1]  # (j, i) orientation is legal too
+    plan = EdgePlan(n, torch.tensor(edges, device=DEV))
+    rowptr, nbr, eid = [t.cpu().numpy() for t in plan.csr()]
+    w_rowptr, w_nbr, w_eid = oracle.plan_csr(n, edges)
+    np.testing.assert_array_equal(rowptr, w_rowptr)
+    np.testing.assert_array_equal(nbr, w_nbr)
+    np.testing.assert_array_equal(eid, w_eid)
+    # sharded plans tile the full plan; the bounds equal the numpy restatement
+    from pymde_amd import distributed
+    bounds = distributed.shard_bounds(n, torch.tensor(edges, device=DEV), 3)
+    assert bounds == oracle.shard_bounds(n, edges, 3)
+    for r in range(3):
+        sp = EdgePlan(n, torch.tensor(edges, device=DEV), bounds[r], bounds[r + 1])
+        s_rowptr, s_nbr, s_eid = [t.cpu().numpy() for t in sp.csr()]
+        o = oracle.plan_csr(n, edges, bounds[r], bounds[r + 1])
+        np.testing.assert_array_equal(s_rowptr, o[0])
+        np.testing.assert_array_equal(s_nbr, o[1])
+        np.testing.assert_array_equal(s_eid, o[2])
+
+
+def test_plan_edge_cases():
+    import pymde_amd
+    from pymde_amd.average_distortion import EdgePlan
+    # isolated vertices (empty rows) and duplicate edges
+    edges = np.array([[0, 5], [0, 5], [2, 5], [7, 2]])
+    plan = EdgePlan(9, torch.tensor(edges, device=DEV))
+    rowptr, nbr, eid = [t.cpu().numpy() for t in plan.csr()]
+    o = oracle.plan_csr(9, edges)
+    np.testing.assert_array_equal(rowptr, o[0])
+    np.testing.assert_array_equal(nbr, o[1])
+    # self edges raise the reference's ValueError (problem.py:134-140, test_optim.py:157-170)
+    bad = np.array([(0, 1), (0, 0), (0, 2), (1, 2), (1, 1)])
+    with pytest.raises(ValueError, match=r"The edge list must not contain self edges.*"):
+        pymde_amd.MDE(3, 3, bad, pymde_amd.penalties.Quadratic(torch.ones(5)))
+    with pytest.raises(ValueError):
+        EdgePlan(3, torch.tensor([[0, 3]], device=DEV))
+    with pytest.raises(ValueError, match="more than"):
+        pymde_amd.MDE(3, 2, np.array([[0, 1]] * 4), pymde_amd.penalties.Quadratic(torch.ones(4)))
+
+
+# ---------------------------------------------------------------- the hot kernel
+def test_known_answer_62_over_3():
+    # pymde/test_optim.py:75-93
+    import pymde_amd
+    edges = np.array([(0, 1), (0, 2), (1, 2)])
+    mde = pymde_amd.MDE(3, 2, edges, pymde_amd.penalties.Quadratic(torch.tensor([1.0, 2.0, 3.0])),
+                        constraint=pymde_amd.Standardized())
+    X = torch.tensor([[0.0, 0.0], [1.0, 1.0], [3.0, 3.0]], device=DEV)
+    assert float(mde.average_distortion(X)) == pytest.approx(62.0 / 3, rel=1e-6)
+
+
+def test_every_function_against_reference_golden(golden_functions):
+    g = golden_functions
+    edges, n = g["edges"], int(g["n"])
+    for name in g["names"]:
+        fd = func_from_golden(g, str(name))
+        f = _make_function(fd)
+        for tag in ("d1", "d2", "d3", "d8", "zero"):
+            X = g["X_zero"] if tag == "zero" else g["X_" + tag]
+            mde, E, grad = _hip_eval(n, X.shape[1], edges, f, X)
+            want_E = float(g["%s__%s__loss" % (name, tag)])
+            if np.isfinite(want_E):
+                assert E == pytest.approx(want_E, rel=LOSS_RTOL, abs=1e-7), (name, tag)
+            else:
+                assert not np.isfinite(E) or abs(E) > 1e30, (name, tag)
+            assert_grad_close(grad, g["%s__%s__grad" % (name, tag)])
+            want = g["%s__%s__distortions" % (name, tag)]
+            got = mde.distortions(torch.tensor(X, device=DEV)).cpu().numpy()
+            fin = np.isfinite(want)
+            np.testing.assert_allclose(got[fin], want[fin], rtol=2e-5, atol=1e-6, err_msg=str((name, tag)))
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 7, 8, 16, 33, 64, 100, 128, 200])
+def test_fused_kernel_against_oracle_all_dims(d):
+    rng = np.random.default_rng(d)
+    n, p = 3000, 40000
+    pairs_i = rng.integers(0, n, p)
+    pairs_j = (pairs_i + 1 + rng.integers(0, n - 1, p)) % n
+    edges = np.stack([pairs_i, pairs_j], axis=1)
+    X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    w = np.where(rng.random(p) < 0.3, -1.0, rng.uniform(0.5, 2.0, p)).astype(np.float32)
+    dev = rng.uniform(0.3, 2.0, p).astype(np.float32)
+    cases = [oracle.func("LOG1P", np.abs(w), None, (1.5,)),
+             oracle.func("LOG1P", w, None, (1.5,), "LOG", (1.0,)),
+             oracle.func("QUADRATIC", np.abs(w)),
+             oracle.func("L_ABSOLUTE", dev),
+             oracle.func("L_HUBER", dev, None, (0.5,))]
+    for fd in cases:
+        f = _make_function(fd)
+        _, E, grad = _hip_eval(n, d, edges, f, X)
+        wE, wgrad = oracle.average_distortion(edges, X, fd)
+        assert E == pytest.approx(wE, rel=LOSS_RTOL), (d, fd["kind"])
+        assert_grad_close(grad, wgrad)
+
+
+@pytest.mark.parametrize("group", ["4", "8", "16", "32", "64"])
+def test_row_group_widths_agree(group, monkeypatch):
+    """Every lanes-per-row variant of the small-d kernel gives the oracle's answer (run in a
+    subprocess because the library reads MDE_GROUP once)."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import oracle
+import pymde_amd
+rng = np.random.default_rng(0)
+n, p = 2000, 30000
+i = rng.integers(0, n, p); j = (i + 1 + rng.integers(0, n - 1, p)) %% n
+edges = np.stack([i, j], 1); X = rng.standard_normal((n, 2)).astype(np.float32)
+w = rng.uniform(0.5, 2, p).astype(np.float32)
+mde = pymde_amd.MDE(n, 2, torch.tensor(edges), pymde_amd.penalties.Log1p(torch.tensor(w)))
+Xt = torch.tensor(X, device='cuda', requires_grad=True)
+E = mde.average_distortion(Xt); E.backward()
+wE, wg = oracle.average_distortion(edges, X, oracle.func('LOG1P', w, None, (1.5,)))
+assert abs(float(E) - wE) < 1e-5 * abs(wE)
+assert np.abs(Xt.grad.cpu().numpy() - wg).max() < 1e-4 * np.abs(wg).max()
+print('ok')
+""" % (str(__import__("conftest").ROOT),)
+    import os
+    env = dict(os.environ, MDE_GROUP=group)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_zero_distance_edges_contribute_nothing():
+    # average_distortion.py:81-88: g = NaN/Inf -> 1.0 but diff = 0, so the gradient stays finite
+    import pymde_amd
+    pen = pymde_amd.penalties
+    n = 6
+    edges = np.array([[0, 1], [1, 2], [3, 4], [0, 5]])
+    X = np.array([[0, 0], [0, 0], [1, 0], [2, 2], [2, 2], [0.5, 1]], dtype=np.float32)
+    w = torch.tensor([1.0, 2.0, -1.0, 1.0])
+    for f, fd in ((pen.Log1p(w.abs()), oracle.func("LOG1P", w.abs().numpy(), None, (1.5,))),
+                  (pen.PushAndPull(w, pen.Log1p, pen.Log), oracle.func("LOG1P", w.numpy(), None, (1.5,), "LOG", (1.0,))),
+                  (pen.Linear(w.abs()), oracle.func("LINEAR", w.abs().numpy()))):
+        _, E, grad = _hip_eval(n, 2, edges, f, X)
+        wE, wgrad = oracle.average_distortion(edges, X, fd)
+        assert np.isfinite(grad).all()
+        assert_grad_close(grad, wgrad)
+        assert (np.isinf(E) and np.isinf(wE)) or E == pytest.approx(wE, rel=1e-5)
+
+
+def test_scalar_weight_broadcast_and_grad_output():
+    import pymde_amd
+    rng = np.random.default_rng(0)
+    n, p = 500, 3000
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    edges = np.stack([i, j], 1)
+    X = rng.standard_normal((n, 3)).astype(np.float32)
+    f = pymde_amd.penalties.Huber(torch.tensor(2.0))  # weights.nelement() == 1 (penalties.py:224-227)
+    mde = pymde_amd.MDE(n, 3, edges, f)
+    Xt = torch.tensor(X, device=DEV, requires_grad=True)
+    (3.0 * mde.average_distortion(Xt)).backward()  # upstream scalar (average_distortion.py:105)
+    wE, wgrad = oracle.average_distortion(edges, X, oracle.func("HUBER", [2.0], None, (0.5,)), grad_output=3.0)
+    assert_grad_close(Xt.grad.cpu().numpy(), wgrad)
+    assert float(mde.average_distortion(Xt.detach())) == pytest.approx(wE, rel=1e-5)
+
+
+def test_arbitrary_callable_takes_the_unfused_path():
+    """Any Python callable on distances is a legal distortion function
+    (docs_src/source/mde/index.rst:300-306): gather/scatter stay on the HIP kernels."""
+    import pymde_amd
+    rng = np.random.default_rng(1)
+    n, p = 800, 6000
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    edges = np.stack([i, j], 1)
+    X = rng.standard_normal((n, 2)).astype(np.float32)
+    w = torch.tensor(rng.uniform(0.5, 2, p).astype(np.float32), device=DEV)
+
+    def custom(distances):
+        return w * torch.log1p(distances.pow(1.5))
+    mde = pymde_amd.MDE(n, 2, edges, custom)
+    assert not mde._binding().fused
+    Xt = torch.tensor(X, device=DEV, requires_grad=True)
+    E = mde.average_distortion(Xt)
+    E.backward()
+    wE, wgrad = oracle.average_distortion(edges, X, oracle.func("LOG1P", w.cpu().numpy(), None, (1.5,)))
+    assert float(E) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(Xt.grad.cpu().numpy(), wgrad)
+    # composition of built-in functions differentiates through the element-wise HIP kernel
+    f2 = pymde_amd.penalties.Log1p(w)
+    mde2 = pymde_amd.MDE(n, 2, edges, lambda dd: 0.5 * f2(dd) + 0.5 * f2(dd))
+    Xt2 = torch.tensor(X, device=DEV, requires_grad=True)
+    mde2.average_distortion(Xt2).backward()
+    assert_grad_close(Xt2.grad.cpu().numpy(), wgrad)
+
+
+def test_distances_differences_and_norm_backward(golden_functions):
+    import pymde_amd
+    g = golden_functions
+    edges, n = g["edges"], int(g["n"])
+    for tag in ("d1", "d2", "d3", "d8", "zero"):
+        X = g["X_zero"] if tag == "zero" else g["X_" + tag]
+        mde = pymde_amd.MDE(n, X.shape[1], edges, pymde_amd.penalties.Quadratic(torch.ones(len(edges))))
+        Xt = torch.tensor(X, device=DEV)
+        np.testing.assert_allclose(mde.distances(Xt).cpu().numpy(), g[tag + "__distances"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(mde.differences(Xt).cpu().numpy(), g[tag + "__differences"])
+        Xg = Xt.clone().requires_grad_(True)
+        gout = torch.linspace(0.5, 1.5, len(edges), device=DEV)
+        (mde.distances(Xg) * gout).sum().backward()
+        want = oracle.distances_backward(edges, X, gout.cpu().numpy())
+        assert_grad_close(Xg.grad.cpu().numpy(), want)
+    # test_optim.py:57-71: sub-gradient 0 at coincident points
+    mde = pymde_amd.MDE(3, 3, np.array([(0, 1)]), pymde_amd.penalties.Quadratic(torch.ones(1)))
+    Xo = torch.ones((3, 3), requires_grad=True, device=DEV)
+    mde.distances(Xo).backward()
+    np.testing.assert_array_equal(Xo.grad.cpu().numpy(), g["norm_grad_zero"])
+
+
+def test_high_distortion_pairs_sorted():
+    import pymde_amd
+    rng = np.random.default_rng(2)
+    n = 100
+    edges = np.stack(np.triu_indices(n, 1), 1)[:900]
+    mde = pymde_amd.MDE(n, 2, edges, pymde_amd.penalties.Cubic(torch.ones(900)))
+    X = torch.tensor(rng.standard_normal((n, 2)).astype(np.float32), device=DEV)
+    pairs, dist = mde.high_distortion_pairs(X)
+    dd = dist.cpu().numpy()
+    assert (np.diff(dd) <= 0).all() and pairs.shape == (900, 2)
+
+
+# ---------------------------------------------------------------- constraints
+def test_constraints_against_reference_golden(golden_constraints):
+    import pymde_amd
+    g = golden_constraints
+    std, cen = pymde_amd.Standardized(), pymde_amd.Centered()
+    for n, d in g["shapes"]:
+        tag = "%dx%d" % (n, d)
+        X = torch.tensor(g["X_" + tag], device=DEV)
+        Z = torch.tensor(g["Z_" + tag], device=DEV)
+        P = std.project_onto_constraint(X, inplace=False)
+        np.testing.assert_allclose(P.cpu().numpy(), g["std_retract_" + tag], rtol=2e-3, atol=5e-4)
+        Pn = P.double().cpu().numpy()
+        np.testing.assert_allclose(Pn.T @ Pn / n, np.eye(d), rtol=1e-4, atol=1e-5)  # test_util.py:20-71
+        np.testing.assert_allclose(Pn.mean(0), 0, atol=1e-5)
+        Pref = torch.tensor(g["std_retract_" + tag], device=DEV)
+        T = std.project_onto_tangent_space(Pref, Z, inplace=False)
+        np.testing.assert_allclose(T.cpu().numpy(), g["std_tangent_" + tag], rtol=1e-4, atol=1e-5)
+        C = cen.project_onto_constraint(X, inplace=False)
+        np.testing.assert_allclose(C.cpu().numpy(), g["centered_" + tag], rtol=1e-5, atol=1e-6)
+        assert torch.equal(X, torch.tensor(g["X_" + tag], device=DEV))  # inplace=False leaves X alone
+    anc = pymde_amd.Anchored(torch.tensor(g["anchors"]), torch.tensor(g["anchor_values"]))
+    Z = torch.tensor(g["anchor_Z"], device=DEV)
+    np.testing.assert_array_equal(anc.project_onto_tangent_space(None, Z, inplace=False).cpu().numpy(),
+                                  g["anchor_tangent"])
+    np.testing.assert_array_equal(anc.project_onto_constraint(Z, inplace=False).cpu().numpy(),
+                                  g["anchor_retract"])
+
+
+@pytest.mark.parametrize("n,d", [(2, 2), (10, 3), (100, 3), (1000, 2), (1000, 3), (1000, 250), (5000, 128),
+                                 (3000, 64), (777, 96)])
+def test_proj_standardized_property(n, d):
+    # pymde/test_util.py:20-71 (shapes incl. (1000, 250)); d = 64/96/128 take the f32 MFMA Gram
+    from pymde_amd import util
+    torch.manual_seed(0)
+    X = torch.randn((n, d), device=DEV)
+    demean = n > 2
+    P = util.proj_standardized(X, demean=demean).double().cpu().numpy()
+    np.testing.assert_allclose(P.T @ P / n, np.eye(d), rtol=1e-4, atol=2e-5)
+    if demean:
+        np.testing.assert_allclose(P.mean(0), 0, atol=1e-5)
+        want = oracle.proj_standardized(X.cpu().numpy(), demean=True)
+        np.testing.assert_allclose(P, want, rtol=2e-3, atol=5e-4)
+
+
+def test_standardized_initialization():
+    # pymde/test_optim.py:14-18
+    import pymde_amd
+    torch.manual_seed(0)
+    X = pymde_amd.Standardized().initialization(5, 3, device=DEV).double().cpu().numpy()
+    np.testing.assert_allclose(X.T @ X / 5, np.eye(3), rtol=1e-4, atol=1e-5)
+    Xc = pymde_amd.Centered().initialization(1000, 2, device=DEV)
+    assert abs(float(Xc.mean())) < 1e-6
+
+
+@pytest.mark.parametrize("da,db", [(32, 32), (64, 128), (128, 128), (33, 7), (9, 9), (250, 250)])
+def test_gram_mfma_and_generic_paths(da, db):
+    import ctypes
+    from pymde_amd import _lib, util
+    lib = _lib.load()
+    n = 4321
+    torch.manual_seed(1)
+    A = torch.randn((n, da), device=DEV)
+    B = torch.randn((n, db), device=DEV) + 0.5
+    out = torch.empty((da, db), dtype=torch.float64, device=DEV)
+    work = util.work_buffer(torch.device(DEV), max(da, db))
+    _lib.check(lib.mde_gram(n, da, db, _lib.ptr(A), _lib.ptr(B), _lib.ptr(out), _lib.ptr(work),
+                            _lib.stream_ptr()))
+    want = A.double().T @ B.double()
+    # asymmetric inputs: a transposed C/D mapping of the MFMA tile would fail here
+    np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-3)
+
+
+# ---------------------------------------------------------------- determinism and invariants
+def test_bitwise_reproducible_and_translation_invariant():
+    import pymde_amd
+    rng = np.random.default_rng(3)
+    n, p = 20000, 400000
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    edges = torch.tensor(np.stack([i, j], 1), device=DEV)
+    w = torch.tensor(np.where(rng.random(p) < 0.3, -1.0, 1.5).astype(np.float32), device=DEV)
+    f = pymde_amd.penalties.PushAndPull(w, pymde_amd.penalties.Log1p, pymde_amd.penalties.Log)
+    X = torch.tensor(rng.standard_normal((n, 2)).astype(np.float32), device=DEV)
+    grads, losses = [], []
+    for _ in range(3):
+        mde = pymde_amd.MDE(n, 2, edges, f)  # a fresh plan every time
+        Xt = X.clone().requires_grad_(True)
+        E = mde.average_distortion(Xt)
+        E.backward()
+        grads.append(Xt.grad.clone())
+        losses.append(E.detach().clone())
+    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2])
+    assert torch.equal(losses[0], losses[1])
+    # E depends on differences only: the gradient rows sum to ~0
+    s = grads[0].double().sum(0).abs().max().item()
+    assert s < 1e-4 * grads[0].abs().max().item() * np.sqrt(n)

@@ -1,0 +1,254 @@
+"""embed(): the device-resident projected L-BFGS against the reference's recorded
+trajectories (tests/golden/trajectories.npz, cycle.npz) and solver-level properties.
+
+Tolerance tiers: first iterations of the trajectory rtol 1e-3 (fp32
+summation order makes the iterates drift apart afterwards -- the reference differs from
+itself by O(1) in X between 1 and 8 threads); end of solve: final average distortion within
+1e-2 relative; constraint residuals at the projection tolerance; no element-wise comparison
+of the final embedding."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _problem(g, name):
+    import pymde_amd
+    pen, los = pymde_amd.penalties, pymde_amd.losses
+    n = int(g["n"])
+    edges = torch.tensor(g["edges"], device=DEV)
+    w_pos = torch.tensor(g["w_pos"], device=DEV)
+    w_mix = torch.tensor(g["w_mix"], device=DEV)
+    dev = torch.tensor(g["dev"], device=DEV)
+    d = int(g[name + "__d"])
+    cname = str(g[name + "__constraint"])
+    f = {
+        "quad_std": lambda: pen.Quadratic(w_pos),
+        "log1p_centered": lambda: pen.Log1p(w_pos),
+        "pushpull_std": lambda: pen.PushAndPull(w_mix, pen.Log1p, pen.Log),
+        "pushpull_centered_d3": lambda: pen.PushAndPull(w_mix),
+        "absolute_centered": lambda: los.Absolute(dev),
+        "huber_std": lambda: los.Huber(dev, 0.5),
+        "quadloss_anchored": lambda: los.Quadratic(dev),
+    }[name]()
+    if cname == "standardized":
+        c = pymde_amd.Standardized()
+    elif cname == "centered":
+        c = pymde_amd.Centered()
+    else:
+        c = pymde_amd.Anchored(torch.tensor(g["anchors"]), torch.tensor(g["anchor_values"]))
+    return pymde_amd.MDE(n, d, edges, f, constraint=c), c, cname
+
+
+NAMES = ["quad_std", "log1p_centered", "pushpull_std", "pushpull_centered_d3", "absolute_centered",
+         "huber_std", "quadloss_anchored"]
+
+
+def _match_member(got, members, k, rtol):
+    """Index of an ensemble member whose first k entries agree with `got`, or None."""
+    got = np.asarray(got[:k], dtype=np.float64)
+    for idx in range(members.shape[0]):
+        want = members[idx, :k]
+        if np.all(np.isfinite(want)) and np.allclose(got, want, rtol=rtol, atol=1e-7):
+            return idx
+    return None
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_trajectory_matches_reference(golden_trajectories, name):
+    """The fixture holds an ENSEMBLE of reference runs from X0 perturbed by <= 1e-5 (relative):
+    the reference's line search branches on fp32 rounding (see make_golden.py), so parity is
+    "the first iterations agree with one member to rtol 1e-3 and the run stays inside the
+    ensemble's envelope"."""
+    g = golden_trajectories
+    mde, c, cname = _problem(g, name)
+    X0 = torch.tensor(g[name + "__X0"], device=DEV)
+    mde.embed(X=X0, max_iter=12, eps=1e-9, memory_size=5)
+    s = mde.solve_stats
+    E_ref, R_ref, S_ref = g[name + "__distortions"], g[name + "__residuals"], g[name + "__steps"]
+    # iteration 0 is the plain evaluation at X0: tight
+    assert s.average_distortions[0] == pytest.approx(E_ref[0, 0], rel=1e-5)
+    assert s.residual_norms[0] == pytest.approx(R_ref[0, 0], rel=1e-4)
+    k = 3
+    idx = _match_member(s.average_distortions, E_ref, k, 1e-3)
+    assert idx is not None, (s.average_distortions[:k], E_ref[:, :k])
+    np.testing.assert_allclose(s.residual_norms[:k], R_ref[idx, :k], rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(s.step_size_percents[:k], S_ref[idx, :k], rtol=5e-3, atol=1e-5)
+    m = min(E_ref.shape[1], len(s.average_distortions))
+    lo = np.nanmin(E_ref[:, :m], axis=0)
+    hi = np.nanmax(E_ref[:, :m], axis=0)
+    got = np.array(s.average_distortions[:m])
+    assert np.all(got >= lo * (1 - 2e-2) - 1e-9) and np.all(got <= hi * (1 + 2e-2) + 1e-9), (got, lo, hi)
+    assert s.iterations == len(s.average_distortions) == len(s.residual_norms)
+    X = mde.X.double().cpu().numpy()
+    n, d = X.shape
+    if cname == "standardized":
+        np.testing.assert_allclose(X.T @ X / n, np.eye(d), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(X.mean(0), 0, atol=1e-5)
+    elif cname == "centered":
+        np.testing.assert_allclose(X.mean(0), 0, atol=1e-5)
+    else:
+        np.testing.assert_array_equal(X[g["anchors"]].astype(np.float32), g["anchor_values"])
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_end_of_solve_value(golden_trajectories, name):
+    g = golden_trajectories
+    mde, _, _ = _problem(g, name)
+    X0 = torch.tensor(g[name + "__X0"], device=DEV)
+    mde.embed(X=X0, max_iter=150, eps=1e-6, memory_size=10)
+    finals = g[name + "__final_value_150"]
+    # within 1e-2 (relative) of the reference ensemble's own spread of final values
+    assert finals.min() * (1 - 1e-2) - 1e-9 <= mde.value <= finals.max() * (1 + 1e-2) + 1e-9, (mde.value, finals)
+    assert mde.value == pytest.approx(float(mde.average_distortion(mde.X)), rel=1e-3, abs=1e-9)
+    assert mde.residual_norm == mde.solve_stats.residual_norms[-1]
+    # monotone decrease of the recorded objective (strong-Wolfe accepts only decreases)
+    E = np.array(mde.solve_stats.average_distortions)
+    assert (np.diff(E) <= 1e-6 * np.abs(E[:-1]) + 1e-12).all()
+
+
+def test_config1_cycle_graph_quadratic_loss(golden_cycle):
+    """BASELINE config 1 (scaled to n = 300): preserve_distances on a cycle graph, Quadratic
+    loss over all pairs, against the reference CPU run from the same initial point."""
+    import pymde_amd
+    g = golden_cycle
+    n = int(g["n"])
+    f = pymde_amd.losses.Quadratic(torch.tensor(g["deviations"], device=DEV))
+    mde = pymde_amd.MDE(n, 2, torch.tensor(g["edges"], device=DEV), f)
+    mde.embed(X=torch.tensor(g["X0"], device=DEV), max_iter=40, eps=1e-8)
+    E = np.array(mde.solve_stats.average_distortions)
+    assert _match_member(E, g["distortions"], 3, 1e-3) is not None, (E[:3], g["distortions"][:, :3])
+    finals = g["final_value"]
+    assert finals.min() * (1 - 1e-2) <= mde.value <= finals.max() * (1 + 1e-2)
+    # a cycle embeds as a circle: all radii equal
+    X = mde.X.cpu().numpy()
+    r = np.linalg.norm(X - X.mean(0), axis=1)
+    assert r.std() / r.mean() < 0.05
+
+
+def test_embed_api_and_stats():
+    import pymde_amd
+    torch.manual_seed(0)
+    n = 500
+    edges = pymde_amd.all_edges(40)
+    rng = np.random.default_rng(0)
+    i = rng.integers(0, n, 4000)
+    j = (i + 1 + rng.integers(0, n - 1, 4000)) % n
+    edges = torch.tensor(np.stack([i, j], 1))
+    mde = pymde_amd.MDE(n, 2, edges, pymde_amd.penalties.Quadratic(torch.ones(4000)),
+                        constraint=pymde_amd.Standardized())
+    assert "standardized" in str(mde) and mde.X is None
+    with pytest.raises(ValueError):
+        mde.average_distortion()
+    X = mde.embed(max_iter=30, snapshot_every=10, verbose=False)
+    assert X is mde.X and X.is_cuda and X.shape == (n, 2)
+    s = mde.solve_stats
+    assert len(s.snapshots) == (s.iterations + 9) // 10 and not s.snapshots[0].is_cuda
+    assert len(s.times) == s.iterations and s.solve_time > 0
+    assert "iterations" in str(s)
+    # warm start from the solution converges immediately-ish and does not move far
+    X2 = mde.embed(X=X, max_iter=5)
+    assert float(mde.average_distortion(X2)) <= s.average_distortions[-1] * (1 + 1e-5)
+    with pytest.raises(ValueError):
+        mde.embed(memory_size=0)
+    # eps reached -> early stop
+    mde.embed(eps=1e9, max_iter=50)
+    assert mde.solve_stats.iterations == 1
+
+
+def test_custom_constraint_and_callable_take_the_generic_path():
+    """A user-defined Constraint object and a plain callable still solve (callbacks in Python,
+    vectors on the device)."""
+    import pymde_amd
+    from pymde_amd import constraints
+
+    class Scaled(constraints.Constraint):  # rows mean zero, Frobenius norm sqrt(n)
+        def name(self):
+            return "scaled"
+
+        def initialization(self, n_items, embedding_dim, device=None):
+            X = torch.randn((int(n_items), int(embedding_dim)), device=device)
+            return self.project_onto_constraint(X)
+
+        def project_onto_constraint(self, Z, inplace=True):
+            W = Z if inplace else Z.clone()
+            W.sub_(W.mean(0))
+            W.mul_((W.shape[0] ** 0.5) / W.norm())
+            return W
+
+        def project_onto_tangent_space(self, X, Z, inplace=True):
+            W = Z if inplace else Z.clone()
+            W.sub_(W.mean(0))
+            W.sub_(X * ((W * X).sum() / (X * X).sum()))
+            return W
+
+    rng = np.random.default_rng(0)
+    n, p = 300, 2500
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    w = torch.tensor(rng.uniform(0.5, 2, p).astype(np.float32), device=DEV)
+    mde = pymde_amd.MDE(n, 2, np.stack([i, j], 1), lambda d: w * d.pow(2), constraint=Scaled())
+    torch.manual_seed(1)
+    X = mde.embed(max_iter=40)
+    E = mde.solve_stats.average_distortions
+    assert E[-1] < 0.7 * E[0]
+    assert abs(float(X.norm()) - n ** 0.5) < 1e-2 and abs(float(X.mean())) < 1e-5
+
+
+def test_sharded_evaluation_sums_to_the_full_one():
+    """Two vertex-range shards evaluated on this one GPU: their [grad | loss] buffers add up
+    (bitwise for the gradient) to the unsharded evaluation -- what the RCCL all-reduce does."""
+    import pymde_amd
+    from pymde_amd import distributed
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    rng = np.random.default_rng(4)
+    n, p, d = 5000, 80000, 2
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    edges = torch.tensor(np.stack([i, j], 1), device=DEV)
+    w = torch.tensor(rng.uniform(0.5, 2, p).astype(np.float32), device=DEV)
+    f = pymde_amd.penalties.Log1p(w)
+    X = torch.tensor(rng.standard_normal((n, d)).astype(np.float32), device=DEV)
+    full = torch.zeros(n * d + 1, device=DEV)
+    fused_evaluate(Binding(EdgePlan(n, edges), f), X, full[:n * d].view(n, d), full[n * d:])
+    bounds = distributed.shard_bounds(n, edges, 2)
+    total = torch.zeros_like(full)
+    for r in range(2):
+        lo, hi = distributed.shard_range(bounds, r)
+        buf = torch.zeros_like(full)
+        fused_evaluate(Binding(EdgePlan(n, edges, lo, hi), f), X, buf[:n * d].view(n, d), buf[n * d:])
+        assert float(buf[:lo * d].abs().sum()) == 0 and float(buf[hi * d:n * d].abs().sum()) == 0
+        total += buf
+    assert torch.equal(total[:n * d], full[:n * d])
+    assert float(total[n * d]) == pytest.approx(float(full[n * d]), rel=1e-6)
+    # ShardedMDE with world_size 1 behaves like MDE
+    smde = distributed.ShardedMDE(n, d, edges, f, rank=0, world_size=1)
+    Xt = X.clone().requires_grad_(True)
+    E = smde.average_distortion(Xt)
+    E.backward()
+    assert torch.equal(Xt.grad.reshape(-1), full[:n * d]) and float(E) == pytest.approx(float(full[n * d]))
+
+
+def test_spectral_initialiser(golden_spectral):
+    # pymde/test_quadratic.py:67-109: same subspace as the ARPACK eigenvectors
+    from pymde_amd import quadratic
+    g = golden_spectral
+    for key, n, m in (("small", 12, 3), ("mid", 400, 2)):
+        torch.manual_seed(0)
+        emb = quadratic.spectral(n, m, torch.tensor(g[key + "_edges"], device=DEV),
+                                 torch.tensor(g[key + "_weights"], device=DEV)).double().cpu().numpy()
+        np.testing.assert_allclose(emb.T @ emb / n, np.eye(m), atol=1e-4)
+        want = g[key + "_emb"].astype(np.float64)
+        Q, _ = np.linalg.qr(want)
+        resid = emb - Q @ (Q.T @ emb)
+        assert np.linalg.norm(resid) / np.linalg.norm(emb) < 2e-2, key
+    import pymde_amd
+    n, m = 400, 2
+    mde = pymde_amd.MDE(n, m, torch.tensor(g["mid_edges"], device=DEV),
+                        pymde_amd.penalties.Quadratic(torch.tensor(g["mid_weights"], device=DEV)),
+                        constraint=pymde_amd.Standardized())
+    torch.manual_seed(0)
+    emb = quadratic.spectral(n, m, mde.edges, torch.tensor(g["mid_weights"], device=DEV))
+    assert float(mde.average_distortion(emb)) == pytest.approx(float(g["mid_value"]), rel=1e-3)

@@ -1,0 +1,215 @@
+"""Host-side logic that needs no GPU: the C-ABI library exports what include/mde_hip.h
+declares, the line search / L-BFGS coefficient recursion, function descriptors, and the
+loud failure when there is no GPU."""
+import ctypes
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from pymde_amd import _lib, lbfgs
+
+
+# ---------------------------------------------------------------- the C ABI
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mde_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mde_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()  # loads (and builds if needed) without a GPU; no compute calls here
+    declared = _declared_symbols()
+    assert len(declared) >= 35
+    for name in declared:
+        assert hasattr(lib, name), "libmde_hip.so does not export %s" % name
+    # and the ctypes table binds exactly the declared set
+    assert sorted(_lib.SYMBOLS) == declared
+    assert lib.mde_abi_version() == 1
+    assert lib.mde_work_doubles(2) > 0
+
+
+def test_mde_func_struct_layout_matches_header():
+    # struct mde_func: 2 x int32, 2 x pointer, 2 x int32, 6 x float (include/mde_hip.h)
+    assert ctypes.sizeof(_lib.MdeFunc) == 8 + 16 + 8 + 24
+    assert _lib.MdeFunc.a0.offset == 8 and _lib.MdeFunc.s0.offset == 32
+
+
+# ---------------------------------------------------------------- no GPU -> loud failure
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_fails_loudly():
+    import pymde_amd
+    edges = torch.tensor([[0, 1], [1, 2]])
+    with pytest.raises(RuntimeError, match="GPU|cuda"):
+        pymde_amd.MDE(3, 2, edges, pymde_amd.penalties.Quadratic(torch.ones(2)))
+    with pytest.raises(RuntimeError, match="no CPU path|CPU"):
+        pymde_amd.MDE(3, 2, edges, pymde_amd.penalties.Quadratic(torch.ones(2)), device="cpu")
+    with pytest.raises(RuntimeError):
+        pymde_amd.penalties.Quadratic(torch.ones(2))(torch.ones(2))
+
+
+# ---------------------------------------------------------------- function descriptors
+def test_function_descriptors():
+    from pymde_amd import losses, penalties
+    from pymde_amd.functions.function import KIND
+    w = torch.tensor([1.0, -1.0, 2.0, 0.0])
+    f = penalties.PushAndPull(w, penalties.Log1p, penalties.Log)
+    s = f._hip_spec()
+    assert (s.kind, s.kind_neg) == (KIND["LOG1P"], KIND["LOG"])
+    assert s.scalars[0] == 1.5 and s.scalars_neg[0] == 1.0
+    assert f.pos_idx.tolist() == [True, False, True, True]  # zero weight is attractive
+    assert f.attractive_penalty.weights.tolist() == [1.0, 2.0, 0.0]
+    assert f.repulsive_penalty.weights.tolist() == [-1.0]
+    assert set(dict(f.named_buffers())) >= {"weights", "pos_idx"}
+    h = penalties.Huber(torch.ones(3))
+    assert h._hip_spec().scalars[0] == 0.5
+    with pytest.raises(ValueError):
+        penalties.Huber(torch.ones(3), threshold=-1)
+    with pytest.raises(ValueError):
+        penalties.InvPower(torch.ones(3))
+    with pytest.raises(ValueError):
+        penalties.PushAndPull(torch.ones(1))
+    q = losses.WeightedQuadratic(torch.tensor([1.0, 2.0]))
+    np.testing.assert_allclose(q.weights.numpy(), [1.0, 0.25])
+    assert q._hip_spec().kind == KIND["L_WEIGHTED_QUADRATIC"] and q._hip_spec().a1 is q.weights
+    assert losses.SoftFractional(torch.ones(2))._hip_spec().scalars[0] == 10.0
+    with pytest.raises(ValueError):
+        losses.SoftFractional(torch.ones(2), gamma=0.0)
+    # every public class of the reference surface exists
+    for name in ("Linear Quadratic Cubic Power Huber Logistic Sigmoid Hinge Log1p Log InvPower "
+                 "LogRatio PushAndPull").split():
+        assert hasattr(penalties, name)
+    for name in ("Quadratic WeightedQuadratic Huber Cubic Power Absolute Logistic Fractional "
+                 "SoftFractional").split():
+        assert hasattr(losses, name)
+
+
+# ---------------------------------------------------------------- line search
+def test_cubic_interpolate():
+    # minimiser of f(x) = (x - 1)^2 from the points 0 and 3
+    assert lbfgs.cubic_interpolate(0.0, 1.0, -2.0, 3.0, 4.0, 4.0) == pytest.approx(1.0)
+    # negative discriminant -> bisection
+    assert lbfgs.cubic_interpolate(0.0, 0.0, 4.0, 1.0, 3.0, 4.0) == pytest.approx(0.5)
+    # clipped to the bounds
+    assert lbfgs.cubic_interpolate(0.0, 1.0, -2.0, 3.0, 4.0, 4.0, bounds=(1.5, 2.0)) == 1.5
+
+
+def _wolfe_ok(phi, t, f0, g0, c1=1e-4, c2=0.9):
+    f, g, _ = phi(t)
+    return f <= f0 + c1 * t * g0 and abs(g) <= -c2 * g0
+
+
+@pytest.mark.parametrize("case", ["quadratic", "quartic", "steep", "far"])
+def test_strong_wolfe_satisfies_the_conditions(case):
+    fns = {
+        "quadratic": (lambda t: ((t - 2.0) ** 2, 2 * (t - 2.0)), 1.0),
+        "quartic": (lambda t: ((t - 0.3) ** 4 + 0.1 * t, 4 * (t - 0.3) ** 3 + 0.1), 1.0),
+        "steep": (lambda t: (math.exp(5 * t) - 20 * t, 5 * math.exp(5 * t) - 20), 1.0),
+        "far": (lambda t: (0.5 * (t - 50.0) ** 2, t - 50.0), 0.01),
+    }
+    fn, t0 = fns[case]
+    calls = []
+
+    def phi(t):
+        f, g = fn(t)
+        calls.append(t)
+        return f, g, True
+
+    f0, g0 = fn(0.0)
+    f_t, t, n = lbfgs.strong_wolfe(phi, t0, f0, g0, d_norm=1.0)
+    assert _wolfe_ok(phi, t, f0, g0)
+    assert f_t == pytest.approx(fn(t)[0])
+    assert n <= 26
+
+
+def test_strong_wolfe_backs_off_non_finite_trials():
+    def phi(t):
+        if t > 0.3:
+            return float("nan"), float("nan"), False
+        return (t - 0.2) ** 2, 2 * (t - 0.2), True
+    f_t, t, _ = lbfgs.strong_wolfe(phi, 1.0, 0.04, -0.4, d_norm=1.0)
+    assert 0 < t <= 0.3 and f_t < 0.04
+
+    def always_nan(t):
+        return float("nan"), 0.0, True
+    with pytest.raises(lbfgs.LineSearchError):
+        lbfgs.strong_wolfe(always_nan, 1.0, 1.0, -1.0, d_norm=1.0)
+
+
+def test_strong_wolfe_matches_reference_trace_on_a_scalar_problem():
+    """Trace of the reference's _strong_wolfe (lbfgs.py:44-253) on phi(t) = (t-0.25)^2 (t+1)^2
+    started at t = 1, recorded by running the reference in the build container."""
+    def fn(t):
+        return (t - 0.25) ** 2 * (t + 1) ** 2, 2 * (t - 0.25) * (t + 1) * (2 * t + 0.75)
+    seen = []
+
+    def phi(t):
+        seen.append(t)
+        f, g = fn(t)
+        return f, g, True
+    f0, g0 = fn(0.0)
+    f_t, t, n = lbfgs.strong_wolfe(phi, 1.0, f0, g0, d_norm=1.0)
+    assert _wolfe_ok(lambda s: fn(s) + (True,), t, f0, g0)
+    assert seen[0] == 1.0 and len(seen) == n
+    assert abs(t - 0.25) < 0.2
+
+
+# ---------------------------------------------------------------- two-loop recursion
+def _two_loop(g, S, Y, H):
+    """Explicit recursion of lbfgs.py:490-507 on numpy vectors."""
+    q = -g.copy()
+    m = len(S)
+    ro = [1.0 / Y[i].dot(S[i]) for i in range(m)]
+    al = [0.0] * m
+    for i in range(m - 1, -1, -1):
+        al[i] = S[i].dot(q) * ro[i]
+        q -= al[i] * Y[i]
+    r = q * H
+    for i in range(m):
+        be = Y[i].dot(r) * ro[i]
+        r += (al[i] - be) * S[i]
+    return r
+
+
+def test_lbfgs_memory_matches_explicit_two_loop():
+    rng = np.random.default_rng(0)
+    N, hist = 50, 4
+    mem = lbfgs.LbfgsMemory(hist)
+    A = rng.standard_normal((N, N))
+    A = A @ A.T + N * np.eye(N)  # SPD quadratic -> y.s > 0
+    S, Y = [], []
+    x = rng.standard_normal(N)
+    g_prev = A @ x
+    for step in range(9):
+        d = -rng.standard_normal(N) * 0.1 - 0.05 * g_prev
+        t = 0.7
+        x = x + t * d
+        g = A @ x
+        y, s = g - g_prev, t * d
+        # the dots the device would return for (y*, s*) against the stored pairs
+        dots = [y.dot(s), y.dot(y), s.dot(g), y.dot(g)]
+        for sj, yj in zip(S, Y):
+            dots += [sj.dot(y), yj.dot(y), s.dot(yj), sj.dot(g), yj.dot(g)]
+        accepted, Sg, Yg = mem.absorb(np.array(dots))
+        assert accepted
+        S.append(s)
+        Y.append(y)
+        if len(S) > hist:
+            S.pop(0)
+            Y.pop(0)
+        assert mem.count == len(S)
+        c_g, cs, cy = mem.direction_coefficients(Sg, Yg)
+        got = c_g * g + sum(c * v for c, v in zip(cs, S)) + sum(c * v for c, v in zip(cy, Y))
+        want = _two_loop(g, S, Y, y.dot(s) / y.dot(y))
+        np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
+        g_prev = g
+    # a pair with y.s <= 1e-10 is rejected and leaves the memory untouched (lbfgs.py:472)
+    before = mem.SY.copy()
+    dots = [1e-12, 1.0, 0.0, 0.0] + [0.0] * (5 * mem.count)
+    accepted, Sg, Yg = mem.absorb(np.array(dots))
+    assert not accepted and mem.count == hist and np.array_equal(before, mem.SY)
+    assert len(Sg) == hist
