@@ -102,7 +102,8 @@ def test_end_of_solve_value(golden_trajectories, name):
     finals = g[name + "__final_value_150"]
     # within 1e-2 (relative) of the reference ensemble's own spread of final values
     assert finals.min() * (1 - 1e-2) - 1e-9 <= mde.value <= finals.max() * (1 + 1e-2) + 1e-9, (mde.value, finals)
-    assert mde.value == pytest.approx(float(mde.average_distortion(mde.X)), rel=1e-3, abs=1e-9)
+    # `value` is recorded at the start of the last step: X is one step past it (optim.py:149, 165)
+    assert float(mde.average_distortion(mde.X)) <= mde.value * (1 + 1e-5) + 1e-12
     assert mde.residual_norm == mde.solve_stats.residual_norms[-1]
     # monotone decrease of the recorded objective (strong-Wolfe accepts only decreases)
     E = np.array(mde.solve_stats.average_distortions)
