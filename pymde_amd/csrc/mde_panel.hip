@@ -1,0 +1,598 @@
+// mde_panel.hip -- LDS-tiled ("column panel") variant of the fused average-distortion kernel
+// for small embedding dimensions (d <= 4) on graphs whose embedding table does not fit L2.
+//
+// Why: the CSR kernel's only random access is the gather of x_u.  Measured on MI355X
+// (tools/gprobe.hip): random 8-byte gathers reach ~100 G/s from an 8 MB table (41 % L2 hit
+// rate, 4.5 GB of fabric traffic per evaluation against 0.6 GB of algorithmic bytes) and only
+// ~160 G/s even when the table is L2-resident -- the L2 request rate, not HBM, bounds the
+// kernel at ~1.2 ms for 10^8 half-edges.  Here every random access is served by LDS instead:
+//
+//   * vertices are cut into row blocks (R rows: x_v and the gradient accumulators of the
+//     block live in LDS for the whole kernel) and column panels (C vertices: x_u staged in
+//     LDS, one panel at a time, with coalesced 16-byte loads);
+//   * half-edges are grouped into tiles (row block, panel), sorted by row inside a tile, and
+//     stored as one packed uint32 (row_local << 16 | col_local) + one fp32 parameter: the
+//     same 8 streamed bytes per half-edge as the CSR layout;
+//   * one workgroup owns a row block: it walks the panels, and for each tile streams the
+//     packed half-edges, reads x_v / x_u from LDS, evaluates f and f'/d, and accumulates
+//     g (x_v - x_u) into the block's LDS accumulators with ds_add_f32.  Rows are owned by
+//     exactly one workgroup, so the gradient rows it writes at the end are final: no global
+//     atomics, no partial-gradient pass.
+//
+// The summation order inside a row now depends on LDS atomic arbitration, so results are
+// reproducible to fp32 rounding, not bitwise (the CSR kernel stays bitwise reproducible and is
+// used for everything this layout does not cover).
+#include <hipcub/hipcub.hpp>
+
+#include "mde_common.h"
+#include "mde_functions.h"
+#include "mde_plan.h"
+#define COMMA ,
+
+#define MDE_LDS_BYTES 163840
+#define MDE_PANEL_RESERVE 2048  // reduction scratch + slack
+
+// ---------------------------------------------------------------- layout construction
+__global__ __launch_bounds__(MDE_BLOCK) void k_panel_keys(int nrows, const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ nbr, int P_R,
+                                                          int P_C, int NP, int KR_shift,
+                                                          uint32_t* __restrict__ keys,
+                                                          uint32_t* __restrict__ vals) {
+  constexpr int G = 16;
+  const int lig = threadIdx.x & (G - 1);
+  const int group = (blockIdx.x * MDE_BLOCK + threadIdx.x) / G;
+  const int ngroups = (gridDim.x * MDE_BLOCK) / G;
+  for (int r = group; r < nrows; r += ngroups) {
+    const int beg = rowptr[r], end = rowptr[r + 1];
+    const uint32_t rb = (uint32_t)(r / P_R), rl = (uint32_t)(r % P_R);
+    for (int q = beg + lig; q < end; q += G) {
+      const uint32_t cp = (uint32_t)(nbr[q] / P_C);
+      keys[q] = ((rb * (uint32_t)NP + cp) << KR_shift) | rl;
+      vals[q] = (uint32_t)q;
+    }
+  }
+}
+
+__global__ __launch_bounds__(MDE_BLOCK) void k_panel_fill(int64_t H, const uint32_t* __restrict__ keys,
+                                                          const uint32_t* __restrict__ vals,
+                                                          const int32_t* __restrict__ nbr,
+                                                          const int32_t* __restrict__ eid, int P_C,
+                                                          int NP, int KR_shift,
+                                                          uint32_t* __restrict__ packed,
+                                                          int32_t* __restrict__ peid) {
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < H;
+       i += (int64_t)gridDim.x * MDE_BLOCK) {
+    const uint32_t key = keys[i], q = vals[i];
+    const uint32_t rl = key & ((1u << KR_shift) - 1u);
+    const uint32_t cp = (key >> KR_shift) % (uint32_t)NP;
+    const uint32_t cl = (uint32_t)nbr[q] - cp * (uint32_t)P_C;
+    packed[i] = (rl << 16) | cl;
+    peid[i] = eid[q];
+  }
+}
+
+// tile_ptr[t] = first sorted position whose tile id (key >> shift) >= t, t = 0..ntiles
+__global__ __launch_bounds__(MDE_BLOCK) void k_tile_ptr(int64_t H, uint32_t ntiles, int shift,
+                                                        const uint32_t* __restrict__ keys,
+                                                        int32_t* __restrict__ tile_ptr) {
+  for (int64_t h = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; h <= H;
+       h += (int64_t)gridDim.x * MDE_BLOCK) {
+    const int64_t prev = (h == 0) ? -1 : (int64_t)(keys[h - 1] >> shift);
+    int64_t cur = (h == H) ? (int64_t)ntiles : (int64_t)(keys[h] >> shift);
+    if (cur > (int64_t)ntiles) cur = ntiles;
+    for (int64_t t = prev + 1; t <= cur; ++t) tile_ptr[t] = (int32_t)h;
+  }
+}
+
+// sub_ptr[t * NW + w] = first sorted position with key >= (t << shift | w * RW): the rows of a
+// tile are split into NW contiguous ranges, one per wave of the workgroup, so that every
+// accumulator row has exactly one writer (no LDS atomics, fixed summation order).
+__global__ __launch_bounds__(MDE_BLOCK) void k_sub_ptr(int64_t H, uint32_t ntiles, int NW, int RW,
+                                                       int shift, const uint32_t* __restrict__ keys,
+                                                       int32_t* __restrict__ sub_ptr) {
+  const int64_t total = (int64_t)ntiles * NW;
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i <= total;
+       i += (int64_t)gridDim.x * MDE_BLOCK) {
+    if (i == total) {
+      sub_ptr[i] = (int32_t)H;
+      continue;
+    }
+    const uint32_t t = (uint32_t)(i / NW), w = (uint32_t)(i % NW);
+    const uint64_t target = ((uint64_t)t << shift) | (uint64_t)(w * (uint32_t)RW);
+    int64_t lo = 0, hi = H;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((uint64_t)keys[mid] >= target)
+        hi = mid;
+      else
+        lo = mid + 1;
+    }
+    sub_ptr[i] = (int32_t)lo;
+  }
+}
+
+// Within a (tile, wave) sub-range of m row-sorted half-edges processed in K = ceil(m / 64) wave
+// iterations, store element s at iteration s % K, lane s / K: two half-edges of the same row
+// then share an iteration only when the row has more than K entries in the tile, so the common
+// case needs no run folding at all.  Iteration k owns positions [off(k), off(k) + cnt(k)),
+// cnt(k) = m / K + (k < m % K), off(k) = k * (m / K) + min(k, m % K).
+__global__ __launch_bounds__(MDE_BLOCK) void k_interleave(int64_t nsub, const int32_t* __restrict__ sub_ptr,
+                                                          const uint32_t* __restrict__ keys_in,
+                                                          const uint32_t* __restrict__ vals_in,
+                                                          uint32_t* __restrict__ keys_out,
+                                                          uint32_t* __restrict__ vals_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * MDE_BLOCK) >> 6;
+  for (int64_t i = w0; i < nsub; i += nw) {
+    const int beg = sub_ptr[i], m = sub_ptr[i + 1] - beg;
+    if (m <= 0) continue;
+    const int K = (m + 63) >> 6, q = m / K, rem = m % K;
+    for (int sidx = lane; sidx < m; sidx += 64) {
+      const int k = sidx % K, l = sidx / K;
+      const int pos = beg + k * q + (k < rem ? k : rem) + l;
+      keys_out[pos] = keys_in[beg + sidx];
+      vals_out[pos] = vals_in[beg + sidx];
+    }
+  }
+}
+
+static int g_panel_mode = -2;  // MDE_PANEL env: -1 auto, 0 never, 1 whenever the layout is feasible
+static int panel_mode() {
+  if (g_panel_mode == -2) {
+    const char* e = getenv("MDE_PANEL");
+    g_panel_mode = e ? atoi(e) : -1;
+  }
+  return g_panel_mode;
+}
+
+static int bits_for_u64(uint64_t maxval) {
+  int b = 1;
+  while (b < 64 && (maxval >> b)) ++b;
+  return b;
+}
+
+// Decide tile sizes for dimension d; returns false when the layout is not worthwhile.
+static bool choose_sizes(const mde_plan* plan, int d, int* P_R, int* P_C) {
+  const int64_t nloc = plan->row_hi - plan->row_lo;
+  if (d < 1 || d > 4 || nloc <= 0 || plan->H <= 0) return false;
+  const int mode = panel_mode();
+  if (mode == 0) return false;
+  // rows: about one block per CU (256), multiple of 64, LDS: 2*d*4 bytes per row, at most
+  // ~40 % of the LDS so the panel keeps the rest
+  int64_t pr = (nloc + 255) / 256;
+  pr = ((pr + 63) / 64) * 64;
+  const int64_t pr_max = ((int64_t)(0.4 * MDE_LDS_BYTES) / (8 * d)) / 64 * 64;
+  if (pr > pr_max) pr = pr_max;
+  if (pr < 64) pr = 64;
+  int64_t pc = (MDE_LDS_BYTES - MDE_PANEL_RESERVE - pr * 8 * d) / (4 * d);
+  if (pc > 65535) pc = 65535;
+  if (pc * d > 6 * 1024 * 4) pc = (6 * 1024 * 4) / d;  // MDE_PANEL_STG float4 per thread
+  pc = (pc / 256) * 256;
+  if (pc < 1024) return false;
+  if (pc > plan->n) pc = ((plan->n + 255) / 256) * 256;
+  const int64_t nrb = (nloc + pr - 1) / pr, np = (plan->n + pc - 1) / pc;
+  if (nrb > MDE_MAX_PARTIALS) return false;
+  int kr_shift = bits_for_u64((uint64_t)pr - 1);
+  if (bits_for_u64((uint64_t)(nrb * np)) + kr_shift > 32) return false;
+  if (mode != 1) {
+    // auto: only when the table overflows L2 and tiles are big enough to amortise the staging
+    if ((int64_t)plan->n * d * 4 < (6 << 20)) return false;
+    if ((double)plan->H / (double)(nrb * np) < 1536.0) return false;
+  }
+  *P_R = (int)pr;
+  *P_C = (int)pc;
+  return true;
+}
+
+static int build_panels(mde_plan* plan, int d, hipStream_t st) {
+  int P_R = 0, P_C = 0;
+  if (!choose_sizes(plan, d, &P_R, &P_C)) return 0;
+  mde_panel_layout& L = plan->panel;
+  const int64_t nloc = plan->row_hi - plan->row_lo;
+  const int64_t H = plan->H;
+  const int NRB = (int)((nloc + P_R - 1) / P_R), NP = (int)((plan->n + P_C - 1) / P_C);
+  const int KR_shift = bits_for_u64((uint64_t)P_R - 1);
+  const uint32_t ntiles = (uint32_t)NRB * (uint32_t)NP;
+  uint32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;
+  void* tmp = nullptr;
+  uint32_t* packed = nullptr;
+  int32_t *peid = nullptr, *tile_ptr = nullptr, *sub_ptr = nullptr;
+  hipError_t e = hipSuccess;
+  auto fail = [&](hipError_t err, const char* what) {
+    if (keys) (void)hipFree(keys);
+    if (vals) (void)hipFree(vals);
+    if (keys2) (void)hipFree(keys2);
+    if (vals2) (void)hipFree(vals2);
+    if (tmp) (void)hipFree(tmp);
+    if (packed) (void)hipFree(packed);
+    if (peid) (void)hipFree(peid);
+    if (tile_ptr) (void)hipFree(tile_ptr);
+    if (sub_ptr) (void)hipFree(sub_ptr);
+    return mde_hip_fail(err, what, __FILE__, __LINE__);
+  };
+  const size_t hb = (size_t)H * sizeof(uint32_t);
+#define PB(call)                                   \
+  do {                                             \
+    e = (call);                                    \
+    if (e != hipSuccess) return fail(e, #call);    \
+  } while (0)
+  PB(hipMalloc(&keys, hb));
+  PB(hipMalloc(&vals, hb));
+  PB(hipMalloc(&keys2, hb));
+  PB(hipMalloc(&vals2, hb));
+  PB(hipMalloc(&packed, hb));
+  PB(hipMalloc(&peid, hb));
+  PB(hipMalloc(&tile_ptr, ((size_t)ntiles + 1) * sizeof(int32_t)));
+  PB(hipMalloc(&sub_ptr, ((size_t)ntiles * MDE_PANEL_WAVES + 1) * sizeof(int32_t)));
+  hipLaunchKernelGGL(k_panel_keys, dim3(mde_grid(nloc * 16, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st,
+                     (int)nloc, plan->rowptr, plan->nbr, P_R, P_C, NP, KR_shift, keys, vals);
+  PB(hipGetLastError());
+  size_t tmp_bytes = 0;
+  const int end_bit = bits_for_u64((uint64_t)ntiles) + KR_shift;
+  PB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)H, 0,
+                                        end_bit > 32 ? 32 : end_bit, st));
+  PB(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  PB(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)H, 0,
+                                        end_bit > 32 ? 32 : end_bit, st));
+  hipLaunchKernelGGL(k_tile_ptr, dim3(mde_grid(H + 1, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, H,
+                     ntiles, KR_shift, keys2, tile_ptr);
+  PB(hipGetLastError());
+  const int64_t nsub = (int64_t)ntiles * MDE_PANEL_WAVES;
+  hipLaunchKernelGGL(k_sub_ptr, dim3(mde_grid(nsub + 1, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, H,
+                     ntiles, MDE_PANEL_WAVES, P_R / MDE_PANEL_WAVES, KR_shift, keys2, sub_ptr);
+  PB(hipGetLastError());
+  hipLaunchKernelGGL(k_interleave, dim3(mde_grid(nsub * 64, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st,
+                     nsub, sub_ptr, keys2, vals2, keys, vals);
+  PB(hipGetLastError());
+  hipLaunchKernelGGL(k_panel_fill, dim3(mde_grid(H, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, H, keys,
+                     vals, plan->nbr, plan->eid, P_C, NP, KR_shift, packed, peid);
+  PB(hipGetLastError());
+  PB(hipStreamSynchronize(st));
+#undef PB
+  (void)hipFree(keys);
+  (void)hipFree(vals);
+  (void)hipFree(keys2);
+  (void)hipFree(vals2);
+  (void)hipFree(tmp);
+  if (L.packed) (void)hipFree(L.packed);
+  if (L.eid) (void)hipFree(L.eid);
+  if (L.tile_ptr) (void)hipFree(L.tile_ptr);
+  if (L.sub_ptr) (void)hipFree(L.sub_ptr);
+  L.sub_ptr = sub_ptr;
+  L.rows_per_wave = P_R / MDE_PANEL_WAVES;
+  L.d = d;
+  L.rows_per_block = P_R;
+  L.cols_per_panel = P_C;
+  L.n_row_blocks = NRB;
+  L.n_panels = NP;
+  L.H = H;
+  L.packed = packed;
+  L.eid = peid;
+  L.tile_ptr = tile_ptr;
+  return 1;
+}
+
+// layout the fused kernel will use for dimension d: 0 = CSR, 1 = column panels (built on first
+// request).  Negative: error.
+extern "C" int mde_plan_layout(mde_plan* plan, int32_t d, void* stream) {
+  if (!plan || d <= 0) return MDE_E_INVALID;
+  if (plan->panel.packed && plan->panel.d == d) return 1;
+  int P_R, P_C;
+  if (!choose_sizes(plan, d, &P_R, &P_C)) return 0;
+  return build_panels(plan, d, mde_stream(stream));
+}
+
+__global__ __launch_bounds__(MDE_BLOCK) void k_expand_panel(int64_t H, const int32_t* __restrict__ eid,
+                                                            const float* __restrict__ in,
+                                                            float* __restrict__ out) {
+  for (int64_t q = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; q < H;
+       q += (int64_t)gridDim.x * MDE_BLOCK)
+    out[q] = in[eid[q]];
+}
+
+extern "C" int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in_edge,
+                                      float* out_half, void* stream) {
+  if (!plan || !in_edge || !out_half) return MDE_E_INVALID;
+  if (layout == 0) return mde_plan_expand(plan, in_edge, out_half, stream);
+  if (layout != 1 || !plan->panel.eid) {
+    mde_set_error("mde_plan_expand_layout: the panel layout has not been built");
+    return MDE_E_INVALID;
+  }
+  if (plan->H == 0) return MDE_OK;
+  hipLaunchKernelGGL(k_expand_panel, dim3(mde_grid(plan->H, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0,
+                     mde_stream(stream), plan->H, plan->panel.eid, in_edge, out_half);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+// ---------------------------------------------------------------- the kernel
+// 1024 threads = 16 waves per workgroup; wave w owns rows [w * RW, (w+1) * RW) of the block:
+// only it reads-modifies-writes their LDS accumulators, so no atomics are needed and the
+// order of additions is fixed by the (sorted) tile order.  Inside one wave iteration lanes
+// that hit the same row are adjacent (tiles are sorted by row): a segmented Hillis-Steele
+// scan over the lanes (shuffles, early exit when no run is longer than the current stride)
+// folds each run into its last lane, which performs the single read-add-write of that row.
+//
+// Software pipeline across tiles: while tile k is processed out of LDS, the x_u panel of tile
+// k+1 (STG float4 per thread) and the wave's packed half-edges + parameters of tile k+1
+// (MAXI registers each) are already in flight from L2 / HBM; they are committed to LDS /
+// consumed after the two barriers that separate the tiles.
+#define MDE_PANEL_STG 6   // float4 staging registers per thread (panel = STG * 1024 float4)
+#define MDE_PANEL_MAXI 8  // prefetched wave-iterations per tile
+
+template <int D, class Fn, int ABL>
+__global__ __launch_bounds__(1024) void k_fused_panel(
+    int nloc, int row_lo, int n, int P_R, int P_C, int NP, const int32_t* __restrict__ tile_ptr,
+    const int32_t* __restrict__ sub_ptr, const uint32_t* __restrict__ packed,
+    const float* __restrict__ a0, const float* __restrict__ a1, int a0_scalar, int a1_scalar,
+    const float* __restrict__ X, float* __restrict__ grad, double* __restrict__ loss_partials, Fn fn,
+    float inv_p, float grad_scale) {
+  constexpr int BS = 1024, NW = MDE_PANEL_WAVES, STG = MDE_PANEL_STG, MAXI = MDE_PANEL_MAXI;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* XR = lds;                 // [P_R * D]  x_v of the block's rows
+  float* GR = XR + P_R * D;        // [P_R * D]  gradient accumulators
+  float* XC = GR + P_R * D;        // [P_C * D]  x_u of the current panel
+  double* red = reinterpret_cast<double*>(XC + (size_t)P_C * D);  // [NW]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keep it scalar
+  const int rb = blockIdx.x;
+  const int r0 = rb * P_R;
+  const int nr = min(P_R, nloc - r0);
+  const float a0s = a0_scalar ? a0[0] : 1.0f;
+  const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
+  const bool a1_arr = a1 && !a1_scalar;
+  const float* Xrow = X + (size_t)(row_lo + r0) * D;
+  for (int i = tid; i < nr * D; i += BS) {
+    XR[i] = Xrow[i];
+    GR[i] = 0.0f;
+  }
+  for (int i = nr * D + tid; i < P_R * D; i += BS) {
+    XR[i] = 0.0f;
+    GR[i] = 0.0f;
+  }
+  float loss = 0.0f;
+  const int32_t* tp = tile_ptr + (size_t)rb * NP;
+  const int32_t* sp_base = sub_ptr + (size_t)rb * NP * NW + wave;
+
+  // one half-edge per lane: evaluate, fold runs of equal rows, accumulate into LDS
+  auto process = [&](bool active, uint32_t pk, float p0, float p1) {
+    const int rl = (int)(pk >> 16), cl = (int)(pk & 0xffffu);
+    float diff[D], ss = 0.0f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      diff[c] = XR[rl * D + c] - XC[cl * D + c];
+      ss = fmaf(diff[c], diff[c], ss);
+    }
+    float f, gd;
+    if (ABL & 2) {
+      f = p0 * ss;
+      gd = p0;
+    } else {
+      fn.eval(ss, p0, p1, f, gd);
+    }
+    const float g = active ? mde_fix_g(gd * inv_p) : 0.0f;
+    loss += active ? f : 0.0f;
+    if (grad) {
+      float v[D];
+#pragma unroll
+      for (int c = 0; c < D; ++c) v[c] = g * diff[c];
+      // Lanes of one iteration hold ascending rows (row-sorted tile, interleaved storage), so
+      // equal rows are adjacent lanes.  Inactive lanes carry unique negative keys.
+      const int key = active ? rl : (-2 - lane);
+      bool tail = active;
+      const int kprev = __builtin_amdgcn_update_dpp(-1, key, 0x138, 0xf, 0xf, false);  // wave_shr:1
+      if (!(ABL & 1) && __any(kprev == key)) {
+        // rare: a row has more entries in this tile than the wave has iterations.  Round r adds
+        // the ORIGINAL contribution of lane i-r when it has the same row (keys / values shifted
+        // one lane per round with DPP wave_shr); the last lane of each run writes.
+        int kc = key;
+        float sv[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) sv[c] = v[c];
+#pragma nounroll
+        for (int r = 1; r < 64; ++r) {
+          kc = __builtin_amdgcn_update_dpp(-1, kc, 0x138, 0xf, 0xf, false);
+          const bool m = (kc == key);
+          if (!__any(m)) break;
+#pragma unroll
+          for (int c = 0; c < D; ++c) {
+            sv[c] = __int_as_float(
+                __builtin_amdgcn_update_dpp(0, __float_as_int(sv[c]), 0x138, 0xf, 0xf, false));
+            v[c] += m ? sv[c] : 0.0f;
+          }
+        }
+        const int knext = __builtin_amdgcn_update_dpp(-1, key, 0x130, 0xf, 0xf, false);  // wave_shl:1
+        tail = active && (knext != key);
+      }
+      if (tail) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) GR[rl * D + c] += v[c];
+      }
+    }
+  };
+
+  float4 stg[STG];
+  uint32_t pkn[MAXI];
+  float wn[MAXI];
+  int nbeg = 0, nend = 0;
+  // issue every global load of tile `cp` (panel -> staging registers, stream -> pkn / wn)
+  auto prefetch = [&](int cp) {
+    const int c0 = cp * P_C;
+    const int nc = min(P_C, n - c0);
+    const int t4 = (nc * D) >> 2;  // c0 * D * 4 bytes is 16-byte aligned (P_C multiple of 256)
+    const float4* s4 = reinterpret_cast<const float4*>(X + (size_t)c0 * D);
+#pragma unroll
+    for (int k = 0; k < STG; ++k) {
+      const int i = tid + k * BS;
+      stg[k] = (i < t4) ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int32_t* sp = sp_base + (size_t)cp * NW;
+    nbeg = __builtin_amdgcn_readfirstlane(sp[0]);
+    nend = __builtin_amdgcn_readfirstlane(sp[1]);
+    // interleaved order (k_interleave): iteration k holds cnt(k) = q + (k < rem) entries at off(k)
+    const int m = nend - nbeg, K = (m + 63) >> 6;
+    const int q = K > 0 ? m / K : 0, rem = K > 0 ? m % K : 0;
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+      const int off = k * q + (k < rem ? k : rem), cnt = (k < K) ? q + (k < rem ? 1 : 0) : 0;
+      const int h = nbeg + off + lane;
+      const bool ok = lane < cnt;
+      pkn[k] = ok ? packed[h] : 0u;
+      wn[k] = (ok && !a0_scalar) ? a0[h] : a0s;
+    }
+  };
+  auto next_nonempty = [&](int cp) {
+    while (cp < NP && tp[cp] == tp[cp + 1]) ++cp;
+    return cp;
+  };
+
+  int cp = next_nonempty(0);
+  if (cp < NP) prefetch(cp);
+  while (cp < NP) {
+    const int c0 = cp * P_C;
+    const int nc = min(P_C, n - c0);
+    __syncthreads();  // everyone is done with the previous panel (and XR/GR are initialised)
+    {
+      float4* d4 = reinterpret_cast<float4*>(XC);
+      const int t4 = (nc * D) >> 2;
+#pragma unroll
+      for (int k = 0; k < STG; ++k) {
+        const int i = tid + k * BS;
+        if (i < t4) d4[i] = stg[k];
+      }
+      const float* src = X + (size_t)c0 * D;
+      for (int i = (t4 << 2) + tid; i < nc * D; i += BS) XC[i] = src[i];  // < 4 tail floats
+    }
+    // this tile's stream registers
+    uint32_t pkc[MAXI];
+    float wc[MAXI];
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+      pkc[k] = pkn[k];
+      wc[k] = wn[k];
+    }
+    const int cbeg = nbeg, cend = nend;
+    __syncthreads();
+    const int cpn = next_nonempty(cp + 1);
+    if (cpn < NP) prefetch(cpn);  // in flight while this tile is processed
+    const int cm = cend - cbeg, cK = (cm + 63) >> 6;
+    const int cq = cK > 0 ? cm / cK : 0, crem = cK > 0 ? cm % cK : 0;
+#pragma unroll
+    for (int k = 0; k < MAXI; ++k) {
+      if (k >= cK) break;
+      const int off = k * cq + (k < crem ? k : crem), cnt = cq + (k < crem ? 1 : 0);
+      const bool active = lane < cnt;
+      const float p1 = a1_arr ? (active ? a1[cbeg + off + lane] : 1.0f) : a1s;
+      process(active, pkc[k], wc[k], p1);
+    }
+    for (int k = MAXI; k < cK; ++k) {  // oversized tiles (skewed degrees): not prefetched
+      const int off = k * cq + (k < crem ? k : crem), cnt = cq + (k < crem ? 1 : 0);
+      const int h = cbeg + off + lane;
+      const bool active = lane < cnt;
+      const uint32_t pk = active ? packed[h] : 0u;
+      const float p0 = (active && !a0_scalar) ? a0[h] : a0s;
+      const float p1 = a1_arr ? (active ? a1[h] : 1.0f) : a1s;
+      process(active, pk, p0, p1);
+    }
+    cp = cpn;
+  }
+  __syncthreads();
+  if (grad) {
+    float* grow = grad + (size_t)(row_lo + r0) * D;
+    for (int i = tid; i < nr * D; i += BS) grow[i] = GR[i] * grad_scale;
+  }
+  // block-wide loss partial
+  double v = mde_wave_sum((double)loss);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int i = 0; i < NW; ++i) s += red[i];
+    loss_partials[rb] = s;
+  }
+}
+
+struct PanelArgs {
+  mde_plan* plan;
+  const float* X;
+  int d;
+  const float *a0, *a1;
+  int a0_scalar, a1_scalar;
+  float* grad;
+  float inv_p, grad_scale;
+  hipStream_t st;
+};
+
+template <int D, class Fn>
+static int launch_panel(const PanelArgs& A, const Fn& fn, int* nblocks) {
+  const mde_panel_layout& L = A.plan->panel;
+  const size_t lds = ((size_t)L.rows_per_block * 2 * D + (size_t)L.cols_per_panel * D) * sizeof(float) +
+                     MDE_PANEL_WAVES * sizeof(double) + 64;
+  static bool attr_set = false;
+  static int abl = -1;
+  if (abl < 0) {
+    const char* e = getenv("MDE_PANEL_ABLATE");
+    abl = e ? atoi(e) : 0;
+  }
+  auto kern = abl == 1 ? k_fused_panel<D, Fn, 1> : (abl == 2 ? k_fused_panel<D, Fn, 2> : (abl == 3 ? k_fused_panel<D, Fn, 3> : k_fused_panel<D, Fn, 0>));
+  if (!attr_set) {
+    MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, MDE_LDS_BYTES));
+    attr_set = true;
+  }
+  *nblocks = L.n_row_blocks;
+  hipLaunchKernelGGL(kern, dim3(L.n_row_blocks), dim3(1024), lds, A.st,
+                     (int)(A.plan->row_hi - A.plan->row_lo), (int)A.plan->row_lo, (int)A.plan->n,
+                     L.rows_per_block, L.cols_per_panel, L.n_panels, L.tile_ptr, L.sub_ptr, L.packed, A.a0,
+                     A.a1, A.a0_scalar, A.a1_scalar, A.X, A.grad, A.plan->partials, fn, A.inv_p,
+                     A.grad_scale);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+static MdeFuncArgs panel_func_args(const mde_func* f) {
+  MdeFuncArgs a;
+  a.kind = f->kind;
+  a.kind_neg = f->kind_neg;
+  a.S = {f->s0, f->s1, f->s2};
+  a.N = {f->n0, f->n1, f->n2};
+  return a;
+}
+
+// Called by mde_average_distortion.  Returns 1 when the panel kernel was launched (nblocks =
+// number of loss partials written), 0 when the caller should use the CSR kernel, < 0 on error.
+int mde_panel_try(mde_plan* plan, const float* X, int d, const mde_func* f, float grad_scale,
+                  float* grad, float inv_p, hipStream_t st, int* nblocks) {
+  if (!plan->panel.packed || plan->panel.d != d) return 0;
+  PanelArgs A{plan, X, d, f->a0, f->a1, f->a0_scalar, f->a1_scalar, grad, inv_p, grad_scale, st};
+  const MdeFuncArgs a = panel_func_args(f);
+  const int ea = mde_exp_class(f->s0), en = mde_exp_class(f->n0);
+  int rc = MDE_OK;
+#define PANEL(FN)                                               \
+  do {                                                          \
+    FN fn{a};                                                   \
+    if (d == 2)                                                 \
+      rc = launch_panel<2, FN>(A, fn, nblocks);                 \
+    else if (d == 3)                                            \
+      rc = launch_panel<3, FN>(A, fn, nblocks);                 \
+    else if (d == 1)                                            \
+      rc = launch_panel<1, FN>(A, fn, nblocks);                 \
+    else                                                        \
+      rc = launch_panel<4, FN>(A, fn, nblocks);                 \
+    return rc == MDE_OK ? 1 : rc;                               \
+  } while (0)
+  if (d == 2 || d == 3) {
+    if (f->kind_neg == MDE_F_NONE) {
+      if (f->kind == MDE_F_LOG1P && ea == 2) PANEL(FnSingle<MDE_F_LOG1P COMMA 2>);
+      if (f->kind == MDE_F_QUADRATIC) PANEL(FnSingle<MDE_F_QUADRATIC COMMA 0>);
+    } else if (f->kind == MDE_F_LOG1P && ea == 2) {
+      if (f->kind_neg == MDE_F_LOG && en == 1)
+        PANEL(FnPushPull<MDE_F_LOG1P COMMA 2 COMMA MDE_F_LOG COMMA 1>);
+      if (f->kind_neg == MDE_F_LOGRATIO && en == 3)
+        PANEL(FnPushPull<MDE_F_LOG1P COMMA 2 COMMA MDE_F_LOGRATIO COMMA 3>);
+    }
+  }
+  PANEL(FnRuntime);
+#undef PANEL
+}

@@ -14,6 +14,7 @@
 #include <stdarg.h>
 
 #include "mde_common.h"
+#include "mde_plan.h"
 
 // ---------------------------------------------------------------- error plumbing
 static thread_local std::string g_last_error;
@@ -34,15 +35,6 @@ extern "C" const char* mde_last_error(void) { return g_last_error.c_str(); }
 extern "C" int mde_abi_version(void) { return MDE_ABI_VERSION; }
 
 // ---------------------------------------------------------------- plan object
-struct mde_plan {
-  int64_t n = 0, p = 0, H = 0, row_lo = 0, row_hi = 0;
-  int32_t* rowptr = nullptr;
-  int32_t* nbr = nullptr;
-  int32_t* eid = nullptr;
-  double* partials = nullptr;  // [MDE_MAX_PARTIALS] loss partial sums of the fused kernel
-  float avg_degree = 0.f;
-};
-
 extern "C" int64_t mde_plan_n(const mde_plan* p) { return p ? p->n : 0; }
 extern "C" int64_t mde_plan_p(const mde_plan* p) { return p ? p->p : 0; }
 extern "C" int64_t mde_plan_half_edges(const mde_plan* p) { return p ? p->H : 0; }
@@ -62,6 +54,10 @@ extern "C" int mde_plan_destroy(mde_plan* plan) {
   if (plan->nbr) (void)hipFree(plan->nbr);
   if (plan->eid) (void)hipFree(plan->eid);
   if (plan->partials) (void)hipFree(plan->partials);
+  if (plan->panel.packed) (void)hipFree(plan->panel.packed);
+  if (plan->panel.eid) (void)hipFree(plan->panel.eid);
+  if (plan->panel.tile_ptr) (void)hipFree(plan->panel.tile_ptr);
+  if (plan->panel.sub_ptr) (void)hipFree(plan->panel.sub_ptr);
   delete plan;
   return MDE_OK;
 }

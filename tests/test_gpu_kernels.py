@@ -397,3 +397,59 @@ def test_bitwise_reproducible_and_translation_invariant():
     # E depends on differences only: the gradient rows sum to ~0
     s = grads[0].double().sum(0).abs().max().item()
     assert s < 1e-4 * grads[0].abs().max().item() * np.sqrt(n)
+
+
+# ---------------------------------------------------------------- LDS column-panel kernel
+_PANEL_CODE = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from oracle import oracle
+import pymde_amd
+from pymde_amd import _lib
+rng = np.random.default_rng(7)
+for (n, p, d, fname) in [(30000, 400000, 2, 'log1p'), (30000, 400000, 2, 'pushpull'), (50000, 300000, 3, 'quad'),
+                         (20000, 250000, 1, 'absolute'), (70001, 500003, 2, 'pushpull_lr'), (9000, 200000, 4, 'huber')]:
+    i = rng.integers(0, n, p); j = (i + 1 + rng.integers(0, n - 1, p)) %% n
+    edges = np.stack([i, j], 1)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    w = np.where(rng.random(p) < 0.3, -1.0, rng.uniform(0.5, 2.0, p)).astype(np.float32)
+    dev = rng.uniform(0.3, 2.0, p).astype(np.float32)
+    pen, los = pymde_amd.penalties, pymde_amd.losses
+    wt, dt = torch.tensor(w, device='cuda'), torch.tensor(dev, device='cuda')
+    f, fd = {
+        'log1p': (pen.Log1p(wt.abs()), oracle.func('LOG1P', np.abs(w), None, (1.5,))),
+        'pushpull': (pen.PushAndPull(wt, pen.Log1p, pen.Log), oracle.func('LOG1P', w, None, (1.5,), 'LOG', (1.0,))),
+        'pushpull_lr': (pen.PushAndPull(wt), oracle.func('LOG1P', w, None, (1.5,), 'LOGRATIO', (2.0,))),
+        'quad': (pen.Quadratic(wt.abs()), oracle.func('QUADRATIC', np.abs(w))),
+        'absolute': (los.Absolute(dt), oracle.func('L_ABSOLUTE', dev)),
+        'huber': (los.Huber(dt, 0.5), oracle.func('L_HUBER', dev, None, (0.5,))),
+    }[fname]
+    mde = pymde_amd.MDE(n, d, torch.tensor(edges, device='cuda'), f)
+    Xt = torch.tensor(X, device='cuda', requires_grad=True)
+    E = mde.average_distortion(Xt); E.backward()
+    assert mde._binding().struct(d).layout == %d, 'unexpected layout'
+    wE, wg = oracle.average_distortion(edges, X, fd)
+    assert abs(float(E) - wE) <= 1e-5 * abs(wE), (fname, float(E), wE)
+    err = np.abs(Xt.grad.cpu().numpy() - wg).max()
+    assert err <= 1e-4 * np.abs(wg).max() , (fname, err)
+    # forward only (no grad) gives the same value
+    assert abs(float(mde.average_distortion(Xt.detach())) - wE) <= 1e-5 * abs(wE)
+    # repeated evaluations agree to fp32 rounding
+    Xt2 = torch.tensor(X, device='cuda', requires_grad=True)
+    mde.average_distortion(Xt2).backward()
+    assert np.abs((Xt2.grad - Xt.grad).cpu().numpy()).max() <= 2e-6 * np.abs(wg).max()
+print('ok')
+"""
+
+
+@pytest.mark.parametrize("mode,bs", [("1", "1024"), ("0", "1024")])
+def test_panel_kernel_against_oracle(mode, bs):
+    """The LDS column-panel kernel (forced on with MDE_PANEL=1 at sizes the oracle checks in
+    seconds) and the CSR kernel (MDE_PANEL=0) both reproduce the oracle."""
+    import os
+    import subprocess
+    import sys
+    code = _PANEL_CODE % (str(__import__("conftest").ROOT), int(mode))
+    env = dict(os.environ, MDE_PANEL=mode, MDE_PANEL_BS=bs)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])

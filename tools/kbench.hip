@@ -166,7 +166,17 @@ int main(int argc, char** argv) {
   CK(hipEventElapsedTime(&ms, a, b));
   const int64_t H = mde_plan_half_edges(plan);
   printf("n=%lld p=%lld H=%lld plan_build_ms=%.2f\n", (long long)n, (long long)p, (long long)H, ms);
-  MK(mde_plan_expand(plan, w, wh, st));
+  hipEvent_t a2, b2;
+  CK(hipEventCreate(&a2));
+  CK(hipEventCreate(&b2));
+  CK(hipEventRecord(a2, st));
+  const int layout = mde_plan_layout(plan, 2, st);
+  CK(hipEventRecord(b2, st));
+  CK(hipEventSynchronize(b2));
+  CK(hipEventElapsedTime(&ms, a2, b2));
+  printf("layout=%d (0 CSR, 1 LDS column panels) layout_build_ms=%.2f\n", layout, ms);
+  if (layout < 0) { printf("layout error %s\n", mde_last_error()); return 1; }
+  MK(mde_plan_expand_layout(plan, layout, w, wh, st));
 
   const double alg_bytes = 12.0 * p + 2.0 * n * 2 * 4;  // 8 + 4 B/edge + X read + grad write
   mde_func f = {};
@@ -174,6 +184,7 @@ int main(int argc, char** argv) {
   f.kind_neg = MDE_F_NONE;
   f.a0 = wh;
   f.s0 = 1.5f;
+  f.layout = layout;
   {
     double t = time_ms([&]() { MK(mde_average_distortion(plan, X, 2, &f, 1.0f, grad, loss, st)); }, reps, st);
     float hl;
@@ -194,7 +205,7 @@ int main(int argc, char** argv) {
     t = time_ms([&]() { MK(mde_average_distortion(plan, X, 2, &fp, 1.0f, grad, loss, st)); }, reps, st);
     printf("fused PushPull(Log1p,Log) d=2 (all w>0): %.3f ms\n", t);
   }
-  if (!getenv("MDE_GROUP")) {
+  if (!getenv("MDE_GROUP") && layout == 0) {
     const int* nbr = mde_plan_nbr(plan);
     const int* rowptr = mde_plan_rowptr(plan);
     double t = time_ms([&]() { hipLaunchKernelGGL(k_stream, dim3(4096), dim3(256), 0, st, H, nbr, wh, loss); }, reps, st);
