@@ -410,6 +410,14 @@ rng = np.random.default_rng(7)
 for (n, p, d, fname) in [(30000, 400000, 2, 'log1p'), (30000, 400000, 2, 'pushpull'), (50000, 300000, 3, 'quad'),
                          (20000, 250000, 1, 'absolute'), (70001, 500003, 2, 'pushpull_lr'), (9000, 200000, 4, 'huber')]:
     i = rng.integers(0, n, p); j = (i + 1 + rng.integers(0, n - 1, p)) %% n
+    # hub vertices (degree ~ p/20 and p/50): rows with far more entries per tile than a wave has
+    # iterations exercise the run-folding slow path; vertex n-1 is isolated (empty row)
+    i[: p // 20] = 3
+    i[p // 20: p // 20 + p // 50] = n // 2
+    j[j == i] = (j[j == i] + 1) %% n
+    j[j == n - 1] = 0; i[i == n - 1] = 1
+    keep = i != j
+    i, j = i[keep], j[keep]; p = len(i)
     edges = np.stack([i, j], 1)
     X = rng.standard_normal((n, d)).astype(np.float32)
     w = np.where(rng.random(p) < 0.3, -1.0, rng.uniform(0.5, 2.0, p)).astype(np.float32)
