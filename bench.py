@@ -33,6 +33,11 @@ OUT_DEGREE = 50
 DIM = 2
 HBM_PEAK_BPS = 8.0e12           # MI355X_MICROARCH.md: 8 TB/s spec
 ALG_BYTES_PER_EDGE = 8 + 4      # two int32 endpoints + one fp32 parameter  
+# HBM-side bytes per launch of the config-4 kernel from the rocprofv3 PMC passes committed in
+# profiles/r01_pmc_summary.md (separate --pmc runs; FETCH_SIZE doubled for wide coalesced reads as
+# MI355X_MICROARCH.md prescribes, + WRITE_SIZE).  bench.py cannot collect PMC counters itself.
+PMC_TRAFFIC_BYTES = {1: 2 * 430.7e6 + 7.8e6,   # k_fused_panel  (LDS column panels)
+                     0: 4.45e9 + 9.4e6}        # k_fused_small  (CSR; narrow gather line fills, no doubling)
 
 
 def make_workload(device, n=N_ITEMS, deg=OUT_DEGREE, d=DIM):
@@ -177,7 +182,10 @@ def main():
                        if world > 1 else "single GPU",
                        "loss": gpu_loss},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BPS / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_BPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_BPS,
+                         "traffic": (PMC_TRAFFIC_BYTES.get(int(binding.struct(d).layout))
+                                     if (world == 1 and n == N_ITEMS) else None),
+                         "traffic_source": "profiles/r01_pmc_summary.md (rocprofv3 --pmc, bytes/launch)",
                          "kernel": ("k_fused_panel<2,Log1p> (LDS column panels)" if binding.struct(d).layout == 1
                                     else "k_fused_small<2,G,Log1p> (CSR)") + " + 1-block loss finalize",
                          "kernel_ms": k_ms, "alg_bytes_per_launch": alg_bytes},
