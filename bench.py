@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n", type=int, default=N_ITEMS)
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="single process: time only the kernel of rank 0 of a W-way shard (no collective)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -119,8 +121,9 @@ def main():
     edges, w, X = make_workload(device, n=n)
     p = edges.shape[0]
     f = pymde_amd.penalties.Log1p(w)
-    if world > 1:
-        bounds = distributed.shard_bounds(n, edges, world)
+    if world > 1 or args.emulate_world > 1:
+        W = world if world > 1 else args.emulate_world
+        bounds = distributed.shard_bounds(n, edges, W)
         lo, hi = distributed.shard_range(bounds, rank)
         plan = EdgePlan(n, edges, lo, hi)
     else:

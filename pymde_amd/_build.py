@@ -45,7 +45,7 @@ def build(force=False, verbose=True):
     objdir = os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
     flags = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-I", INCLUDE,
-             "-Wno-unused-result", "-ffp-contract=fast"]
+             "-Wno-unused-result", "-ffp-contract=fast"] + os.environ.get("MDE_EXTRA_FLAGS", "").split()
     objs = []
     procs = []
     for src in SOURCES:

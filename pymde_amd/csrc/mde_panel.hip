@@ -120,14 +120,19 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_interleave(int64_t nsub, const in
                                                           const uint32_t* __restrict__ keys_in,
                                                           const uint32_t* __restrict__ vals_in,
                                                           uint32_t* __restrict__ keys_out,
-                                                          uint32_t* __restrict__ vals_out) {
+                                                          uint32_t* __restrict__ vals_out,
+                                                          int32_t* __restrict__ sub_qr) {
   const int lane = threadIdx.x & 63;
   const int64_t w0 = ((int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * MDE_BLOCK) >> 6;
   for (int64_t i = w0; i < nsub; i += nw) {
     const int beg = sub_ptr[i], m = sub_ptr[i + 1] - beg;
-    if (m <= 0) continue;
+    if (m <= 0) {
+      if (lane == 0) sub_qr[i] = 0;
+      continue;
+    }
     const int K = (m + 63) >> 6, q = m / K, rem = m % K;
+    if (lane == 0) sub_qr[i] = (rem << 8) | q;  // the kernel never divides
     for (int sidx = lane; sidx < m; sidx += 64) {
       const int k = sidx % K, l = sidx / K;
       const int pos = beg + k * q + (k < rem ? k : rem) + l;
@@ -160,19 +165,23 @@ static bool choose_sizes(const mde_plan* plan, int d, int* P_R, int* P_C) {
   if (mode == 0) return false;
   // rows: about one block per CU (256), multiple of 64, LDS: 2*d*4 bytes per row, at most
   // ~40 % of the LDS so the panel keeps the rest
-  int64_t pr = (nloc + 255) / 256;
+  // (a rank that owns only n/N rows keeps the same block height as a full plan -- tiles must
+  // not get thinner -- and fills the CUs with Q column groups per row block instead)
+  int64_t pr = (plan->n + 255) / 256;
+  if (pr > nloc) pr = nloc;
   pr = ((pr + 63) / 64) * 64;
+  // (rows are padded by one slot per 32 against bank conflicts: 33/32 of the space)
   const int64_t pr_max = ((int64_t)(0.4 * MDE_LDS_BYTES) / (8 * d)) / 64 * 64;
   if (pr > pr_max) pr = pr_max;
   if (pr < 64) pr = 64;
-  int64_t pc = (MDE_LDS_BYTES - MDE_PANEL_RESERVE - pr * 8 * d) / (4 * d);
+  int64_t pc = (MDE_LDS_BYTES - MDE_PANEL_RESERVE - (pr + pr / 32) * 8 * d) / (4 * d);
   if (pc > 65535) pc = 65535;
   if (pc * d > 6 * 1024 * 4) pc = (6 * 1024 * 4) / d;  // MDE_PANEL_STG float4 per thread
   pc = (pc / 256) * 256;
   if (pc < 1024) return false;
   if (pc > plan->n) pc = ((plan->n + 255) / 256) * 256;
   const int64_t nrb = (nloc + pr - 1) / pr, np = (plan->n + pc - 1) / pc;
-  if (nrb > MDE_MAX_PARTIALS) return false;
+  if (nrb * 16 > MDE_MAX_PARTIALS) return false;
   int kr_shift = bits_for_u64((uint64_t)pr - 1);
   if (bits_for_u64((uint64_t)(nrb * np)) + kr_shift > 32) return false;
   if (mode != 1) {
@@ -197,7 +206,7 @@ static int build_panels(mde_plan* plan, int d, hipStream_t st) {
   uint32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;
   void* tmp = nullptr;
   uint32_t* packed = nullptr;
-  int32_t *peid = nullptr, *tile_ptr = nullptr, *sub_ptr = nullptr;
+  int32_t *peid = nullptr, *tile_ptr = nullptr, *sub_ptr = nullptr, *sub_qr = nullptr;
   hipError_t e = hipSuccess;
   auto fail = [&](hipError_t err, const char* what) {
     if (keys) (void)hipFree(keys);
@@ -209,6 +218,7 @@ static int build_panels(mde_plan* plan, int d, hipStream_t st) {
     if (peid) (void)hipFree(peid);
     if (tile_ptr) (void)hipFree(tile_ptr);
     if (sub_ptr) (void)hipFree(sub_ptr);
+    if (sub_qr) (void)hipFree(sub_qr);
     return mde_hip_fail(err, what, __FILE__, __LINE__);
   };
   const size_t hb = (size_t)H * sizeof(uint32_t);
@@ -225,6 +235,7 @@ static int build_panels(mde_plan* plan, int d, hipStream_t st) {
   PB(hipMalloc(&peid, hb));
   PB(hipMalloc(&tile_ptr, ((size_t)ntiles + 1) * sizeof(int32_t)));
   PB(hipMalloc(&sub_ptr, ((size_t)ntiles * MDE_PANEL_WAVES + 1) * sizeof(int32_t)));
+  PB(hipMalloc(&sub_qr, ((size_t)ntiles * MDE_PANEL_WAVES + 1) * sizeof(int32_t)));
   hipLaunchKernelGGL(k_panel_keys, dim3(mde_grid(nloc * 16, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st,
                      (int)nloc, plan->rowptr, plan->nbr, P_R, P_C, NP, KR_shift, keys, vals);
   PB(hipGetLastError());
@@ -243,7 +254,7 @@ static int build_panels(mde_plan* plan, int d, hipStream_t st) {
                      ntiles, MDE_PANEL_WAVES, P_R / MDE_PANEL_WAVES, KR_shift, keys2, sub_ptr);
   PB(hipGetLastError());
   hipLaunchKernelGGL(k_interleave, dim3(mde_grid(nsub * 64, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st,
-                     nsub, sub_ptr, keys2, vals2, keys, vals);
+                     nsub, sub_ptr, keys2, vals2, keys, vals, sub_qr);
   PB(hipGetLastError());
   hipLaunchKernelGGL(k_panel_fill, dim3(mde_grid(H, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, H, keys,
                      vals, plan->nbr, plan->eid, P_C, NP, KR_shift, packed, peid);
@@ -259,7 +270,24 @@ static int build_panels(mde_plan* plan, int d, hipStream_t st) {
   if (L.eid) (void)hipFree(L.eid);
   if (L.tile_ptr) (void)hipFree(L.tile_ptr);
   if (L.sub_ptr) (void)hipFree(L.sub_ptr);
+  if (L.sub_qr) (void)hipFree(L.sub_qr);
   L.sub_ptr = sub_ptr;
+  L.sub_qr = sub_qr;
+  if (L.partial) (void)hipFree(L.partial);
+  L.partial = nullptr;
+  // column groups: enough workgroups to fill 256 CUs, at least 4 panels per group
+  int Q = 1;
+  if (NRB < 192) {
+    Q = (256 + NRB - 1) / NRB;
+    if (Q > NP / 4) Q = NP / 4;
+    if (Q > 16) Q = 16;
+    if (Q < 1) Q = 1;
+  }
+  L.col_groups = Q;
+  if (Q > 1) {
+    hipError_t pe = hipMalloc(&L.partial, sizeof(float) * (size_t)Q * (size_t)nloc * (size_t)d);
+    if (pe != hipSuccess) return mde_hip_fail(pe, "hipMalloc(panel partials)", __FILE__, __LINE__);
+  }
   L.rows_per_wave = P_R / MDE_PANEL_WAVES;
   L.d = d;
   L.rows_per_block = P_R;
@@ -318,50 +346,68 @@ extern "C" int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, cons
 // k+1 (STG float4 per thread) and the wave's packed half-edges + parameters of tile k+1
 // (MAXI registers each) are already in flight from L2 / HBM; they are committed to LDS /
 // consumed after the two barriers that separate the tiles.
-#define MDE_PANEL_STG 6   // float4 staging registers per thread (panel = STG * 1024 float4)
-#define MDE_PANEL_MAXI 8  // prefetched wave-iterations per tile
+#define MDE_PANEL_BS (64 * MDE_PANEL_WAVES)
+#define MDE_PANEL_STG (6144 / MDE_PANEL_BS)  // float4 staging registers per thread (panel <= 6144 float4)
+#define MDE_PANEL_MAXI (128 / MDE_PANEL_WAVES)  // prefetched wave-iterations per tile
 
 template <int D, class Fn, int ABL>
-__global__ __launch_bounds__(1024) void k_fused_panel(
-    int nloc, int row_lo, int n, int P_R, int P_C, int NP, const int32_t* __restrict__ tile_ptr,
-    const int32_t* __restrict__ sub_ptr, const uint32_t* __restrict__ packed,
-    const float* __restrict__ a0, const float* __restrict__ a1, int a0_scalar, int a1_scalar,
-    const float* __restrict__ X, float* __restrict__ grad, double* __restrict__ loss_partials, Fn fn,
-    float inv_p, float grad_scale) {
-  constexpr int BS = 1024, NW = MDE_PANEL_WAVES, STG = MDE_PANEL_STG, MAXI = MDE_PANEL_MAXI;
+__global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
+    int nloc, int row_lo, int n, int P_R, int P_C, int NP, int Q, const int32_t* __restrict__ tile_ptr,
+    const int32_t* __restrict__ sub_ptr, const int32_t* __restrict__ sub_qr,
+    const uint32_t* __restrict__ packed, const float* __restrict__ a0, const float* __restrict__ a1,
+    int a0_scalar, int a1_scalar, const float* __restrict__ X, float* __restrict__ grad,
+    float* __restrict__ partial, double* __restrict__ loss_partials, Fn fn, float inv_p,
+    float grad_scale) {
+  constexpr int BS = MDE_PANEL_BS, NW = MDE_PANEL_WAVES, STG = MDE_PANEL_STG, MAXI = MDE_PANEL_MAXI;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* XR = lds;                 // [P_R * D]  x_v of the block's rows
-  float* GR = XR + P_R * D;        // [P_R * D]  gradient accumulators
-  float* XC = GR + P_R * D;        // [P_C * D]  x_u of the current panel
+  // row arrays are padded by one slot every 32 rows: interleaved tiles make the lanes of an
+  // iteration touch rows at a near-constant stride, which would otherwise pile onto few banks
+  const int PRP = P_R + (P_R >> 5);
+  float* XR = lds;                 // [PRP * D]  x_v of the block's rows
+  float* GR = XR + PRP * D;        // [PRP * D]  gradient accumulators
+  float* XC = GR + PRP * D;        // [P_C * D]  x_u of the current panel
   double* red = reinterpret_cast<double*>(XC + (size_t)P_C * D);  // [NW]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keep it scalar
-  const int rb = blockIdx.x;
+  // block b = rb * Q + qg: row block rb, column group qg walks panels [cp_lo, cp_hi)
+  const int rb = blockIdx.x / Q, qg = blockIdx.x % Q;
+  const int cp_lo = (int)(((int64_t)NP * qg) / Q), cp_hi = (int)(((int64_t)NP * (qg + 1)) / Q);
   const int r0 = rb * P_R;
   const int nr = min(P_R, nloc - r0);
   const float a0s = a0_scalar ? a0[0] : 1.0f;
   const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
   const bool a1_arr = a1 && !a1_scalar;
   const float* Xrow = X + (size_t)(row_lo + r0) * D;
-  for (int i = tid; i < nr * D; i += BS) {
-    XR[i] = Xrow[i];
-    GR[i] = 0.0f;
-  }
-  for (int i = nr * D + tid; i < P_R * D; i += BS) {
+  for (int i = tid; i < PRP * D; i += BS) {
     XR[i] = 0.0f;
     GR[i] = 0.0f;
+  }
+  __syncthreads();
+  for (int r = tid; r < nr; r += BS) {
+    const int slot = (r + (r >> 5)) * D;
+#pragma unroll
+    for (int c = 0; c < D; ++c) XR[slot + c] = Xrow[r * D + c];
   }
   float loss = 0.0f;
   const int32_t* tp = tile_ptr + (size_t)rb * NP;
   const int32_t* sp_base = sub_ptr + (size_t)rb * NP * NW + wave;
+  const int32_t* qr_base = sub_qr + (size_t)rb * NP * NW + wave;
 
-  // one half-edge per lane: evaluate, fold runs of equal rows, accumulate into LDS
-  auto process = [&](bool active, uint32_t pk, float p0, float p1) {
+  // one half-edge per lane, split in two stages so that two iterations can be in flight per wave
+  // (their LDS reads / transcendental chains are independent; only the accumulator updates are
+  // ordered): compute() evaluates, commit() folds runs of equal rows and updates the LDS row.
+  struct Item {
+    int rslot, key;
+    float v[D];
+    bool active;
+  };
+  auto compute = [&](bool active, uint32_t pk, float p0, float p1, Item& it) {
     const int rl = (int)(pk >> 16), cl = (int)(pk & 0xffffu);
+    it.rslot = (rl + (rl >> 5)) * D;
     float diff[D], ss = 0.0f;
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-      diff[c] = XR[rl * D + c] - XC[cl * D + c];
+      diff[c] = XR[it.rslot + c] - XC[cl * D + c];
       ss = fmaf(diff[c], diff[c], ss);
     }
     float f, gd;
@@ -373,49 +419,51 @@ __global__ __launch_bounds__(1024) void k_fused_panel(
     }
     const float g = active ? mde_fix_g(gd * inv_p) : 0.0f;
     loss += active ? f : 0.0f;
-    if (grad) {
-      float v[D];
 #pragma unroll
-      for (int c = 0; c < D; ++c) v[c] = g * diff[c];
-      // Lanes of one iteration hold ascending rows (row-sorted tile, interleaved storage), so
-      // equal rows are adjacent lanes.  Inactive lanes carry unique negative keys.
-      const int key = active ? rl : (-2 - lane);
-      bool tail = active;
-      const int kprev = __builtin_amdgcn_update_dpp(-1, key, 0x138, 0xf, 0xf, false);  // wave_shr:1
-      if (!(ABL & 1) && __any(kprev == key)) {
-        // rare: a row has more entries in this tile than the wave has iterations.  Round r adds
-        // the ORIGINAL contribution of lane i-r when it has the same row (keys / values shifted
-        // one lane per round with DPP wave_shr); the last lane of each run writes.
-        int kc = key;
-        float sv[D];
+    for (int c = 0; c < D; ++c) it.v[c] = g * diff[c];
+    // Lanes of one iteration hold ascending rows (row-sorted tile, interleaved storage), so
+    // equal rows are adjacent lanes.  Inactive lanes carry unique negative keys.
+    it.key = active ? rl : (-2 - lane);
+    it.active = active;
+  };
+  auto commit = [&](Item& it) {
+    if (!grad) return;
+    const int key = it.key;
+    bool tail = it.active;
+    const int kprev = __builtin_amdgcn_update_dpp(-1, key, 0x138, 0xf, 0xf, false);  // wave_shr:1
+    if (!(ABL & 1) && __any(kprev == key)) {
+      // rare: a row has more entries in this tile than the wave has iterations.  Round r adds
+      // the ORIGINAL contribution of lane i-r when it has the same row (keys / values shifted
+      // one lane per round with DPP wave_shr); the last lane of each run writes.
+      int kc = key;
+      float sv[D];
 #pragma unroll
-        for (int c = 0; c < D; ++c) sv[c] = v[c];
+      for (int c = 0; c < D; ++c) sv[c] = it.v[c];
 #pragma nounroll
-        for (int r = 1; r < 64; ++r) {
-          kc = __builtin_amdgcn_update_dpp(-1, kc, 0x138, 0xf, 0xf, false);
-          const bool m = (kc == key);
-          if (!__any(m)) break;
+      for (int r = 1; r < 64; ++r) {
+        kc = __builtin_amdgcn_update_dpp(-1, kc, 0x138, 0xf, 0xf, false);
+        const bool m = (kc == key);
+        if (!__any(m)) break;
 #pragma unroll
-          for (int c = 0; c < D; ++c) {
-            sv[c] = __int_as_float(
-                __builtin_amdgcn_update_dpp(0, __float_as_int(sv[c]), 0x138, 0xf, 0xf, false));
-            v[c] += m ? sv[c] : 0.0f;
-          }
+        for (int c = 0; c < D; ++c) {
+          sv[c] = __int_as_float(
+              __builtin_amdgcn_update_dpp(0, __float_as_int(sv[c]), 0x138, 0xf, 0xf, false));
+          it.v[c] += m ? sv[c] : 0.0f;
         }
-        const int knext = __builtin_amdgcn_update_dpp(-1, key, 0x130, 0xf, 0xf, false);  // wave_shl:1
-        tail = active && (knext != key);
       }
-      if (tail) {
+      const int knext = __builtin_amdgcn_update_dpp(-1, key, 0x130, 0xf, 0xf, false);  // wave_shl:1
+      tail = it.active && (knext != key);
+    }
+    if (tail) {
 #pragma unroll
-        for (int c = 0; c < D; ++c) GR[rl * D + c] += v[c];
-      }
+      for (int c = 0; c < D; ++c) GR[it.rslot + c] += it.v[c];
     }
   };
 
   float4 stg[STG];
   uint32_t pkn[MAXI];
   float wn[MAXI];
-  int nbeg = 0, nend = 0;
+  int nbeg = 0, nm = 0, nq = 0, nrem = 0;  // next tile's sub-range: start, size, m / K, m % K
   // issue every global load of tile `cp` (panel -> staging registers, stream -> pkn / wn)
   auto prefetch = [&](int cp) {
     const int c0 = cp * P_C;
@@ -429,27 +477,32 @@ __global__ __launch_bounds__(1024) void k_fused_panel(
     }
     const int32_t* sp = sp_base + (size_t)cp * NW;
     nbeg = __builtin_amdgcn_readfirstlane(sp[0]);
-    nend = __builtin_amdgcn_readfirstlane(sp[1]);
-    // interleaved order (k_interleave): iteration k holds cnt(k) = q + (k < rem) entries at off(k)
-    const int m = nend - nbeg, K = (m + 63) >> 6;
-    const int q = K > 0 ? m / K : 0, rem = K > 0 ? m % K : 0;
+    nm = __builtin_amdgcn_readfirstlane(sp[1]) - nbeg;
+    const int qr = __builtin_amdgcn_readfirstlane(qr_base[(size_t)cp * NW]);
+    nq = qr & 255;
+    nrem = qr >> 8;
+    // interleaved order (k_interleave): iteration k holds cnt(k) = q + (k < rem) entries
+    const int K = (nm + 63) >> 6;
+    const uint32_t* pb = packed + nbeg;  // wave-uniform bases: scalar address arithmetic
+    const float* ab = a0 + nbeg;
+    int off = 0;
 #pragma unroll
     for (int k = 0; k < MAXI; ++k) {
-      const int off = k * q + (k < rem ? k : rem), cnt = (k < K) ? q + (k < rem ? 1 : 0) : 0;
-      const int h = nbeg + off + lane;
+      const int cnt = (k < K) ? nq + (k < nrem ? 1 : 0) : 0;
       const bool ok = lane < cnt;
-      pkn[k] = ok ? packed[h] : 0u;
-      wn[k] = (ok && !a0_scalar) ? a0[h] : a0s;
+      pkn[k] = ok ? pb[off + lane] : 0u;
+      wn[k] = (ok && !a0_scalar) ? ab[off + lane] : a0s;
+      off += cnt;
     }
   };
   auto next_nonempty = [&](int cp) {
-    while (cp < NP && tp[cp] == tp[cp + 1]) ++cp;
+    while (cp < cp_hi && tp[cp] == tp[cp + 1]) ++cp;
     return cp;
   };
 
-  int cp = next_nonempty(0);
-  if (cp < NP) prefetch(cp);
-  while (cp < NP) {
+  int cp = next_nonempty(cp_lo);
+  if (cp < cp_hi) prefetch(cp);
+  while (cp < cp_hi) {
     const int c0 = cp * P_C;
     const int nc = min(P_C, n - c0);
     __syncthreads();  // everyone is done with the previous panel (and XR/GR are initialised)
@@ -472,35 +525,52 @@ __global__ __launch_bounds__(1024) void k_fused_panel(
       pkc[k] = pkn[k];
       wc[k] = wn[k];
     }
-    const int cbeg = nbeg, cend = nend;
+    const int cbeg = nbeg, cm = nm, cq = nq, crem = nrem;
+    const int cK = (cm + 63) >> 6;
     __syncthreads();
     const int cpn = next_nonempty(cp + 1);
-    if (cpn < NP) prefetch(cpn);  // in flight while this tile is processed
-    const int cm = cend - cbeg, cK = (cm + 63) >> 6;
-    const int cq = cK > 0 ? cm / cK : 0, crem = cK > 0 ? cm % cK : 0;
+    if (cpn < cp_hi) prefetch(cpn);  // in flight while this tile is processed
+    int off = 0;
 #pragma unroll
-    for (int k = 0; k < MAXI; ++k) {
+    for (int k = 0; k < MAXI; k += 2) {
       if (k >= cK) break;
-      const int off = k * cq + (k < crem ? k : crem), cnt = cq + (k < crem ? 1 : 0);
-      const bool active = lane < cnt;
-      const float p1 = a1_arr ? (active ? a1[cbeg + off + lane] : 1.0f) : a1s;
-      process(active, pkc[k], wc[k], p1);
+      const int cnt0 = cq + (k < crem ? 1 : 0);
+      const int cnt1 = (k + 1 < cK) ? cq + (k + 1 < crem ? 1 : 0) : 0;
+      const bool act0 = lane < cnt0, act1 = lane < cnt1;
+      const float p10 = a1_arr ? (act0 ? a1[cbeg + off + lane] : 1.0f) : a1s;
+      const float p11 = a1_arr ? (act1 ? a1[cbeg + off + cnt0 + lane] : 1.0f) : a1s;
+      Item ia, ib;
+      compute(act0, pkc[k], wc[k], p10, ia);
+      compute(act1, pkc[k + 1], wc[k + 1], p11, ib);
+      commit(ia);
+      commit(ib);
+      off += cnt0 + cnt1;
     }
     for (int k = MAXI; k < cK; ++k) {  // oversized tiles (skewed degrees): not prefetched
-      const int off = k * cq + (k < crem ? k : crem), cnt = cq + (k < crem ? 1 : 0);
+      const int cnt = cq + (k < crem ? 1 : 0);
       const int h = cbeg + off + lane;
       const bool active = lane < cnt;
       const uint32_t pk = active ? packed[h] : 0u;
       const float p0 = (active && !a0_scalar) ? a0[h] : a0s;
       const float p1 = a1_arr ? (active ? a1[h] : 1.0f) : a1s;
-      process(active, pk, p0, p1);
+      Item it;
+      compute(active, pk, p0, p1, it);
+      commit(it);
+      off += cnt;
     }
     cp = cpn;
   }
   __syncthreads();
   if (grad) {
-    float* grow = grad + (size_t)(row_lo + r0) * D;
-    for (int i = tid; i < nr * D; i += BS) grow[i] = GR[i] * grad_scale;
+    // Q == 1: the rows are final.  Q > 1: unscaled per-group partials, summed by k_panel_combine
+    float* grow = (Q == 1) ? grad + (size_t)(row_lo + r0) * D
+                           : partial + ((size_t)qg * nloc + r0) * D;
+    const float sc = (Q == 1) ? grad_scale : 1.0f;
+    for (int r = tid; r < nr; r += BS) {
+      const int slot = (r + (r >> 5)) * D;
+#pragma unroll
+      for (int c = 0; c < D; ++c) grow[r * D + c] = GR[slot + c] * sc;
+    }
   }
   // block-wide loss partial
   double v = mde_wave_sum((double)loss);
@@ -509,7 +579,18 @@ __global__ __launch_bounds__(1024) void k_fused_panel(
   if (tid == 0) {
     double s = 0.0;
     for (int i = 0; i < NW; ++i) s += red[i];
-    loss_partials[rb] = s;
+    loss_partials[blockIdx.x] = s;
+  }
+}
+
+// grad[row] = scale * sum_q partial[q][row]  (fixed order)
+__global__ __launch_bounds__(MDE_BLOCK) void k_panel_combine(int64_t nlocD, int Q, const float* __restrict__ partial,
+                                                             float scale, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < nlocD;
+       i += (int64_t)gridDim.x * MDE_BLOCK) {
+    float s = 0.0f;
+    for (int q = 0; q < Q; ++q) s += partial[(size_t)q * nlocD + i];
+    out[i] = s * scale;
   }
 }
 
@@ -527,7 +608,8 @@ struct PanelArgs {
 template <int D, class Fn>
 static int launch_panel(const PanelArgs& A, const Fn& fn, int* nblocks) {
   const mde_panel_layout& L = A.plan->panel;
-  const size_t lds = ((size_t)L.rows_per_block * 2 * D + (size_t)L.cols_per_panel * D) * sizeof(float) +
+  const size_t prp = (size_t)L.rows_per_block + (size_t)(L.rows_per_block >> 5);
+  const size_t lds = (prp * 2 * D + (size_t)L.cols_per_panel * D) * sizeof(float) +
                      MDE_PANEL_WAVES * sizeof(double) + 64;
   static bool attr_set = false;
   static int abl = -1;
@@ -541,13 +623,20 @@ static int launch_panel(const PanelArgs& A, const Fn& fn, int* nblocks) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, MDE_LDS_BYTES));
     attr_set = true;
   }
-  *nblocks = L.n_row_blocks;
-  hipLaunchKernelGGL(kern, dim3(L.n_row_blocks), dim3(1024), lds, A.st,
+  const int Q = L.col_groups;
+  *nblocks = L.n_row_blocks * Q;
+  hipLaunchKernelGGL(kern, dim3(L.n_row_blocks * Q), dim3(MDE_PANEL_BS), lds, A.st,
                      (int)(A.plan->row_hi - A.plan->row_lo), (int)A.plan->row_lo, (int)A.plan->n,
-                     L.rows_per_block, L.cols_per_panel, L.n_panels, L.tile_ptr, L.sub_ptr, L.packed, A.a0,
-                     A.a1, A.a0_scalar, A.a1_scalar, A.X, A.grad, A.plan->partials, fn, A.inv_p,
-                     A.grad_scale);
+                     L.rows_per_block, L.cols_per_panel, L.n_panels, Q, L.tile_ptr, L.sub_ptr, L.sub_qr, L.packed,
+                     A.a0, A.a1, A.a0_scalar, A.a1_scalar, A.X, A.grad, L.partial, A.plan->partials, fn,
+                     A.inv_p, A.grad_scale);
   MDE_LAUNCH_CHECK();
+  if (Q > 1 && A.grad) {
+    const int64_t nlocD = (A.plan->row_hi - A.plan->row_lo) * (int64_t)D;
+    hipLaunchKernelGGL(k_panel_combine, dim3(mde_grid(nlocD, MDE_BLOCK, 2048)), dim3(MDE_BLOCK), 0, A.st,
+                       nlocD, Q, L.partial, A.grad_scale, A.grad + (size_t)A.plan->row_lo * D);
+    MDE_LAUNCH_CHECK();
+  }
   return MDE_OK;
 }
 

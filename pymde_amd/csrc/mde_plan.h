@@ -5,7 +5,9 @@
 // Column-panel layout for the LDS-tiled small-d kernel (built lazily, per embedding dim).
 // Half-edges are grouped into tiles (row block rb, column panel cp), sorted by row inside a
 // tile; tile t = rb * n_panels + cp covers [tile_ptr[t], tile_ptr[t+1]).
-#define MDE_PANEL_WAVES 16  // waves per workgroup of the panel kernel (1024 threads)
+#ifndef MDE_PANEL_WAVES
+#define MDE_PANEL_WAVES 16  // waves per workgroup of the panel kernel (64 * WAVES threads)
+#endif
 struct mde_panel_layout {
   int d = 0;            // embedding dimension the tile sizes were chosen for
   int rows_per_block = 0, cols_per_panel = 0;
@@ -15,7 +17,10 @@ struct mde_panel_layout {
   int32_t* eid = nullptr;       // [H] original edge id (parameter expansion)
   int32_t* tile_ptr = nullptr;  // [n_row_blocks * n_panels + 1]
   int32_t* sub_ptr = nullptr;   // [n_tiles * MDE_PANEL_WAVES + 1] per-wave row sub-ranges of a tile
+  int32_t* sub_qr = nullptr;    // [n_tiles * MDE_PANEL_WAVES] (m % K) << 8 | (m / K), K = ceil(m / 64)
   int rows_per_wave = 0;
+  int col_groups = 1;           // Q: workgroups per row block, each walking 1/Q of the panels
+  float* partial = nullptr;     // [Q * nloc * d] per-group gradient partials (Q > 1 only)
 };
 
 struct mde_plan {

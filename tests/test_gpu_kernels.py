@@ -446,6 +446,29 @@ for (n, p, d, fname) in [(30000, 400000, 2, 'log1p'), (30000, 400000, 2, 'pushpu
     Xt2 = torch.tensor(X, device='cuda', requires_grad=True)
     mde.average_distortion(Xt2).backward()
     assert np.abs((Xt2.grad - Xt.grad).cpu().numpy()).max() <= 2e-6 * np.abs(wg).max()
+# vertex-range shards (multi-GPU layout; several column groups per row block when panels are on)
+from pymde_amd import distributed
+from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+n, p, d = 120000, 600000, 2
+i = rng.integers(0, n, p); j = (i + 1 + rng.integers(0, n - 1, p)) %% n
+edges = np.stack([i, j], 1); et = torch.tensor(edges, device='cuda')
+w = rng.uniform(0.5, 2.0, p).astype(np.float32); X = rng.standard_normal((n, d)).astype(np.float32)
+f = pymde_amd.penalties.Log1p(torch.tensor(w, device='cuda')); Xt = torch.tensor(X, device='cuda')
+wE, wg = oracle.average_distortion(edges, X, oracle.func('LOG1P', w, None, (1.5,)))
+for world in (1, 2, 8):
+    bounds = distributed.shard_bounds(n, et, world)
+    total = torch.zeros(n * d + 1, device='cuda')
+    for r in range(world):
+        lo, hi = distributed.shard_range(bounds, r)
+        buf = torch.zeros(n * d + 1, device='cuda')
+        b = Binding(EdgePlan(n, et, lo, hi), f)
+        fused_evaluate(b, Xt, buf[:n * d].view(n, d), buf[n * d:])
+        assert b.struct(d).layout == %d
+        assert float(buf[:lo * d].abs().sum()) == 0 and float(buf[hi * d:n * d].abs().sum()) == 0
+        total += buf
+    assert abs(float(total[n * d]) - wE) <= 1e-5 * abs(wE), (world, float(total[n * d]), wE)
+    err = np.abs(total[:n * d].view(n, d).cpu().numpy() - wg).max()
+    assert err <= 1e-4 * np.abs(wg).max(), (world, err)
 print('ok')
 """
 
@@ -457,7 +480,7 @@ def test_panel_kernel_against_oracle(mode, bs):
     import os
     import subprocess
     import sys
-    code = _PANEL_CODE % (str(__import__("conftest").ROOT), int(mode))
+    code = _PANEL_CODE % (str(__import__("conftest").ROOT), int(mode), int(mode))
     env = dict(os.environ, MDE_PANEL=mode, MDE_PANEL_BS=bs)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
