@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--n", type=int, default=N_ITEMS)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single process: time only the kernel of rank 0 of a W-way shard (no collective)")
     args = ap.parse_args()
@@ -107,10 +108,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl")
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+        torch.cuda.set_device(local_rank % ndev)
+        dist.init_process_group(backend=args.backend)
+    device = torch.device("cuda", (local_rank % ndev) if world > 1 else 0)
     torch.cuda.set_device(device)
 
     import pymde_amd

@@ -277,8 +277,8 @@ static int build_panels(mde_plan* plan, int d, hipStream_t st) {
   L.partial = nullptr;
   // column groups: enough workgroups to fill 256 CUs, at least 4 panels per group
   int Q = 1;
-  if (NRB < 192) {
-    Q = (256 + NRB - 1) / NRB;
+  if (NRB <= 128) {
+    Q = 256 / NRB;  // one resident round of workgroups: NRB * Q <= 256 CUs
     if (Q > NP / 4) Q = NP / 4;
     if (Q > 16) Q = 16;
     if (Q < 1) Q = 1;
@@ -350,7 +350,7 @@ extern "C" int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, cons
 #define MDE_PANEL_STG (6144 / MDE_PANEL_BS)  // float4 staging registers per thread (panel <= 6144 float4)
 #define MDE_PANEL_MAXI (128 / MDE_PANEL_WAVES)  // prefetched wave-iterations per tile
 
-template <int D, class Fn, int ABL>
+template <int D, class Fn, bool HAS_GRAD>
 __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
     int nloc, int row_lo, int n, int P_R, int P_C, int NP, int Q, const int32_t* __restrict__ tile_ptr,
     const int32_t* __restrict__ sub_ptr, const int32_t* __restrict__ sub_qr,
@@ -368,6 +368,7 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
   float* XC = GR + PRP * D;        // [P_C * D]  x_u of the current panel
   double* red = reinterpret_cast<double*>(XC + (size_t)P_C * D);  // [NW]
   const int tid = threadIdx.x, lane = tid & 63;
+  const unsigned ulane = (unsigned)lane;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keep it scalar
   // block b = rb * Q + qg: row block rb, column group qg walks panels [cp_lo, cp_hi)
   const int rb = blockIdx.x / Q, qg = blockIdx.x % Q;
@@ -411,12 +412,7 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
       ss = fmaf(diff[c], diff[c], ss);
     }
     float f, gd;
-    if (ABL & 2) {
-      f = p0 * ss;
-      gd = p0;
-    } else {
-      fn.eval(ss, p0, p1, f, gd);
-    }
+    fn.eval(ss, p0, p1, f, gd);
     const float g = active ? mde_fix_g(gd * inv_p) : 0.0f;
     loss += active ? f : 0.0f;
 #pragma unroll
@@ -427,11 +423,11 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
     it.active = active;
   };
   auto commit = [&](Item& it) {
-    if (!grad) return;
+    if (!HAS_GRAD) return;
     const int key = it.key;
     bool tail = it.active;
     const int kprev = __builtin_amdgcn_update_dpp(-1, key, 0x138, 0xf, 0xf, false);  // wave_shr:1
-    if (!(ABL & 1) && __any(kprev == key)) {
+    if (__any(kprev == key)) {
       // rare: a row has more entries in this tile than the wave has iterations.  Round r adds
       // the ORIGINAL contribution of lane i-r when it has the same row (keys / values shifted
       // one lane per round with DPP wave_shr); the last lane of each run writes.
@@ -490,8 +486,10 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
     for (int k = 0; k < MAXI; ++k) {
       const int cnt = (k < K) ? nq + (k < nrem ? 1 : 0) : 0;
       const bool ok = lane < cnt;
-      pkn[k] = ok ? pb[off + lane] : 0u;
-      wn[k] = (ok && !a0_scalar) ? ab[off + lane] : a0s;
+      const uint32_t* pbo = pb + off;  // uniform: scalar base, the vector offset is just the lane
+      const float* abo = ab + off;
+      pkn[k] = ok ? pbo[ulane] : 0u;
+      wn[k] = (ok && !a0_scalar) ? abo[ulane] : a0s;
       off += cnt;
     }
   };
@@ -561,7 +559,7 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
     cp = cpn;
   }
   __syncthreads();
-  if (grad) {
+  if (HAS_GRAD) {
     // Q == 1: the rows are final.  Q > 1: unscaled per-group partials, summed by k_panel_combine
     float* grow = (Q == 1) ? grad + (size_t)(row_lo + r0) * D
                            : partial + ((size_t)qg * nloc + r0) * D;
@@ -612,16 +610,13 @@ static int launch_panel(const PanelArgs& A, const Fn& fn, int* nblocks) {
   const size_t lds = (prp * 2 * D + (size_t)L.cols_per_panel * D) * sizeof(float) +
                      MDE_PANEL_WAVES * sizeof(double) + 64;
   static bool attr_set = false;
-  static int abl = -1;
-  if (abl < 0) {
-    const char* e = getenv("MDE_PANEL_ABLATE");
-    abl = e ? atoi(e) : 0;
-  }
-  auto kern = abl == 1 ? k_fused_panel<D, Fn, 1> : (abl == 2 ? k_fused_panel<D, Fn, 2> : (abl == 3 ? k_fused_panel<D, Fn, 3> : k_fused_panel<D, Fn, 0>));
-  if (!attr_set) {
+  auto kern = A.grad ? k_fused_panel<D, Fn, true> : k_fused_panel<D, Fn, false>;
+  static bool attr_set_fwd = false;
+  bool& attr_done = A.grad ? attr_set : attr_set_fwd;
+  if (!attr_done) {
     MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, MDE_LDS_BYTES));
-    attr_set = true;
+    attr_done = true;
   }
   const int Q = L.col_groups;
   *nblocks = L.n_row_blocks * Q;
