@@ -1,0 +1,169 @@
+"""BASELINE.json configs at (or near) full size: oracle comparison where the oracle finishes in
+seconds, size-independent properties otherwise (translation invariance of E, zero row-sum of the
+gradient, constraint residuals, monotone solver progress, sharding = unsharded)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_grad_close
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _knn_like_graph(rng, n, k):
+    """k out-neighbours per item within a window (kNN-graph-like locality), undirected, unique."""
+    src = np.repeat(np.arange(n), k)
+    off = rng.integers(1, 200, n * k)
+    dst = (src + off) % n
+    lo, hi = np.minimum(src, dst), np.maximum(src, dst)
+    key = np.unique(lo.astype(np.int64) * n + hi)
+    return np.stack([key // n, key % n], 1)
+
+
+def test_config2_mnist_like_preserve_neighbors_problem():
+    """configs[1]: n = 70k, k = 15 kNN + as many repulsive edges, PushAndPull(Log1p, LogRatio), d = 2,
+    Standardized (synthetic stand-in: MNIST is not available offline)."""
+    import pymde_amd
+    pen = pymde_amd.penalties
+    rng = np.random.default_rng(0)
+    n = 70000
+    att = _knn_like_graph(rng, n, 15)
+    i = rng.integers(0, n, len(att))
+    j = (i + 1 + rng.integers(0, n - 1, len(att))) % n
+    rep = np.stack([np.minimum(i, j), np.maximum(i, j)], 1)
+    edges = np.concatenate([att, rep])
+    w = np.concatenate([1.0 + (rng.random(len(att)) < 0.3), -np.ones(len(rep))]).astype(np.float32)
+    f = pen.PushAndPull(torch.tensor(w, device=DEV), pen.Log1p, pen.LogRatio)
+    mde = pymde_amd.MDE(n, 2, torch.tensor(edges, device=DEV), f, constraint=pymde_amd.Standardized())
+    torch.manual_seed(0)
+    X0 = pymde_amd.Standardized().initialization(n, 2, device=DEV)
+    Xt = X0.clone().requires_grad_(True)
+    E = mde.average_distortion(Xt)
+    E.backward()
+    wE, wgrad = oracle.average_distortion(edges, X0.cpu().numpy(),
+                                          oracle.func("LOG1P", w, None, (1.5,), "LOGRATIO", (2.0,)))
+    assert float(E) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(Xt.grad.cpu().numpy(), wgrad)
+    mde.embed(X=X0, max_iter=40)
+    Es = np.array(mde.solve_stats.average_distortions)
+    assert (np.diff(Es) <= 1e-6 * np.abs(Es[:-1])).all() and Es[-1] < Es[0]
+    X = mde.X.double().cpu().numpy()
+    np.testing.assert_allclose(X.T @ X / n, np.eye(2), atol=5e-5)
+    np.testing.assert_allclose(X.mean(0), 0, atol=1e-5)
+
+
+def test_config3_sparse_graph_distances_huber():
+    """configs[2]: n ~ 40k, sampled graph distances, Huber loss, d = 2 (synthetic stand-in for the
+    Google Scholar graph: pairs with ring-lattice hop distances)."""
+    import pymde_amd
+    rng = np.random.default_rng(1)
+    n, p = 40000, 3_000_000
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    key = np.unique(np.minimum(i, j).astype(np.int64) * n + np.maximum(i, j))
+    edges = np.stack([key // n, key % n], 1)
+    hop = np.abs(edges[:, 0] - edges[:, 1])
+    dev = (np.minimum(hop, n - hop) / 500.0 + 1.0).astype(np.float32)
+    f = pymde_amd.losses.Huber(torch.tensor(dev, device=DEV), 1.0)
+    mde = pymde_amd.MDE(n, 2, torch.tensor(edges, device=DEV), f)
+    torch.manual_seed(0)
+    X0 = pymde_amd.Centered().initialization(n, 2, device=DEV) * 10
+    Xt = X0.clone().requires_grad_(True)
+    E = mde.average_distortion(Xt)
+    E.backward()
+    wE, wgrad = oracle.average_distortion(edges, X0.cpu().numpy(), oracle.func("L_HUBER", dev, None, (1.0,)))
+    assert float(E) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(Xt.grad.cpu().numpy(), wgrad)
+    mde.embed(X=X0, max_iter=30)
+    Es = np.array(mde.solve_stats.average_distortions)
+    assert Es[-1] < 0.5 * Es[0] and abs(float(mde.X.mean())) < 1e-4
+
+
+def test_config4_full_size_against_oracle_and_invariants():
+    """configs[3], the headline: n = 1M, |E| = 50M, d = 2, Log1p -- the LDS column-panel kernel
+    against the OpenMP oracle on the full problem, plus invariants."""
+    import bench
+    import pymde_amd
+    from pymde_amd import distributed
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    dev = torch.device(DEV, 0)
+    edges, w, X = bench.make_workload(dev)
+    n, d, p = X.shape[0], 2, edges.shape[0]
+    f = pymde_amd.penalties.Log1p(w)
+    binding = Binding(EdgePlan(n, edges), f)
+    buf = torch.zeros(n * d + 1, device=dev)
+    fused_evaluate(binding, X, buf[:n * d].view(n, d), buf[n * d:])
+    assert binding.struct(d).layout == 1  # the panel kernel is what runs at this size
+    wE, wgrad = oracle.average_distortion(edges.cpu().numpy(), X.cpu().numpy(),
+                                          oracle.func("LOG1P", w.cpu().numpy(), None, (1.5,)))
+    assert float(buf[n * d]) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(buf[:n * d].view(n, d).cpu().numpy(), wgrad)
+    # translation invariance and zero net force
+    buf2 = torch.zeros_like(buf)
+    fused_evaluate(binding, X + torch.tensor([3.0, -2.0], device=dev), buf2[:n * d].view(n, d), buf2[n * d:])
+    assert float(buf2[n * d]) == pytest.approx(float(buf[n * d]), rel=1e-5)
+    assert buf[:n * d].view(n, d).double().sum(0).abs().max().item() < 1e-9 * n
+    # bitwise reproducible; 4-way vertex-range sharding reproduces the unsharded gradient bitwise
+    buf3 = torch.zeros_like(buf)
+    fused_evaluate(binding, X, buf3[:n * d].view(n, d), buf3[n * d:])
+    assert torch.equal(buf3, buf)
+    bounds = distributed.shard_bounds(n, edges, 4)
+    total = torch.zeros_like(buf)
+    for r in range(4):
+        lo, hi = distributed.shard_range(bounds, r)
+        part = torch.zeros_like(buf)
+        fused_evaluate(Binding(EdgePlan(n, edges, lo, hi), f), X, part[:n * d].view(n, d), part[n * d:])
+        total += part
+    np.testing.assert_allclose(total[:n * d].cpu().numpy(), buf[:n * d].cpu().numpy(), rtol=1e-5, atol=1e-12)
+    assert float(total[n * d]) == pytest.approx(float(buf[n * d]), rel=1e-6)
+
+
+def test_config5_high_dim_standardized():
+    """configs[4]: n = 500k, |E| = 20M, d = 128, Standardized (f32 MFMA Gram + projection).
+    The gradient is checked against the oracle on an edge sub-sample; the full-size evaluation
+    through invariants."""
+    import pymde_amd
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    dev = torch.device(DEV, 0)
+    n, d, deg = 500_000, 128, 40
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0)
+    src = torch.arange(n, device=dev).repeat_interleave(deg)
+    dst = torch.randint(0, n - 1, (n * deg,), device=dev, generator=gen)
+    dst += (dst >= src).long()
+    edges = torch.stack([torch.minimum(src, dst), torch.maximum(src, dst)], 1).contiguous()
+    w = 1.0 + (torch.rand(n * deg, device=dev, generator=gen) < 0.3).float()
+    std = pymde_amd.Standardized()
+    torch.manual_seed(0)
+    X = std.initialization(n, d, device=dev)
+    G = (X.double().T @ X.double() / n).cpu().numpy()
+    np.testing.assert_allclose(G, np.eye(d), atol=5e-5)            # MFMA Gram + Newton-Schulz retraction
+    assert X.mean(0).abs().max().item() < 1e-5
+    # full-size fused evaluation (20M edges, 2 KB of gathers per edge)
+    f = pymde_amd.penalties.Quadratic(w)
+    binding = Binding(EdgePlan(n, edges), f)
+    buf = torch.zeros(n * d + 1, device=dev)
+    grad = buf[:n * d].view(n, d)
+    fused_evaluate(binding, X, grad, buf[n * d:])
+    E = float(buf[n * d])
+    # Quadratic: E = (1/p) sum w ||x_i - x_j||^2 = (2/p) tr(X^T L X); grad = (2/p) L X, so <grad, X> = 2 E
+    assert float((grad.double() * X.double()).sum()) == pytest.approx(2 * E, rel=1e-4)
+    assert grad.double().sum(0).abs().max().item() < 1e-7 * n
+    # tangent projection is orthogonal to the constraint normal space: X^T Z_t symmetric-part = 0
+    Zt = std.project_onto_tangent_space(X, grad.clone(), inplace=True)
+    A = (Zt.double().T @ X.double() / n).cpu().numpy()
+    assert np.abs(A).max() < 1e-6 * max(1.0, float(grad.abs().max()) * n ** 0.5)
+    # oracle on a sub-sample of 200k edges over the first 50k vertices
+    m = 50_000
+    sel = ((edges[:, 0] < m) & (edges[:, 1] < m)).nonzero().squeeze(1)[:200_000]
+    es, ws = edges[sel].contiguous(), w[sel].contiguous()
+    Xs = X[:m].contiguous()
+    bs = Binding(EdgePlan(m, es), pymde_amd.penalties.Log1p(ws))
+    out = torch.zeros(m * d + 1, device=dev)
+    fused_evaluate(bs, Xs, out[:m * d].view(m, d), out[m * d:])
+    wE, wgrad = oracle.average_distortion(es.cpu().numpy(), Xs.cpu().numpy(),
+                                          oracle.func("LOG1P", ws.cpu().numpy(), None, (1.5,)))
+    assert float(out[m * d]) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(out[:m * d].view(m, d).cpu().numpy(), wgrad)
