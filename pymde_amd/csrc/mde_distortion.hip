@@ -126,7 +126,9 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide(
     float* __restrict__ grad, double* __restrict__ loss_partials, Fn fn, float inv_p,
     float grad_scale) {
   __shared__ double smem[8];
-  constexpr int E = 64 / GL;  // half-edges per wave iteration
+  constexpr int E = 64 / GL;                       // half-edges per wave step
+  constexpr int U = (K <= 2) ? 4 : (K <= 4 ? 2 : 1);  // independent steps in flight (row gathers
+                                                      // are long-latency HBM reads at large d)
   const int lane = threadIdx.x & 63;
   const int lig = lane & (GL - 1);
   const int sub = lane / GL;  // which of the E half-edges this lane works on
@@ -146,39 +148,54 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide(
       xv[j] = (c < d) ? X[v * d + c] : 0.0f;
       acc[j] = 0.0f;
     }
-    for (int h0 = beg; h0 < end; h0 += E) {
-      const int h = h0 + sub;
-      const bool live = h < end;
-      const int hh = live ? h : beg;
-      const int64_t u = nbr[hh];
-      float p0, p1 = a1s;
-      if constexpr (INDIRECT) {
-        const int k = eid[hh];
-        p0 = a0[k];
-        p1 = a1[k];
-      } else {
-        p0 = a0_scalar ? a0s : a0[hh];
-        if (a1 && !a1_scalar) p1 = a1[hh];
-      }
-      float diff[K], ss = 0.0f;
+    for (int h0 = beg; h0 < end; h0 += E * U) {
+      bool live[U];
+      int64_t u[U];
+      float p0[U], p1[U];
 #pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const int c = lig + j * GL;
-        const float xu = (c < d) ? X[u * d + c] : 0.0f;
-        diff[j] = xv[j] - xu;
-        ss = fmaf(diff[j], diff[j], ss);
+      for (int q = 0; q < U; ++q) {
+        const int h = h0 + q * E + sub;
+        live[q] = h < end;
+        const int hh = live[q] ? h : beg;
+        u[q] = nbr[hh];
+        p1[q] = a1s;
+        if constexpr (INDIRECT) {
+          const int k = eid[hh];
+          p0[q] = a0[k];
+          p1[q] = a1[k];
+        } else {
+          p0[q] = a0_scalar ? a0s : a0[hh];
+          if (a1 && !a1_scalar) p1[q] = a1[hh];
+        }
       }
-      ss = mde_group_sum<GL>(ss);
-      float f, gd;
-      fn.eval(ss, p0, p1, f, gd);
-      float g = mde_fix_g(gd * inv_p);
-      if (!live) {
-        g = 0.0f;
-        f = 0.0f;
-      }
-      if (lig == 0) loss += f;
+      float xu[U][K];
 #pragma unroll
-      for (int j = 0; j < K; ++j) acc[j] = fmaf(g, diff[j], acc[j]);
+      for (int q = 0; q < U; ++q)
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          const int c = lig + j * GL;
+          xu[q][j] = (c < d) ? X[u[q] * d + c] : 0.0f;
+        }
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        float diff[K], ss = 0.0f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+          diff[j] = xv[j] - xu[q][j];
+          ss = fmaf(diff[j], diff[j], ss);
+        }
+        ss = mde_group_sum<GL>(ss);
+        float f, gd;
+        fn.eval(ss, p0[q], p1[q], f, gd);
+        float g = mde_fix_g(gd * inv_p);
+        if (!live[q]) {
+          g = 0.0f;
+          f = 0.0f;
+        }
+        if (lig == 0) loss += f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) acc[j] = fmaf(g, diff[j], acc[j]);
+      }
     }
     if (grad) {
       // combine the E sub-groups (lanes with equal lig): xor over the sub index bits
