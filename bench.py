@@ -133,13 +133,14 @@ def main():
     binding = Binding(plan, f)
     buf = torch.zeros(n * d + 1, dtype=torch.float32, device=device)
     grad, loss = buf[:n * d].view(n, d), buf[n * d:]
+    exchange = distributed.GradExchange(n, d, bounds, rank, world) if world > 1 else None
 
     def step():
-        if world > 1:
-            buf.zero_()
+        if world > 1 and exchange.mode != "all_gather":
+            buf.zero_()          # rows of other ranks must be zero for the all-reduce
         fused_evaluate(binding, X, grad, loss)
         if world > 1:
-            distributed.all_reduce_grad_loss(buf)
+            exchange(buf)
 
     def barrier():
         if world > 1:
@@ -183,7 +184,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: n=%d, |E|=%d uniform-random edges, d=2, "
                                    "penalties.Log1p(1.5), weights in {1,2}" % (n, p),
-                       "parallelism": "vertex-range shards x%d + all_reduce([grad|loss])" % world
+                       "parallelism": ("vertex-range shards x%d + %s of [grad|loss]" % (world, exchange.mode))
                        if world > 1 else "single GPU",
                        "loss": gpu_loss},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BPS / 1e9,

@@ -39,6 +39,22 @@ def _worker(rank, world, port, ret):
     buf[-1] = share
     distributed.all_reduce_grad_loss(buf)
     np.testing.assert_allclose(buf[:-1].numpy().reshape(n, d), grad_full, rtol=0, atol=0)
+    # the exchange object used by ShardedMDE / bench.py: with equal row counts it may switch to an
+    # all-gather after verifying it against the all-reduce; either way the result is the same
+    ub = [0, n // 2, n]
+    ulo, uhi = distributed.shard_range(ub, rank)
+    uown_i = (edges[:, 0] >= ulo) & (edges[:, 0] < uhi)
+    uown_j = (edges[:, 1] >= ulo) & (edges[:, 1] < uhi)
+    ex = distributed.GradExchange(n, d, ub, rank, world)
+    for _ in range(3):
+        b2 = torch.zeros(n * d + 1, dtype=torch.float32)
+        b2[ulo * d:uhi * d] = torch.from_numpy(grad_full[ulo:uhi].reshape(-1))
+        b2[-1] = (0.5 * f_edge * uown_i + 0.5 * f_edge * uown_j).sum() / p
+        ex(b2)
+        np.testing.assert_allclose(b2[:-1].numpy().reshape(n, d), grad_full, rtol=0, atol=0)
+        assert abs(float(b2[-1]) - E_full) < 1e-5 * abs(E_full)
+    assert ex.mode in ("all_gather", "all_reduce")
+    ret["mode%d" % rank] = ex.mode
     assert abs(float(buf[-1]) - E_full) < 1e-5 * abs(E_full)
     # both ranks hold the identical reduced buffer
     gathered = [torch.zeros_like(buf) for _ in range(world)]
@@ -63,4 +79,4 @@ def test_two_rank_gloo_allreduce_matches_unsharded():
     for p in procs:
         p.join(180)
         assert p.exitcode == 0
-    assert len(ret) == world
+    assert ret[0] == 1 and ret[1] == 1 and ret["mode0"] == ret["mode1"]

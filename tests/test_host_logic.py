@@ -34,9 +34,10 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_mde_func_struct_layout_matches_header():
-    # struct mde_func: 2 x int32, 2 x pointer, 2 x int32, 6 x float (include/mde_hip.h)
-    assert ctypes.sizeof(_lib.MdeFunc) == 8 + 16 + 8 + 24
+    # struct mde_func: 2 x int32, 2 x pointer, 2 x int32, 6 x float, int32 (+4 pad) (include/mde_hip.h)
+    assert ctypes.sizeof(_lib.MdeFunc) == 8 + 16 + 8 + 24 + 4 + 4
     assert _lib.MdeFunc.a0.offset == 8 and _lib.MdeFunc.s0.offset == 32
+    assert _lib.MdeFunc.layout.offset == 56
 
 
 # ---------------------------------------------------------------- no GPU -> loud failure
