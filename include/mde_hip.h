@@ -231,6 +231,14 @@ int mde_gram(int64_t n, int32_t da, int32_t db, const float* A, const float* B, 
 /* Z = A M, M [d, d2] device double row-major (small). */
 int mde_right_multiply(int64_t n, int32_t d, int32_t d2, const float* A, const double* M,
                        float* out, void* stream);
+/* out = base + alpha * A M  (base may be NULL or alias out; out may alias A only when d == d2). */
+int mde_right_multiply_add(int64_t n, int32_t d, int32_t d2, const float* A, const double* M,
+                           float alpha, const float* base, float* out, void* stream);
+/* Z[r, :] *= scale[r]  (row scaling, e.g. the Jacobi preconditioner of the spectral initialiser). */
+int mde_row_scale(int64_t n, int32_t d, const float* scale, float* Z, void* stream);
+/* out[v] = sum of the per-edge weights (plan / CSR order) over the half-edges of row v: the diagonal
+ * of the graph Laplacian [ref: quadratic.py:47-68].  Rows outside the plan's range are untouched. */
+int mde_weighted_degree(const mde_plan* plan, const float* w_plan_order, float* out, void* stream);
 /* number of doubles of scratch the constraint / gram / vector calls need for width d */
 int64_t mde_work_doubles(int32_t d);
 

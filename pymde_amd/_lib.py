@@ -61,6 +61,9 @@ SYMBOLS = {
     "mde_std_retract": (c_i32, [c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "mde_gram": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mde_right_multiply": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "mde_right_multiply_add": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp]),
+    "mde_row_scale": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "mde_weighted_degree": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
     "mde_work_doubles": (c_i64, [c_i32]),
     "mde_axpy": (c_i32, [c_i64, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "mde_vec_stats": (c_i32, [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

@@ -352,3 +352,30 @@ extern "C" int mde_plan_export(const mde_plan* plan, int32_t* rowptr_out, int32_
     MDE_HIP(hipMemcpyAsync(eid_out, plan->eid, plan->H * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   return MDE_OK;
 }
+
+// one 16-lane group per row: out[v] = sum of w over the row's half-edges (fixed order)
+__global__ __launch_bounds__(MDE_BLOCK) void k_weighted_degree(int nrows, int row_lo,
+                                                               const int32_t* __restrict__ rowptr,
+                                                               const float* __restrict__ w,
+                                                               float* __restrict__ out) {
+  constexpr int G = 16;
+  const int lig = threadIdx.x & (G - 1);
+  const int group = (blockIdx.x * MDE_BLOCK + threadIdx.x) / G;
+  const int ngroups = (gridDim.x * MDE_BLOCK) / G;
+  for (int r = group; r < nrows; r += ngroups) {
+    float s = 0.0f;
+    for (int h = rowptr[r] + lig; h < rowptr[r + 1]; h += G) s += w[h];
+    s = mde_group_sum<G>(s);
+    if (lig == 0) out[row_lo + r] = s;
+  }
+}
+extern "C" int mde_weighted_degree(const mde_plan* plan, const float* w_plan_order, float* out,
+                                   void* stream) {
+  if (!plan || !w_plan_order || !out) return MDE_E_INVALID;
+  const int64_t nloc = plan->row_hi - plan->row_lo;
+  if (nloc <= 0) return MDE_OK;
+  hipLaunchKernelGGL(k_weighted_degree, dim3(mde_grid(nloc * 16, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0,
+                     mde_stream(stream), (int)nloc, (int)plan->row_lo, plan->rowptr, w_plan_order, out);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}

@@ -467,6 +467,27 @@ extern "C" int mde_right_multiply(int64_t n, int32_t d, int32_t d2, const float*
   return rmul_impl(n, d, d2, A, M, 1.0f, nullptr, out, mde_stream(stream));
 }
 
+extern "C" int mde_right_multiply_add(int64_t n, int32_t d, int32_t d2, const float* A, const double* M,
+                                      float alpha, const float* base, float* out, void* stream) {
+  if (n <= 0 || d <= 0 || d2 <= 0 || d > 8192 || !A || !M || !out) return MDE_E_INVALID;
+  if (A == out && d != d2) return MDE_E_INVALID;
+  return rmul_impl(n, d, d2, A, M, alpha, base, out, mde_stream(stream));
+}
+
+__global__ __launch_bounds__(MDE_BLOCK) void k_row_scale(int64_t N, int d, const float* __restrict__ scale,
+                                                         float* __restrict__ Z) {
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N;
+       i += (int64_t)gridDim.x * MDE_BLOCK)
+    Z[i] *= scale[i / d];
+}
+extern "C" int mde_row_scale(int64_t n, int32_t d, const float* scale, float* Z, void* stream) {
+  if (n <= 0 || d <= 0 || !scale || !Z) return MDE_E_INVALID;
+  hipLaunchKernelGGL(k_row_scale, dim3(mde_grid(n * d, MDE_BLOCK)), dim3(MDE_BLOCK), 0, mde_stream(stream),
+                     n * d, d, scale, Z);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
 // ---------------------------------------------------------------- Standardized: tangent space
 // Z -= (1/n) X (Z^T X)                                    [ref: constraints.py:186-192]
 extern "C" int mde_std_tangent(int64_t n, int32_t d, const float* X, float* Z, double* work,

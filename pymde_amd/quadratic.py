@@ -4,15 +4,19 @@
     minimise sum_k w_k ||x_i - x_j||^2   s.t. (1/n) X^T X = I, X^T 1 = 0
 i.e. the bottom non-trivial eigenvectors of the graph Laplacian L = D - A
 [ref: pymde/quadratic.py:47-179].  The reference calls ARPACK (``eigsh(which='SM')``) on the
-CPU or ``torch.lobpcg`` on CUDA; here a block LOBPCG runs on the device with
-  * L V applied by the SAME fused edge kernel as the solve: for the Quadratic penalty
-    dE/dV = (2/p) L V, so L V = (p/2) grad (``mde_average_distortion`` with grad_scale = p/2),
-  * every Rayleigh-Ritz Gram matrix ([X R P]^T [X R P] and [X R P]^T L [X R P]) formed by
-    ``mde_gram`` (f32 MFMA tiles when the block width is a multiple of 32),
-  * the (<= 3(d+1))-sized dense eigenproblem solved on the host in float64.
-The constant vector is deflated by centring the block, so only non-trivial eigenvectors are
+CPU or ``torch.lobpcg`` on CUDA; here a block LOBPCG runs on the device, built only from the
+library's kernels:
+  * L V is applied by the SAME fused edge kernel as the solve: for the Quadratic penalty
+    dE/dV = (2/p) L V, so L V = (p/2) grad (``mde_average_distortion`` with grad_scale = p/2);
+  * every Rayleigh-Ritz Gram block ([X W P]^T [X W P] and [X W P]^T L [X W P]) is formed by
+    ``mde_gram`` (f32 MFMA tiles when the block widths are multiples of 32);
+  * block updates are ``mde_right_multiply_add`` (n x k times k x k), the Jacobi preconditioner
+    is ``mde_row_scale`` with the Laplacian diagonal from ``mde_weighted_degree``, centring is
+    ``mde_center``;
+  * only the (<= 3 d)-sized dense eigenproblems are solved on the host, in float64.
+The constant vector is deflated by centring every block, so only non-trivial eigenvectors are
 iterated.  The result is centred and projected onto the standardization constraint, as in
-quadratic.py:173-179.
+quadratic.py:173-179.  torch is used for the random start block and buffer allocation only.
 """
 import numpy as np
 import scipy.linalg
@@ -24,10 +28,53 @@ from pymde_amd import util
 from pymde_amd.functions import penalties
 
 
+class _Ops(object):
+    """Thin wrappers over the C ABI for [n, k] float32 blocks on one device."""
+
+    def __init__(self, n, device, kmax):
+        self.lib = _lib.load()
+        self.n = int(n)
+        self.device = device
+        self.work = util.work_buffer(device, max(kmax, 4))
+
+    def _stream(self):
+        return _lib.stream_ptr(self.device)
+
+    def gram(self, A, B):
+        out = torch.empty((A.shape[1], B.shape[1]), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mde_gram(self.n, A.shape[1], B.shape[1], _lib.ptr(A), _lib.ptr(B),
+                                     _lib.ptr(out), _lib.ptr(self.work), self._stream()))
+        return out.cpu().numpy()
+
+    def rmul(self, A, M, alpha=1.0, base=None, out=None):
+        """out = base + alpha * A @ M  (M: small host float64 matrix)."""
+        M = np.ascontiguousarray(M, dtype=np.float64)
+        # small host matrix -> device; keep the upload ordered before its host buffer can go away
+        Md = torch.from_numpy(M).to(self.device)
+        torch.cuda.current_stream(self.device).synchronize()
+        if out is None:
+            out = torch.empty((self.n, M.shape[1]), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mde_right_multiply_add(self.n, A.shape[1], M.shape[1], _lib.ptr(A),
+                                                   _lib.ptr(Md), float(alpha), _lib.ptr(base),
+                                                   _lib.ptr(out), self._stream()))
+        return out
+
+    def center(self, Z):
+        _lib.check(self.lib.mde_center(self.n, Z.shape[1], _lib.ptr(Z), _lib.ptr(self.work),
+                                       self._stream()))
+        return Z
+
+    def row_scale(self, Z, scale):
+        _lib.check(self.lib.mde_row_scale(self.n, Z.shape[1], _lib.ptr(scale), _lib.ptr(Z),
+                                          self._stream()))
+        return Z
+
+
 class _Laplacian(object):
-    """y = L V through the fused edge kernel."""
+    """y = L V through the fused edge kernel; diag(L) through mde_weighted_degree."""
 
     def __init__(self, n, edges, weights, device):
+        lib = _lib.load()
         self.n = int(n)
         self.device = device
         edges = torch.as_tensor(edges).to(device=device, dtype=torch.int64).contiguous()
@@ -36,88 +83,82 @@ class _Laplacian(object):
         self.binding = _ad.Binding(self.plan, penalties.Quadratic(weights))
         self.p = int(edges.shape[0])
         self.loss = torch.empty(1, dtype=torch.float32, device=device)
+        w_csr = self.plan.expand(weights, 0)
         deg = torch.zeros(self.n, dtype=torch.float32, device=device)
-        deg.index_add_(0, edges[:, 0], weights)
-        deg.index_add_(0, edges[:, 1], weights)
-        self.inv_degree = 1.0 / torch.clamp(deg, min=1e-12)
+        _lib.check(lib.mde_weighted_degree(self.plan.handle, _lib.ptr(w_csr), _lib.ptr(deg),
+                                           _lib.stream_ptr(device)))
+        # Jacobi preconditioner 1 / L_vv (isolated vertices: 1)
+        self.inv_degree = torch.where(deg > 0, 1.0 / deg, torch.ones_like(deg)).contiguous()
 
     def apply(self, V):
         out = torch.empty_like(V)
-        _ad.fused_evaluate(self.binding, V.contiguous(), out, self.loss, grad_scale=0.5 * self.p)
+        _ad.fused_evaluate(self.binding, V, out, self.loss, grad_scale=0.5 * self.p)
         return out
 
 
-def _gram(A, B, work):
-    lib = _lib.load()
-    n, da = A.shape
-    db = B.shape[1]
-    out = torch.empty((da, db), dtype=torch.float64, device=A.device)
-    with torch.cuda.device(A.device):
-        _lib.check(lib.mde_gram(n, da, db, _lib.ptr(A), _lib.ptr(B), _lib.ptr(out), _lib.ptr(work),
-                                _lib.stream_ptr(A.device)))
-    return out
-
-
-def _rmul(A, M):
-    """A @ M with M a small host float64 matrix."""
-    lib = _lib.load()
-    n, d = A.shape
-    Md = torch.as_tensor(np.ascontiguousarray(M), dtype=torch.float64, device=A.device)
-    out = torch.empty((n, Md.shape[1]), dtype=torch.float32, device=A.device)
-    with torch.cuda.device(A.device):
-        _lib.check(lib.mde_right_multiply(n, d, Md.shape[1], _lib.ptr(A), _lib.ptr(Md), _lib.ptr(out),
-                                          _lib.stream_ptr(A.device)))
-    return out
-
-
-def _orthonormalise(V, work):
-    """Return V C^{-1/2}-like orthonormal basis via Cholesky of the Gram matrix (host, tiny)."""
-    G = _gram(V, V, work).cpu().numpy()
+def _orthonormalizer(G, rel_tol=1e-9):
+    """Host: M with (S M)^T (S M) = I for the Gram matrix G = S^T S (drops null directions)."""
     G = 0.5 * (G + G.T)
     w, Q = np.linalg.eigh(G)
-    keep = w > max(w.max(), 1e-300) * 1e-10
-    M = Q[:, keep] / np.sqrt(w[keep])
-    return _rmul(V, M)
+    keep = w > max(float(w.max()), 1e-300) * rel_tol
+    return Q[:, keep] / np.sqrt(w[keep])
 
 
-def _lobpcg(lap, k, max_iter, tol, device, seed_block=None):
+def _sym(A):
+    return 0.5 * (A + A.T)
+
+
+def _lobpcg(lap, k, max_iter, tol, device):
+    """Block LOBPCG for the k smallest non-trivial eigenpairs of the Laplacian.
+
+    Every iteration builds an explicitly orthonormal basis Q of span[X, W, P] and applies L to
+    it afresh, so the Rayleigh-Ritz matrices always belong to the vectors actually held (no
+    drift from recombining stored L-images in fp32)."""
     n = lap.n
-    work = util.work_buffer(device, max(3 * k, 4))
-    X = seed_block if seed_block is not None else torch.randn((n, k), device=device,
-                                                              dtype=torch.float32)
-    X = X - X.mean(dim=0, keepdim=True)
-    X = _orthonormalise(X, work)
+    ops = _Ops(n, device, 3 * k)
+
+    def orthonormal(blocks):
+        """Orthonormal basis of the span of the given [n, *] blocks (explicit vectors)."""
+        sizes = [b.shape[1] for b in blocks]
+        offs = np.cumsum([0] + sizes)
+        m = int(offs[-1])
+        G = np.zeros((m, m))
+        for a in range(len(blocks)):
+            for b in range(a, len(blocks)):
+                G[offs[a]:offs[a + 1], offs[b]:offs[b + 1]] = ops.gram(blocks[a], blocks[b])
+        G = np.triu(G) + np.triu(G, 1).T
+        M = _orthonormalizer(G)
+        out = None
+        for a, blk in enumerate(blocks):
+            out = ops.rmul(blk, M[offs[a]:offs[a + 1], :], base=out, out=out)
+        # one re-orthonormalisation pass removes the fp32 error of the first
+        return ops.rmul(out, _orthonormalizer(ops.gram(out, out)))
+
+    X = orthonormal([ops.center(torch.randn((n, k), device=device, dtype=torch.float32))])
+    if X.shape[1] < k:
+        raise util.SolverError("spectral: the random start block is rank deficient")
     P = None
     theta = None
-    for it in range(max_iter):
+    for _ in range(max_iter):
         LX = lap.apply(X)
-        if theta is None:
-            A = _gram(X, LX, work).cpu().numpy()
-            theta, C = np.linalg.eigh(0.5 * (A + A.T))
-            X = _rmul(X, C)
-            LX = _rmul(LX, C)
-        R = LX - X * torch.as_tensor(theta, dtype=torch.float32, device=device)[None, :]
-        rnorm = R.norm(dim=0).cpu().numpy()
-        if np.all(rnorm <= tol * np.maximum(np.abs(theta), 1e-12) + 1e-30):
+        A = _sym(ops.gram(X, LX))
+        theta, C = np.linalg.eigh(A)
+        X, LX = ops.rmul(X, C), ops.rmul(LX, C)       # Ritz vectors of the current block
+        R = ops.rmul(X, np.diag(theta), alpha=-1.0, base=LX)   # residual L X - X diag(theta)
+        rnorm = np.sqrt(np.maximum(np.diag(ops.gram(R, R)), 0.0))
+        if np.all(rnorm <= tol * np.maximum(np.abs(theta), 1e-12)):
             break
-        W = R * lap.inv_degree[:, None]           # Jacobi preconditioner
-        W = W - W.mean(dim=0, keepdim=True)       # stay orthogonal to the constant vector
-        blocks = [X, W] if P is None else [X, W, P]
-        S = _orthonormalise(torch.cat(blocks, dim=1), work)
-        LS = lap.apply(S)
-        A = _gram(S, LS, work).cpu().numpy()
-        evals, evecs = scipy.linalg.eigh(0.5 * (A + A.T))
-        C = evecs[:, :k]
-        X_new = _rmul(S, C)
-        # implicit P: the part of the new iterate outside span(X)
-        P = X_new - X @ (X.T @ X_new)
-        X = X_new
-        theta = evals[:k]
-        # re-orthonormalise X against rounding drift
-        X = X - X.mean(dim=0, keepdim=True)
-        X = _orthonormalise(X, work)
+        W = ops.center(ops.row_scale(R, lap.inv_degree))  # Jacobi-preconditioned, orthogonal to 1
+        Q = orthonormal([X, W] if P is None else [X, W, P])
+        LQ = lap.apply(Q)
+        evals, evecs = scipy.linalg.eigh(_sym(ops.gram(Q, LQ)))
+        X_new = ops.rmul(Q, evecs[:, :k])
+        # conjugate direction: the part of the new iterate outside the old one
+        P = ops.rmul(X, ops.gram(X, X_new), alpha=-1.0, base=X_new)
+        X = orthonormal([X_new])
         if X.shape[1] < k:
             raise util.SolverError("spectral: the iteration block lost rank")
+        theta = evals[:k]
     return theta, X
 
 
@@ -134,10 +175,10 @@ def spectral(n_items, embedding_dim, edges, weights, cg=False, max_iter=40, devi
             util.get_default_device()
     device = util.require_cuda_device(device)
     n, m = int(n_items), int(embedding_dim)
-    lap = _Laplacian(n, edges, weights, device)
     iters = max(int(max_iter), 1) if cg else max(5 * n, 200)
     tol = 1e-3 if cg else 1e-5
     with torch.no_grad(), torch.cuda.device(device):
+        lap = _Laplacian(n, edges, weights, device)
         _, V = _lobpcg(lap, m, iters, tol, device)
-        V = V - V.mean(dim=0, keepdim=True)
+        _Ops(n, device, m).center(V)
         return util.proj_standardized(V.contiguous(), demean=False)
