@@ -175,6 +175,19 @@ int mde_plan_layout(mde_plan* plan, int32_t d, void* stream);
 int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in_edge,
                            float* out_half, void* stream);
 
+/* ------------------------------------------------------------------ edge-list preprocessing
+ *  [ref: pymde/preprocess/preprocess.py:11-129]
+ * De-duplicate an edge list: rows are put in (min, max) order and the unique rows are written to
+ * edges_out [>= p, 2] sorted by (i, j) -- np.unique(axis=0)'s order; *count_host = their number. SYNC. */
+int mde_edges_deduplicate(int64_t n, int64_t p, const int64_t* edges, int64_t* edges_out,
+                          int64_t* count_host, void* stream);
+/* Sample at most num_edges distinct edges i < j uniformly at random from the edges NOT in
+ * `exclude` [n_exclude, 2] (NULL / 0: no exclusion); edges_out must hold num_edges rows, sorted by
+ * (i, j); *count_host = number written (== num_edges unless the complement is nearly exhausted).
+ * Same `seed` -> same edges.  SYNC. */
+int mde_sample_edges(int64_t n, int64_t num_edges, uint64_t seed, const int64_t* exclude,
+                     int64_t n_exclude, int64_t* edges_out, int64_t* count_host, void* stream);
+
 /* ------------------------------------------------------------------ the hot kernel
  * Fused forward + backward of the average distortion
  *   E(X) = (1/p) sum_k f_k(||x_ik - x_jk||),  dE/dX          [ref: average_distortion.py:62-106]

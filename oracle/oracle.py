@@ -220,6 +220,31 @@ def shard_bounds(n, edges, world):
     return bounds
 
 
+# ---------------------------------------------------------------- edge preprocessing (row f1)
+def deduplicate_edges(edges):
+    """Rows put in (min, max) order, unique rows in lexicographic order
+    [ref: preprocess/preprocess.py:116-129]."""
+    e = np.array(edges, dtype=np.int64, copy=True)
+    flip = e[:, 0] > e[:, 1]
+    e[flip] = e[flip][:, ::-1]
+    return np.unique(e, axis=0)
+
+
+def check_sampled_edges(n, sampled, exclude=None):
+    """Invariants every output of sample_edges satisfies [ref: preprocess/preprocess.py:11-80]:
+    i < j, in range, no duplicates, disjoint from `exclude`.  Returns the canonical keys."""
+    s = np.asarray(sampled, dtype=np.int64)
+    assert s.ndim == 2 and s.shape[1] == 2
+    assert (s[:, 0] < s[:, 1]).all() and s.min(initial=0) >= 0 and s.max(initial=0) < n
+    keys = s[:, 0] * n + s[:, 1]
+    assert len(np.unique(keys)) == len(keys)
+    if exclude is not None and len(exclude):
+        ex = np.asarray(exclude, dtype=np.int64)
+        ek = np.minimum(ex[:, 0], ex[:, 1]) * n + np.maximum(ex[:, 0], ex[:, 1])
+        assert not np.isin(keys, ek).any()
+    return keys
+
+
 # ---------------------------------------------------------------- spectral initialiser
 def spectral(n, m, edges, weights):
     """Bottom m non-trivial Laplacian eigenvectors via ARPACK, centred and standardized

@@ -12,3 +12,4 @@ from pymde_amd.constraints import Centered, Anchored, Standardized  # noqa: F401
 from pymde_amd.functions import losses, penalties  # noqa: F401
 from pymde_amd.util import all_edges, center, seed  # noqa: F401
 from pymde_amd import quadratic  # noqa: F401
+from pymde_amd import preprocess  # noqa: F401

@@ -15,6 +15,7 @@ Fixtures
   constraints.npz   Centered / Standardized / Anchored maps   -> pins constraints.py, util.py:129-171
   trajectories.npz  per-iteration SolveStats of short embed() runs (optim.py / lbfgs.py)
   spectral.npz      quadratic.spectral on small graphs         -> pins quadratic.py
+  preprocess.npz    deduplicate_edges / sample_edges of the reference
   cycle.npz         BASELINE config 1 scaled down: preserve_distances on a cycle graph,
                     losses.Quadratic, all pairs
 """
@@ -316,6 +317,24 @@ def gen_cycle(pymde, torch):
     print("cycle.npz: p =", out["edges"].shape[0], "final", out["final_value"])
 
 
+def gen_preprocess(pymde, torch):
+    """deduplicate_edges outputs (exact) and sample_edges invariants of the reference (f1)."""
+    from pymde.preprocess import preprocess as pp
+    rng = np.random.default_rng(77)
+    n = 500
+    e = rng.integers(0, n, (6000, 2))
+    e = e[e[:, 0] != e[:, 1]]
+    e = np.concatenate([e, e[:700][:, ::-1], e[:300]])     # flipped and repeated rows
+    out = {"n": n, "edges": e, "dedup": pp.deduplicate_edges(torch.tensor(e)).numpy()}
+    excl = out["dedup"][:2000]
+    s = pp.sample_edges(n, 5000, exclude=torch.tensor(excl), seed=3).numpy()
+    out["exclude"] = excl
+    out["ref_sample_count"] = np.array(len(s))
+    out["ref_sample"] = s
+    np.savez_compressed(os.path.join(HERE, "preprocess.npz"), **out)
+    print("preprocess.npz: dedup", out["dedup"].shape, "sampled", len(s))
+
+
 def main():
     pymde = import_reference()
     import torch
@@ -325,6 +344,7 @@ def main():
     gen_trajectories(pymde, torch)
     gen_spectral(pymde, torch)
     gen_cycle(pymde, torch)
+    gen_preprocess(pymde, torch)
 
 
 if __name__ == "__main__":

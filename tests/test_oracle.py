@@ -113,3 +113,13 @@ def test_spectral_against_reference(golden_spectral):
         Q, _ = np.linalg.qr(want)
         resid = emb - Q @ (Q.T @ emb)
         assert np.linalg.norm(resid) / np.linalg.norm(emb) < 5e-3
+
+
+def test_edge_preprocessing_against_reference():
+    # deduplicate_edges is exact; sample_edges is pinned through its invariants
+    from conftest import load_golden
+    g = load_golden("preprocess")
+    np.testing.assert_array_equal(oracle.deduplicate_edges(g["edges"]), g["dedup"])
+    keys = oracle.check_sampled_edges(int(g["n"]), g["ref_sample"], g["exclude"])
+    # the reference draws 5000 and then drops the excluded ones: at most 5000 survive
+    assert len(keys) == int(g["ref_sample_count"]) <= 5000
