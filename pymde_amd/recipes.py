@@ -1,0 +1,101 @@
+"""Recipes that build MDE problems from data (the callers either side of the hot path).
+
+``preserve_distances`` for data matrices [ref: pymde/recipes.py:103-218,
+pymde/preprocess/data_matrix.py:11-88] is built from the GPU pieces of this package: the edge
+sampler (``preprocess.sample_edges``, row f1) and the edge-order distance kernel with
+``d = n_features`` (``mde_distances``, row f4).  Graph inputs (shortest-path distances, row f3) and
+``preserve_neighbors`` (kNN graph, row f2) are not built yet and say so.
+"""
+import torch
+
+from pymde_amd import _lib
+from pymde_amd import constraints
+from pymde_amd import preprocess
+from pymde_amd import problem
+from pymde_amd import util
+from pymde_amd.functions import losses
+
+
+class EdgeGraph(object):
+    """Edges with one value per edge (the role ``pymde.Graph`` plays for recipe outputs)."""
+
+    def __init__(self, edges, values, n_items):
+        self.edges = edges
+        self.distances = values
+        self.weights = values
+        self.n_items = int(n_items)
+
+
+def distances(data, retain_fraction=1.0, seed=None, device=None):
+    """Euclidean distances between (a sample of) the pairs of rows of a data matrix
+    [ref: preprocess/data_matrix.py:11-88].  All ``n (n-1)/2`` pairs when ``retain_fraction >= 1``,
+    otherwise a uniform sample of that fraction."""
+    if not isinstance(data, torch.Tensor):
+        data = torch.as_tensor(data)
+    if device is None:
+        device = data.device if data.is_cuda else util.get_default_device()
+    device = util.require_cuda_device(device)
+    data = data.to(device=device, dtype=torch.float32).contiguous()
+    n, nf = int(data.shape[0]), int(data.shape[1])
+    all_edges = n * (n - 1) // 2
+    max_distances = int(retain_fraction * all_edges)
+    if max_distances <= 0:
+        raise ValueError("max_distances must be positive")
+    if max_distances >= all_edges:
+        edges = util.all_edges(n).to(device).contiguous()
+    else:
+        edges = preprocess.sample_edges(n, max_distances, seed=seed, device=device)
+    lib = _lib.load()
+    delta = torch.empty(edges.shape[0], dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.mde_distances(n, edges.shape[0], _lib.ptr(edges), _lib.ptr(data), nf,
+                                     _lib.ptr(delta), _lib.stream_ptr(device)))
+    return EdgeGraph(edges, delta, n)
+
+
+def _remove_anchor_anchor_edges(edges, data, anchors):
+    """Drop edges whose two endpoints are both anchors: they are pinned by the constraint
+    [ref: recipes.py:15-100]."""
+    anchors = torch.as_tensor(anchors).to(edges.device)
+    if anchors.numel() == 0:
+        return edges, data
+    both = torch.isin(edges[:, 0], anchors) & torch.isin(edges[:, 1], anchors)
+    return edges[~both].contiguous(), data[~both].contiguous()
+
+
+def preserve_distances(data, embedding_dim=2, loss=losses.Absolute, constraint=None,
+                       max_distances=5e7, device=None, verbose=False, seed=None):
+    """An MDE problem that preserves the pairwise Euclidean distances of a data matrix
+    (rows = items) [ref: recipes.py:103-218].  At most ``max_distances`` pairs are used, sampled
+    uniformly; with ``Standardized()`` the distances are rescaled to the constraint's natural
+    length.  Call ``.embed()`` on the result."""
+    if not isinstance(data, torch.Tensor) and not hasattr(data, "shape"):
+        raise ValueError("`data` must be a np.ndarray / torch.Tensor data matrix")
+    if hasattr(data, "edges") and not isinstance(data, torch.Tensor):
+        raise NotImplementedError(
+            "preserve_distances on a graph needs shortest-path distances (SURVEY 8f row f3), which "
+            "this package does not build yet")
+    n_items = int(data.shape[0])
+    n_all_edges = n_items * (n_items - 1) / 2
+    retain_fraction = max_distances / n_all_edges
+    if verbose:
+        problem.LOGGER.info(f"Computing {int(min(max_distances, n_all_edges))} distances")
+    graph = distances(data, retain_fraction=retain_fraction, seed=seed, device=device)
+    edges, deviations = graph.edges, graph.distances
+    if constraint is None:
+        constraint = constraints.Centered()
+    elif isinstance(constraint, constraints._Standardized):
+        deviations = preprocess.scale(deviations,
+                                      constraint.natural_length(n_items, embedding_dim).to(deviations.device))
+    elif isinstance(constraint, constraints.Anchored):
+        edges, deviations = _remove_anchor_anchor_edges(edges, deviations, constraint.anchors)
+    return problem.MDE(n_items=n_items, embedding_dim=embedding_dim, edges=edges,
+                       distortion_function=loss(deviations), constraint=constraint,
+                       device=edges.device)
+
+
+def preserve_neighbors(*args, **kwargs):
+    raise NotImplementedError(
+        "preserve_neighbors needs a k-nearest-neighbour graph (SURVEY 8f row f2), which this package "
+        "does not build yet; construct the edges yourself and use pymde_amd.MDE with "
+        "penalties.PushAndPull + preprocess.dissimilar_edges (see tests/test_gpu_preprocess.py)")

@@ -331,6 +331,14 @@ def gen_preprocess(pymde, torch):
     out["exclude"] = excl
     out["ref_sample_count"] = np.array(len(s))
     out["ref_sample"] = s
+    # preserve_distances on a small data matrix with every pair retained (deterministic)
+    data = rng.standard_normal((40, 5)).astype(np.float32)
+    for cname, c in (("centered", None), ("standardized", pymde.Standardized())):
+        mde = pymde.preserve_distances(torch.tensor(data), embedding_dim=2, loss=pymde.losses.Absolute,
+                                       constraint=c)
+        out["pd_edges_" + cname] = mde.edges.numpy()
+        out["pd_deviations_" + cname] = mde.distortion_function.deviations.numpy()
+    out["pd_data"] = data
     np.savez_compressed(os.path.join(HERE, "preprocess.npz"), **out)
     print("preprocess.npz: dedup", out["dedup"].shape, "sampled", len(s))
 

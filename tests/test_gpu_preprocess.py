@@ -82,3 +82,30 @@ def test_negative_sampling_feeds_an_mde_problem():
     mde.embed(max_iter=30)
     E = mde.solve_stats.average_distortions
     assert E[-1] < E[0]
+
+
+def test_preserve_distances_recipe_matches_reference():
+    """recipes.preserve_distances on a data matrix (rows f1 + f4): with every pair retained the
+    problem is deterministic -- same edges and deviations as the reference's recipe."""
+    import pymde_amd
+    g = load_golden("preprocess")
+    data = torch.tensor(g["pd_data"])
+    for cname, c in (("centered", None), ("standardized", pymde_amd.Standardized())):
+        mde = pymde_amd.preserve_distances(data, embedding_dim=2, loss=pymde_amd.losses.Absolute, constraint=c)
+        np.testing.assert_array_equal(mde.edges.cpu().numpy(), g["pd_edges_" + cname])
+        np.testing.assert_allclose(mde.distortion_function.deviations.cpu().numpy(),
+                                   g["pd_deviations_" + cname], rtol=1e-6, atol=1e-7)
+        torch.manual_seed(0)
+        mde.embed(max_iter=50)
+        assert mde.value < mde.solve_stats.average_distortions[0]
+    # sampled pairs on a larger matrix: distances are exact for the sampled edges
+    rng = np.random.default_rng(0)
+    big = rng.standard_normal((5000, 64)).astype(np.float32)
+    mde = pymde_amd.preserve_distances(torch.tensor(big), max_distances=200_000, seed=1)
+    e = mde.edges.cpu().numpy()
+    assert len(e) == 200_000
+    oracle.check_sampled_edges(5000, e)
+    want = np.linalg.norm(big[e[:, 0]].astype(np.float64) - big[e[:, 1]], axis=1)
+    np.testing.assert_allclose(mde.distortion_function.deviations.cpu().numpy(), want, rtol=1e-5)
+    with pytest.raises(NotImplementedError):
+        pymde_amd.preserve_neighbors(big)
