@@ -181,6 +181,17 @@ int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in
  * edges_out [>= p, 2] sorted by (i, j) -- np.unique(axis=0)'s order; *count_host = their number. SYNC. */
 int mde_edges_deduplicate(int64_t n, int64_t p, const int64_t* edges, int64_t* edges_out,
                           int64_t* count_host, void* stream);
+/* Unique edges (i < j, sorted) with their multiplicity as a float weight; rows with i == j or a
+ * negative index are dropped.  This is how the k-NN graph gets weight 2 on mutual neighbours
+ * [ref: preprocess/data_matrix.py:141-178, graph.py:51-72].  SYNC. */
+int mde_edges_count_unique(int64_t n, int64_t p, const int64_t* edges, int64_t* edges_out,
+                           float* weights_out, int64_t* count_host, void* stream);
+/* Exact k nearest neighbours (Euclidean) of every row of data [n, nf]
+ * [ref: preprocess/data_matrix.py:91-140].  idx_out [n, k] int32 (self excluded; -1 when fewer than
+ * k other rows exist), d2_out [n, k] squared distances ascending per row; 1 <= k <= 64;
+ * sqn_work: n floats of scratch.  The Gram tiles run on the f32 matrix cores. */
+int mde_knn(int64_t n, int32_t nf, const float* data, int32_t k, int32_t* idx_out, float* d2_out,
+            float* sqn_work, void* stream);
 /* Sample at most num_edges distinct edges i < j uniformly at random from the edges NOT in
  * `exclude` [n_exclude, 2] (NULL / 0: no exclusion); edges_out must hold num_edges rows, sorted by
  * (i, j); *count_host = number written (== num_edges unless the complement is nearly exhausted).

@@ -230,6 +230,22 @@ def deduplicate_edges(edges):
     return np.unique(e, axis=0)
 
 
+def knn_graph(data, k):
+    """Exact k-NN graph of a data matrix: unique edges i < j (sorted) and weights 1 / 2 (mutual)
+    [ref: preprocess/data_matrix.py:91-178 with the sklearn brute-force branch]."""
+    X = np.asarray(data, dtype=np.float64)
+    n = X.shape[0]
+    sq = (X ** 2).sum(1)
+    D = sq[:, None] + sq[None, :] - 2.0 * X @ X.T
+    np.fill_diagonal(D, np.inf)
+    nbr = np.argsort(D, axis=1, kind="stable")[:, :k]
+    items = np.repeat(np.arange(n), k)
+    e = np.stack([items, nbr.ravel()], 1)
+    e = np.stack([e.min(1), e.max(1)], 1)
+    uniq, counts = np.unique(e, axis=0, return_counts=True)
+    return uniq.astype(np.int64), counts.astype(np.float32)
+
+
 def check_sampled_edges(n, sampled, exclude=None):
     """Invariants every output of sample_edges satisfies [ref: preprocess/preprocess.py:11-80]:
     i < j, in range, no duplicates, disjoint from `exclude`.  Returns the canonical keys."""

@@ -165,6 +165,86 @@ extern "C" int mde_edges_deduplicate(int64_t n, int64_t p, const int64_t* edges,
   return MDE_OK;
 }
 
+// Unique edges (i < j, sorted by (i, j)) with their multiplicity as a float weight: duplicated
+// edges have their unit weights summed, as Graph.from_edges does [ref: preprocess/graph.py:51-72,
+// data_matrix.py:170-178] (a mutual k-NN pair gets weight 2).  Rows with i == j are dropped.  SYNC.
+__global__ __launch_bounds__(MDE_BLOCK) void k_runs_to_edges(int64_t n, int64_t m, const uint64_t* __restrict__ keys,
+                                                             const int32_t* __restrict__ counts,
+                                                             int64_t* __restrict__ edges, float* __restrict__ w) {
+  for (int64_t k = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; k < m;
+       k += (int64_t)gridDim.x * MDE_BLOCK) {
+    const uint64_t key = keys[k];
+    reinterpret_cast<longlong2*>(edges)[k] = make_longlong2((long long)(key / (uint64_t)n),
+                                                             (long long)(key % (uint64_t)n));
+    w[k] = (float)counts[k];
+  }
+}
+__global__ __launch_bounds__(MDE_BLOCK) void k_flag_valid_pairs(int64_t p, const int64_t* __restrict__ edges,
+                                                                uint8_t* __restrict__ flags) {
+  for (int64_t k = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; k < p;
+       k += (int64_t)gridDim.x * MDE_BLOCK) {
+    const longlong2 e = reinterpret_cast<const longlong2*>(edges)[k];
+    flags[k] = (e.x != e.y && e.x >= 0 && e.y >= 0) ? 1 : 0;
+  }
+}
+
+extern "C" int mde_edges_count_unique(int64_t n, int64_t p, const int64_t* edges, int64_t* edges_out,
+                                      float* weights_out, int64_t* count_host, void* stream) {
+  if (!edges_out || !weights_out || !count_host || (p > 0 && !edges)) return MDE_E_INVALID;
+  int rc = check_sizes(n, p);
+  if (rc != MDE_OK) return rc;
+  hipStream_t st = mde_stream(stream);
+  *count_host = 0;
+  if (p == 0) return MDE_OK;
+  DevBuf keys, flags, kept, sorted, uniq, counts, num, tmp;
+  MDE_HIP(keys.alloc(p * sizeof(uint64_t)));
+  MDE_HIP(kept.alloc(p * sizeof(uint64_t)));
+  MDE_HIP(flags.alloc(p));
+  MDE_HIP(num.alloc(sizeof(int64_t)));
+  hipLaunchKernelGGL(k_edge_keys, dim3(mde_grid(p, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, n, p, edges,
+                     keys.as<uint64_t>());
+  MDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_flag_valid_pairs, dim3(mde_grid(p, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, p, edges,
+                     flags.as<uint8_t>());
+  MDE_LAUNCH_CHECK();
+  size_t tb = 0;
+  MDE_HIP(hipcub::DeviceSelect::Flagged(nullptr, tb, keys.as<uint64_t>(), flags.as<uint8_t>(), kept.as<uint64_t>(),
+                                        num.as<int64_t>(), (int)p, st));
+  MDE_HIP(tmp.alloc(tb));
+  MDE_HIP(hipcub::DeviceSelect::Flagged(tmp.p, tb, keys.as<uint64_t>(), flags.as<uint8_t>(), kept.as<uint64_t>(),
+                                        num.as<int64_t>(), (int)p, st));
+  int64_t pv = 0;
+  MDE_HIP(hipMemcpyAsync(&pv, num.p, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  MDE_HIP(hipStreamSynchronize(st));
+  if (pv == 0) return MDE_OK;
+  MDE_HIP(sorted.alloc(pv * sizeof(uint64_t)));
+  MDE_HIP(uniq.alloc(pv * sizeof(uint64_t)));
+  MDE_HIP(counts.alloc(pv * sizeof(int32_t)));
+  size_t tb2 = 0;
+  const int end_bit = bits_for_key((uint64_t)n * (uint64_t)n);
+  DevBuf tmp2, tmp3;
+  MDE_HIP(hipcub::DeviceRadixSort::SortKeys(nullptr, tb2, kept.as<uint64_t>(), sorted.as<uint64_t>(), (int)pv, 0,
+                                            end_bit, st));
+  MDE_HIP(tmp2.alloc(tb2));
+  MDE_HIP(hipcub::DeviceRadixSort::SortKeys(tmp2.p, tb2, kept.as<uint64_t>(), sorted.as<uint64_t>(), (int)pv, 0,
+                                            end_bit, st));
+  size_t tb3 = 0;
+  MDE_HIP(hipcub::DeviceRunLengthEncode::Encode(nullptr, tb3, sorted.as<uint64_t>(), uniq.as<uint64_t>(),
+                                                counts.as<int32_t>(), num.as<int64_t>(), (int)pv, st));
+  MDE_HIP(tmp3.alloc(tb3));
+  MDE_HIP(hipcub::DeviceRunLengthEncode::Encode(tmp3.p, tb3, sorted.as<uint64_t>(), uniq.as<uint64_t>(),
+                                                counts.as<int32_t>(), num.as<int64_t>(), (int)pv, st));
+  int64_t m = 0;
+  MDE_HIP(hipMemcpyAsync(&m, num.p, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+  MDE_HIP(hipStreamSynchronize(st));
+  hipLaunchKernelGGL(k_runs_to_edges, dim3(mde_grid(m, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, n, m,
+                     uniq.as<uint64_t>(), counts.as<int32_t>(), edges_out, weights_out);
+  MDE_LAUNCH_CHECK();
+  MDE_HIP(hipStreamSynchronize(st));
+  *count_host = m;
+  return MDE_OK;
+}
+
 // Sample (at most) `num_edges` distinct edges i < j uniformly from the complement of `exclude`
 // [n_exclude, 2] (may be NULL).  edges_out must hold num_edges rows.  SYNC.
 extern "C" int mde_sample_edges(int64_t n, int64_t num_edges, uint64_t seed, const int64_t* exclude,

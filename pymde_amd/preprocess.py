@@ -80,6 +80,48 @@ def dissimilar_edges(n_items, similar_edges, num_edges=None, seed=None):
     return sample_edges(n_items, num_edges, exclude=similar_edges, seed=seed)
 
 
+def k_nearest_neighbors(data, k, max_distance=None, device=None):
+    """Exact k-nearest-neighbour graph of the rows of a data matrix (Euclidean distance)
+    [ref: preprocess/data_matrix.py:91-178].
+
+    Returns ``(edges, weights)`` on the GPU: unique edges i < j sorted by (i, j); the weight is 2
+    when i and j are neighbours of each other, 1 when only one is a neighbour of the other.
+    The reference is exact (sklearn brute force) below 10 000 items and approximate
+    (pynndescent) above; this search is exact at every size.  Self matches are excluded by
+    index, so duplicated rows become ordinary zero-distance neighbours."""
+    if max_distance is not None:
+        raise NotImplementedError("max_distance is not supported by the GPU k-NN graph yet")
+    if not isinstance(data, torch.Tensor):
+        data = torch.as_tensor(data)
+    if device is None:
+        device = data.device if data.is_cuda else util.get_default_device()
+    device = util.require_cuda_device(device)
+    data = data.to(device=device, dtype=torch.float32).contiguous()
+    n, nf = int(data.shape[0]), int(data.shape[1])
+    k = int(k)
+    if k > n - 1:
+        k = n - 1
+    if k < 1:
+        raise ValueError("k must be at least 1")
+    lib = _lib.load()
+    idx = torch.empty((n, k), dtype=torch.int32, device=device)
+    d2 = torch.empty((n, k), dtype=torch.float32, device=device)
+    sqn = torch.empty(n, dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.mde_knn(n, nf, _lib.ptr(data), k, _lib.ptr(idx), _lib.ptr(d2), _lib.ptr(sqn),
+                               _lib.stream_ptr(device)))
+    items = torch.arange(n, device=device, dtype=torch.int64).repeat_interleave(k)
+    pairs = torch.stack([items, idx.reshape(-1).to(torch.int64)], dim=1).contiguous()
+    edges = torch.empty_like(pairs)
+    weights = torch.empty(pairs.shape[0], dtype=torch.float32, device=device)
+    count = ctypes.c_int64(0)
+    with torch.cuda.device(device):
+        _lib.check(lib.mde_edges_count_unique(n, pairs.shape[0], _lib.ptr(pairs), _lib.ptr(edges),
+                                              _lib.ptr(weights), ctypes.byref(count),
+                                              _lib.stream_ptr(device)))
+    return edges[:count.value], weights[:count.value]
+
+
 def _rms(distances):
     return distances.pow(2).mean().sqrt()
 

@@ -3,8 +3,9 @@
 ``preserve_distances`` for data matrices [ref: pymde/recipes.py:103-218,
 pymde/preprocess/data_matrix.py:11-88] is built from the GPU pieces of this package: the edge
 sampler (``preprocess.sample_edges``, row f1) and the edge-order distance kernel with
-``d = n_features`` (``mde_distances``, row f4).  Graph inputs (shortest-path distances, row f3) and
-``preserve_neighbors`` (kNN graph, row f2) are not built yet and say so.
+``d = n_features`` (``mde_distances``, row f4).  ``preserve_neighbors`` for data matrices [ref: recipes.py:221-448] adds
+the exact GPU k-NN graph (``preprocess.k_nearest_neighbors``, row f2) and the spectral initialiser.
+Graph inputs (shortest-path distances, row f3) are not built yet and say so.
 """
 import torch
 
@@ -13,7 +14,8 @@ from pymde_amd import constraints
 from pymde_amd import preprocess
 from pymde_amd import problem
 from pymde_amd import util
-from pymde_amd.functions import losses
+from pymde_amd import quadratic
+from pymde_amd.functions import losses, penalties
 
 
 class EdgeGraph(object):
@@ -94,8 +96,76 @@ def preserve_distances(data, embedding_dim=2, loss=losses.Absolute, constraint=N
                        device=edges.device)
 
 
-def preserve_neighbors(*args, **kwargs):
-    raise NotImplementedError(
-        "preserve_neighbors needs a k-nearest-neighbour graph (SURVEY 8f row f2), which this package "
-        "does not build yet; construct the edges yourself and use pymde_amd.MDE with "
-        "penalties.PushAndPull + preprocess.dissimilar_edges (see tests/test_gpu_preprocess.py)")
+def preserve_neighbors(data, embedding_dim=2, attractive_penalty=penalties.Log1p,
+                       repulsive_penalty=penalties.Log, constraint=None, n_neighbors=None,
+                       repulsive_fraction=None, max_distance=None, init="quadratic", device=None,
+                       verbose=False, seed=None):
+    """An MDE problem that preserves the k-nearest-neighbour structure of a data matrix
+    (rows = items) [ref: recipes.py:221-448]: k-NN graph (weights 1 / 2), optional spectral
+    initialisation, uniformly sampled repulsive edges (weight -1), ``PushAndPull`` of the two
+    penalties.  Every stage runs on the GPU (rows f2, a10, f1 of SURVEY section 8).  Graph inputs
+    (shortest-path neighbourhoods, row f3) are not built yet."""
+    if hasattr(data, "edges") and not isinstance(data, torch.Tensor):
+        raise NotImplementedError(
+            "preserve_neighbors on a graph needs shortest-path distances (SURVEY 8f row f3), which "
+            "this package does not build yet")
+    if not isinstance(data, torch.Tensor):
+        data = torch.as_tensor(data)
+    if device is None:
+        device = data.device if data.is_cuda else util.get_default_device()
+    device = util.require_cuda_device(device)
+    n = int(data.shape[0])
+    if n_neighbors is None:
+        # the reference's default (recipes.py:300-307): max(min(15, 2 % of the items), 5)
+        n_neighbors = int(max(min(15, n * 0.02), 5))
+    if n_neighbors > n:
+        problem.LOGGER.warning(
+            "Requested n_neighbors {0} > number of items {1}. Setting n_neighbors to {2}".format(
+                n_neighbors, n, n - 1))
+        n_neighbors = n - 1
+    if constraint is None and repulsive_penalty is not None:
+        constraint = constraints.Centered()
+    elif constraint is None and repulsive_penalty is None:
+        constraint = constraints.Standardized()
+    if verbose:
+        problem.LOGGER.info(f"Computing {n_neighbors}-nearest neighbors, with max_distance={max_distance}")
+    edges, weights = preprocess.k_nearest_neighbors(data, k=n_neighbors, max_distance=max_distance,
+                                                    device=device)
+    if isinstance(constraint, constraints.Anchored):
+        edges, weights = _remove_anchor_anchor_edges(edges, weights, constraint.anchors)
+    if init == "quadratic":
+        if verbose:
+            problem.LOGGER.info(f"Computing {init} initialization.")
+        X_init = quadratic.spectral(n, embedding_dim, edges, weights, max_iter=1000, device=device, cg=True)
+        if not isinstance(constraint, (constraints._Centered, constraints._Standardized)):
+            constraint.project_onto_constraint(X_init, inplace=True)
+    elif init == "random":
+        X_init = constraint.initialization(n, embedding_dim, device)
+    else:
+        raise ValueError(f"Unsupported value '{init}' for keyword argument `init`; "
+                         "the supported values are 'quadratic' and 'random'.")
+    if repulsive_penalty is not None:
+        if repulsive_fraction is None:
+            # the standardization constraint already spreads the points: use a lower repulsion
+            repulsive_fraction = 0.5 if isinstance(constraint, constraints._Standardized) else 1
+        n_choose_2 = n * (n - 1) // 2
+        n_repulsive = min(int(repulsive_fraction * edges.shape[0]), n_choose_2 - edges.shape[0])
+        negative_edges = preprocess.sample_edges(n, n_repulsive, exclude=edges, seed=seed, device=device)
+        negative_weights = -torch.ones(negative_edges.shape[0], dtype=torch.float32, device=device)
+        if isinstance(constraint, constraints.Anchored):
+            negative_edges, negative_weights = _remove_anchor_anchor_edges(
+                negative_edges, negative_weights, constraint.anchors)
+        edges = torch.cat([edges, negative_edges])
+        weights = torch.cat([weights, negative_weights])
+        f = penalties.PushAndPull(weights, attractive_penalty=attractive_penalty,
+                                  repulsive_penalty=repulsive_penalty)
+    else:
+        f = attractive_penalty(weights)
+    mde = problem.MDE(n_items=n, embedding_dim=embedding_dim, edges=edges, distortion_function=f,
+                      constraint=constraint, device=device)
+    mde._X_init = X_init
+    # overlapping points make the average distortion non-differentiable: perturb them apart
+    if bool((mde.distances(mde._X_init) == 0).any()):
+        mde._X_init = mde._X_init + 1e-4 * torch.randn(mde._X_init.shape, device=device,
+                                                       dtype=mde._X_init.dtype)
+    return mde

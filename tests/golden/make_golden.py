@@ -339,6 +339,14 @@ def gen_preprocess(pymde, torch):
         out["pd_edges_" + cname] = mde.edges.numpy()
         out["pd_deviations_" + cname] = mde.distortion_function.deviations.numpy()
     out["pd_data"] = data
+    # k-NN graph of the reference (sklearn brute-force branch, n < 10 000); the stub for the
+    # un-installed pynndescent only has to be importable
+    sys.modules["pynndescent"].NNDescent = None
+    kd = rng.standard_normal((600, 20)).astype(np.float32)
+    kg = pymde.preprocess.k_nearest_neighbors(torch.tensor(kd), k=15)
+    out["knn_data"] = kd
+    out["knn_edges"] = kg.edges.numpy()
+    out["knn_weights"] = kg.weights.numpy()
     np.savez_compressed(os.path.join(HERE, "preprocess.npz"), **out)
     print("preprocess.npz: dedup", out["dedup"].shape, "sampled", len(s))
 

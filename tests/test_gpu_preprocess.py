@@ -107,5 +107,49 @@ def test_preserve_distances_recipe_matches_reference():
     oracle.check_sampled_edges(5000, e)
     want = np.linalg.norm(big[e[:, 0]].astype(np.float64) - big[e[:, 1]], axis=1)
     np.testing.assert_allclose(mde.distortion_function.deviations.cpu().numpy(), want, rtol=1e-5)
-    with pytest.raises(NotImplementedError):
-        pymde_amd.preserve_neighbors(big)
+
+
+def test_knn_graph_matches_reference_and_oracle():
+    """Row f2: exact k-NN graph (f32 MFMA Gram tiles + top-k) -- bit-identical edges and weights to
+    the reference's sklearn brute-force branch, and to the oracle at sizes / widths that exercise
+    partial tiles (n, nf not multiples of 64 / 32)."""
+    from pymde_amd import preprocess
+    g = load_golden("preprocess")
+    e, w = preprocess.k_nearest_neighbors(torch.tensor(g["knn_data"]), 15)
+    assert e.is_cuda
+    np.testing.assert_array_equal(e.cpu().numpy(), g["knn_edges"])
+    np.testing.assert_array_equal(w.cpu().numpy(), g["knn_weights"])
+    rng = np.random.default_rng(3)
+    for n, nf, k in ((1000, 37, 5), (3001, 784, 15), (130, 3, 64), (65, 130, 7)):
+        X = rng.standard_normal((n, nf)).astype(np.float32)
+        e, w = preprocess.k_nearest_neighbors(torch.tensor(X, device=DEV), k)
+        oe, ow = oracle.knn_graph(X, k)
+        np.testing.assert_array_equal(e.cpu().numpy(), oe)
+        np.testing.assert_array_equal(w.cpu().numpy(), ow)
+
+
+def test_preserve_neighbors_recipe_end_to_end():
+    """recipes.preserve_neighbors on clustered data: k-NN graph, spectral init, negative sampling,
+    PushAndPull, embed -- all on the GPU; the embedding keeps the clusters apart."""
+    import pymde_amd
+    rng = np.random.default_rng(0)
+    centers = rng.standard_normal((6, 50)) * 6
+    labels = rng.integers(0, 6, 6000)
+    data = (centers[labels] + rng.standard_normal((6000, 50))).astype(np.float32)
+    torch.manual_seed(0)
+    mde = pymde_amd.preserve_neighbors(torch.tensor(data), embedding_dim=2, constraint=pymde_amd.Standardized(),
+                                       seed=0)
+    assert mde._X_init is not None and mde._X_init.shape == (6000, 2)
+    w = mde.distortion_function.weights
+    assert set(np.unique(w.cpu().numpy()).tolist()) <= {-1.0, 1.0, 2.0}
+    X = mde.embed(max_iter=100).cpu().numpy()
+    np.testing.assert_allclose(X.T @ X / 6000, np.eye(2), atol=1e-3)
+    cent = np.stack([X[labels == c].mean(0) for c in range(6)])
+    within = np.mean([np.linalg.norm(X[labels == c] - cent[c], axis=1).mean() for c in range(6)])
+    between = np.linalg.norm(cent[:, None] - cent[None], axis=2)[np.triu_indices(6, 1)].mean()
+    assert between > 3 * within, (between, within)
+    # default constraint / random init / no repulsion variants construct as well
+    m2 = pymde_amd.preserve_neighbors(torch.tensor(data[:500]), init="random", repulsive_penalty=None)
+    assert isinstance(m2.constraint, pymde_amd.constraints._Standardized)
+    with pytest.raises(ValueError):
+        pymde_amd.preserve_neighbors(torch.tensor(data[:500]), init="bogus")

@@ -123,3 +123,12 @@ def test_edge_preprocessing_against_reference():
     keys = oracle.check_sampled_edges(int(g["n"]), g["ref_sample"], g["exclude"])
     # the reference draws 5000 and then drops the excluded ones: at most 5000 survive
     assert len(keys) == int(g["ref_sample_count"]) <= 5000
+
+
+def test_knn_graph_against_reference():
+    # the oracle's exact k-NN graph equals the reference's (sklearn brute force)
+    from conftest import load_golden
+    g = load_golden("preprocess")
+    e, w = oracle.knn_graph(g["knn_data"], 15)
+    np.testing.assert_array_equal(e, g["knn_edges"])
+    np.testing.assert_array_equal(w, g["knn_weights"])
