@@ -192,6 +192,16 @@ int mde_edges_count_unique(int64_t n, int64_t p, const int64_t* edges, int64_t* 
  * sqn_work: n floats of scratch.  The Gram tiles run on the f32 matrix cores. */
 int mde_knn(int64_t n, int32_t nf, const float* data, int32_t k, int32_t* idx_out, float* d2_out,
             float* sqn_work, void* stream);
+/* Shortest-path distances on the graph whose edges built `plan` (a FULL plan; its symmetrised CSR
+ * is the adjacency) [ref: preprocess/graph.py:286-474, _graph.pyx:10-52].
+ * w: per-half-edge edge lengths in plan (CSR) order (mde_plan_expand), or NULL for unit lengths
+ * (BFS).  For every pair i < j at finite positive distance <= max_length (<= 0: no limit) the pair is
+ * kept with probability retain_fraction (>= 1: all), decided by a hash of (seed, i, j).  Writes the
+ * kept pairs sorted by (i, j) to edges_out [capacity, 2] / dist_out [capacity]; *count_host = their
+ * number (fails with MDE_E_INVALID, count still reported, when it exceeds `capacity`).  SYNC. */
+int mde_graph_shortest_paths(const mde_plan* plan, const float* w, float max_length,
+                             double retain_fraction, uint64_t seed, int64_t capacity,
+                             int64_t* edges_out, float* dist_out, int64_t* count_host, void* stream);
 /* Sample at most num_edges distinct edges i < j uniformly at random from the edges NOT in
  * `exclude` [n_exclude, 2] (NULL / 0: no exclusion); edges_out must hold num_edges rows, sorted by
  * (i, j); *count_host = number written (== num_edges unless the complement is nearly exhausted).

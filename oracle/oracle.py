@@ -246,6 +246,24 @@ def knn_graph(data, k):
     return uniq.astype(np.int64), counts.astype(np.float32)
 
 
+def shortest_path_pairs(n, edges, weights=None, max_length=None):
+    """All pairs i < j at finite positive shortest-path distance (<= max_length), sorted by (i, j),
+    with their distances [ref: preprocess/graph.py:345-474 with retain_fraction = 1]."""
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as csgraph
+    e = np.asarray(edges)
+    w = np.ones(len(e)) if weights is None else np.asarray(weights, dtype=np.float64)
+    A = sp.coo_matrix((w, (e[:, 0], e[:, 1])), shape=(n, n))
+    A = (A + A.T).tocsr()
+    D = csgraph.shortest_path(A, directed=False)
+    iu, ju = np.triu_indices(n, 1)
+    d = D[iu, ju]
+    ok = np.isfinite(d) & (d > 0)
+    if max_length is not None:
+        ok &= d <= max_length
+    return np.stack([iu[ok], ju[ok]], 1).astype(np.int64), d[ok]
+
+
 def check_sampled_edges(n, sampled, exclude=None):
     """Invariants every output of sample_edges satisfies [ref: preprocess/preprocess.py:11-80]:
     i < j, in range, no duplicates, disjoint from `exclude`.  Returns the canonical keys."""

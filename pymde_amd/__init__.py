@@ -13,4 +13,5 @@ from pymde_amd.functions import losses, penalties  # noqa: F401
 from pymde_amd.util import all_edges, center, seed  # noqa: F401
 from pymde_amd import quadratic  # noqa: F401
 from pymde_amd import preprocess  # noqa: F401
+from pymde_amd.graph import Graph  # noqa: F401
 from pymde_amd.recipes import preserve_distances, preserve_neighbors  # noqa: F401

@@ -51,6 +51,8 @@ SYMBOLS = {
     "mde_edges_deduplicate": (c_i32, [c_i64, c_i64, c_vp, c_vp, ctypes.POINTER(c_i64), c_vp]),
     "mde_edges_count_unique": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, ctypes.POINTER(c_i64), c_vp]),
     "mde_knn": (c_i32, [c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "mde_graph_shortest_paths": (c_i32, [c_vp, c_vp, c_f32, ctypes.c_double, ctypes.c_uint64, c_i64,
+                                         c_vp, c_vp, ctypes.POINTER(c_i64), c_vp]),
     "mde_sample_edges": (c_i32, [c_i64, c_i64, ctypes.c_uint64, c_vp, c_i64, c_vp,
                                  ctypes.POINTER(c_i64), c_vp]),
     "mde_average_distortion": (c_i32, [c_vp, c_vp, c_i32, ctypes.POINTER(MdeFunc), c_f32, c_vp,

@@ -1,0 +1,207 @@
+// mde_graph.hip -- shortest-path distances on a graph.
+//   [ref: pymde/preprocess/graph.py:286-474 shortest_paths / _shortest_paths and the Cython BFS
+//    pymde/preprocess/_graph.pyx:10-52 -- the reference's only native code]
+// The reference runs one BFS (unit weights) or Dijkstra per node in a multiprocessing pool and
+// keeps, for node i, the targets j > i at finite positive distance (<= max_length), each with
+// probability retain_fraction.  Here a batch of B sources is solved at once on the device: the
+// distance rows dist[b][.] live in HBM/L2 and are relaxed with a pull-style Bellman-Ford sweep
+//      dist[b][u] = min(dist[b][u], min_{v ~ u} dist[b][v] + w_uv)
+// over the symmetrised CSR of the edge plan (no atomics; in-place updates are safe because every
+// value is always the length of a real path and only decreases).  With unit weights the sweep count
+// is the hop eccentricity of the batch (a level-synchronous BFS); the fixed point is detected with
+// a device flag checked every few sweeps.  Retained pairs are selected by a per-pair hash (so the
+// outcome does not depend on the batching), compacted with wave-aggregated atomics and finally
+// sorted by (i, j).
+#include <hipcub/hipcub.hpp>
+
+#include "mde_common.h"
+#include "mde_plan.h"
+
+#define MDE_INF_F 3.402823466e+38f
+
+__device__ __forceinline__ uint64_t gsplitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(MDE_BLOCK) void k_sp_init(int64_t B, int64_t n, int64_t src0, float* __restrict__ dist) {
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < B * n;
+       i += (int64_t)gridDim.x * MDE_BLOCK) {
+    const int64_t b = i / n, v = i % n;
+    dist[i] = (v == src0 + b) ? 0.0f : MDE_INF_F;
+  }
+}
+
+// one relaxation sweep over every (source b, vertex u)
+__global__ __launch_bounds__(MDE_BLOCK) void k_sp_relax(int64_t B, int n, const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ nbr,
+                                                        const float* __restrict__ w, float max_length,
+                                                        float* __restrict__ dist, int* __restrict__ changed) {
+  bool any = false;
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < B * (int64_t)n;
+       i += (int64_t)gridDim.x * MDE_BLOCK) {
+    const int64_t b = i / n;
+    const int u = (int)(i % n);
+    float* row = dist + b * (int64_t)n;
+    const float cur = row[u];
+    float best = cur;
+    for (int h = rowptr[u]; h < rowptr[u + 1]; ++h) {
+      const float dv = row[nbr[h]];
+      if (dv < MDE_INF_F) {
+        const float cand = dv + (w ? w[h] : 1.0f);
+        best = cand < best ? cand : best;
+      }
+    }
+    if (best < cur && best <= max_length) {
+      row[u] = best;
+      any = true;
+    }
+  }
+  if (__any(any) && (threadIdx.x & 63) == 0) *changed = 1;
+}
+
+// keep (i = src0 + b, j) with j > i, 0 < dist < inf, hash(i, j) < threshold
+__global__ __launch_bounds__(MDE_BLOCK) void k_sp_emit(int64_t B, int64_t n, int64_t src0,
+                                                       const float* __restrict__ dist, uint64_t seed,
+                                                       uint64_t threshold, int keep_all, int64_t capacity,
+                                                       unsigned long long* __restrict__ counter,
+                                                       uint64_t* __restrict__ keys, float* __restrict__ vals) {
+  for (int64_t i0 = (int64_t)blockIdx.x * MDE_BLOCK; i0 < B * n; i0 += (int64_t)gridDim.x * MDE_BLOCK) {
+    const int64_t i = i0 + threadIdx.x;
+    bool keep = false;
+    uint64_t key = 0;
+    float d = 0.0f;
+    if (i < B * n) {
+      const int64_t src = src0 + i / n, j = i % n;
+      d = dist[i];
+      if (j > src && d > 0.0f && d < MDE_INF_F) {
+        key = (uint64_t)src * (uint64_t)n + (uint64_t)j;
+        keep = keep_all || gsplitmix64(seed ^ gsplitmix64(key)) < threshold;
+      }
+    }
+    // wave-aggregated slot reservation
+    const unsigned long long mask = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    unsigned long long base = 0;
+    if (mask) {
+      const int leader = __ffsll((long long)mask) - 1;
+      if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(mask));
+      base = __shfl(base, leader, 64);
+      if (keep) {
+        const unsigned long long pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if ((int64_t)pos < capacity) {
+          keys[pos] = key;
+          vals[pos] = d;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(MDE_BLOCK) void k_sp_unpack(int64_t n, int64_t m, const uint64_t* __restrict__ keys,
+                                                         int64_t* __restrict__ edges) {
+  for (int64_t k = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; k < m;
+       k += (int64_t)gridDim.x * MDE_BLOCK) {
+    const uint64_t key = keys[k];
+    reinterpret_cast<longlong2*>(edges)[k] = make_longlong2((long long)(key / (uint64_t)n),
+                                                             (long long)(key % (uint64_t)n));
+  }
+}
+
+struct GBuf {
+  void* p = nullptr;
+  ~GBuf() {
+    if (p) (void)hipFree(p);
+  }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  template <typename T>
+  T* as() {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+// plan: a FULL plan of the graph's edges (its symmetrised CSR is the adjacency); w: per-half-edge
+// edge lengths in plan (CSR) order, or NULL for unit lengths.  Writes at most `capacity` pairs
+// (i < j, sorted by (i, j)) with their shortest-path distances; *count_host = number of pairs (if it
+// exceeds `capacity` the call fails with MDE_E_INVALID and reports the needed size).  SYNC.
+extern "C" int mde_graph_shortest_paths(const mde_plan* plan, const float* w, float max_length,
+                                        double retain_fraction, uint64_t seed, int64_t capacity,
+                                        int64_t* edges_out, float* dist_out, int64_t* count_host,
+                                        void* stream) {
+  if (!plan || !edges_out || !dist_out || !count_host || capacity < 0) return MDE_E_INVALID;
+  if (plan->row_lo != 0 || plan->row_hi != plan->n) {
+    mde_set_error("mde_graph_shortest_paths needs a full (unsharded) plan");
+    return MDE_E_INVALID;
+  }
+  hipStream_t st = mde_stream(stream);
+  const int64_t n = plan->n;
+  *count_host = 0;
+  if (capacity >= ((int64_t)1 << 31) - 1) return MDE_E_TOO_LARGE;
+  if (!(max_length > 0.0f)) max_length = MDE_INF_F;
+  const int keep_all = retain_fraction >= 1.0;
+  uint64_t threshold = ~0ull;
+  if (!keep_all) {
+    const double t = retain_fraction <= 0.0 ? 0.0 : retain_fraction * 18446744073709551616.0;
+    threshold = t >= 18446744073709549568.0 ? ~0ull : (uint64_t)t;
+  }
+  // batch of sources: about 1 GiB of distance rows
+  int64_t B = ((int64_t)1 << 28) / (n > 0 ? n : 1);
+  if (B < 1) B = 1;
+  if (B > n) B = n;
+  GBuf dist, keys, vals, counter, changed;
+  MDE_HIP(dist.alloc((size_t)B * n * sizeof(float)));
+  MDE_HIP(keys.alloc((size_t)(capacity + 1) * sizeof(uint64_t)));
+  MDE_HIP(vals.alloc((size_t)(capacity + 1) * sizeof(float)));
+  MDE_HIP(counter.alloc(sizeof(unsigned long long)));
+  MDE_HIP(changed.alloc(sizeof(int)));
+  MDE_HIP(hipMemsetAsync(counter.p, 0, sizeof(unsigned long long), st));
+  const int nblk = mde_grid(B * n, MDE_BLOCK, 8192);
+  for (int64_t src0 = 0; src0 < n; src0 += B) {
+    const int64_t Bc = (src0 + B <= n) ? B : n - src0;
+    hipLaunchKernelGGL(k_sp_init, dim3(nblk), dim3(MDE_BLOCK), 0, st, Bc, n, src0, dist.as<float>());
+    MDE_LAUNCH_CHECK();
+    for (int64_t sweep = 0; sweep < 4 * n + 8; sweep += 4) {
+      MDE_HIP(hipMemsetAsync(changed.p, 0, sizeof(int), st));
+      for (int s4 = 0; s4 < 4; ++s4) {
+        hipLaunchKernelGGL(k_sp_relax, dim3(nblk), dim3(MDE_BLOCK), 0, st, Bc, (int)n, plan->rowptr, plan->nbr, w,
+                           max_length, dist.as<float>(), changed.as<int>());
+        MDE_LAUNCH_CHECK();
+      }
+      int h = 0;
+      MDE_HIP(hipMemcpyAsync(&h, changed.p, sizeof(int), hipMemcpyDeviceToHost, st));
+      MDE_HIP(hipStreamSynchronize(st));
+      if (!h) break;
+    }
+    hipLaunchKernelGGL(k_sp_emit, dim3(nblk), dim3(MDE_BLOCK), 0, st, Bc, n, src0, dist.as<float>(), seed, threshold,
+                       keep_all, capacity, counter.as<unsigned long long>(), keys.as<uint64_t>(), vals.as<float>());
+    MDE_LAUNCH_CHECK();
+  }
+  unsigned long long total = 0;
+  MDE_HIP(hipMemcpyAsync(&total, counter.p, sizeof(total), hipMemcpyDeviceToHost, st));
+  MDE_HIP(hipStreamSynchronize(st));
+  *count_host = (int64_t)total;
+  if ((int64_t)total > capacity) {
+    mde_set_error("shortest paths: %lld pairs retained but the output holds %lld", (long long)total,
+                  (long long)capacity);
+    return MDE_E_INVALID;
+  }
+  if (total == 0) return MDE_OK;
+  // sort by (i, j): the emission order depends on atomic arbitration, the result must not
+  GBuf keys2, tmp;
+  MDE_HIP(keys2.alloc((size_t)total * sizeof(uint64_t)));
+  size_t tb = 0;
+  int end_bit = 1;
+  while (end_bit < 64 && (((uint64_t)n * (uint64_t)n) >> end_bit)) ++end_bit;
+  MDE_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<float>(),
+                                             dist_out, (int)total, 0, end_bit, st));
+  MDE_HIP(tmp.alloc(tb));
+  MDE_HIP(hipcub::DeviceRadixSort::SortPairs(tmp.p, tb, keys.as<uint64_t>(), keys2.as<uint64_t>(), vals.as<float>(),
+                                             dist_out, (int)total, 0, end_bit, st));
+  hipLaunchKernelGGL(k_sp_unpack, dim3(mde_grid((int64_t)total, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, n,
+                     (int64_t)total, keys2.as<uint64_t>(), edges_out);
+  MDE_LAUNCH_CHECK();
+  MDE_HIP(hipStreamSynchronize(st));
+  return MDE_OK;
+}

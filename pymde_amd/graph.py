@@ -1,0 +1,110 @@
+"""Graphs as MDE inputs: the ``Graph`` container and shortest-path distances on the GPU.
+
+``Graph`` keeps the role of the reference's ``pymde.Graph`` [ref: pymde/preprocess/graph.py:75-256]
+for what the recipes need: unique undirected edges ``i < j`` with one positive value each (called
+``weights`` or ``distances`` depending on the use), ``n_items``, ``from_edges`` (duplicate edges
+have their values summed).  It lives on the GPU; its adjacency is the symmetrised CSR of an
+``EdgePlan``.  ``shortest_paths`` [ref: graph.py:345-474] runs batched Bellman-Ford / BFS sweeps
+(``csrc/mde_graph.hip``) instead of one scipy Dijkstra or Cython BFS per node in a process pool.
+"""
+import ctypes
+import math
+
+import torch
+
+from pymde_amd import _lib
+from pymde_amd import average_distortion as _ad
+from pymde_amd import util
+
+
+class Graph(object):
+    """An undirected weighted graph given by its unique edges."""
+
+    def __init__(self, edges, values, n_items):
+        self.edges = edges
+        self._values = values
+        self.n_items = int(n_items)
+        self._plan = None
+
+    @staticmethod
+    def from_edges(edges, weights=None, n_items=None, device=None):
+        """Build a graph from an edge list; edges are put in ``i < j`` order, sorted, and the
+        values of repeated edges are summed [ref: graph.py:51-72, :118-140]."""
+        if not isinstance(edges, torch.Tensor):
+            edges = torch.as_tensor(edges)
+        if device is None:
+            device = edges.device if edges.is_cuda else util.get_default_device()
+        device = util.require_cuda_device(device)
+        edges = edges.to(device=device, dtype=torch.int64).contiguous()
+        if (edges[:, 0] == edges[:, 1]).any():
+            raise ValueError("Adjacency matrices must not contain self edges")
+        if n_items is None:
+            n_items = int(edges.max().item()) + 1
+        n_items = int(n_items)
+        if weights is None:
+            weights = torch.ones(edges.shape[0], dtype=torch.float32, device=device)
+        else:
+            weights = torch.as_tensor(weights).to(device=device, dtype=torch.float32).contiguous()
+        lo = torch.minimum(edges[:, 0], edges[:, 1])
+        hi = torch.maximum(edges[:, 0], edges[:, 1])
+        key = lo * n_items + hi
+        uniq, inverse = torch.unique(key, sorted=True, return_inverse=True)
+        vals = torch.zeros(uniq.shape[0], dtype=torch.float32, device=device)
+        vals.index_add_(0, inverse, weights)
+        e = torch.stack([uniq // n_items, uniq % n_items], dim=1).contiguous()
+        return Graph(e, vals, n_items)
+
+    @property
+    def weights(self):
+        return self._values
+
+    @property
+    def distances(self):
+        return self._values
+
+    @property
+    def n_edges(self):
+        return int(self.edges.shape[0])
+
+    @property
+    def n_all_edges(self):
+        return self.n_items * (self.n_items - 1) // 2
+
+    def plan(self):
+        if self._plan is None:
+            self._plan = _ad.EdgePlan(self.n_items, self.edges)
+        return self._plan
+
+    def neighbors(self, node):
+        rowptr, nbr, _ = self.plan().csr()
+        return nbr[int(rowptr[node]):int(rowptr[node + 1])].to(torch.int64)
+
+
+def shortest_paths(graph, retain_fraction=1.0, max_length=None, seed=0, verbose=False):
+    """Shortest-path distances between pairs of nodes [ref: graph.py:345-474].
+
+    Every pair at finite positive distance (``<= max_length`` if given) is kept with probability
+    ``retain_fraction``; returns a ``Graph`` whose edges are the kept pairs and whose distances are
+    the path lengths.  Unit-length graphs take the BFS path of the same kernel."""
+    if not isinstance(graph, Graph):
+        raise ValueError("`graph` must be a pymde_amd.Graph instance.")
+    lib = _lib.load()
+    plan = graph.plan()
+    device = plan.device
+    n = graph.n_items
+    unweighted = bool((graph.distances == 1.0).all())
+    w = None if unweighted else plan.expand(graph.distances, 0)
+    frac = min(max(float(retain_fraction), 0.0), 1.0)
+    expected = frac * graph.n_all_edges
+    capacity = int(min(graph.n_all_edges, expected + 8.0 * math.sqrt(max(expected, 1.0)) + 1024))
+    edges = torch.empty((max(capacity, 1), 2), dtype=torch.int64, device=device)
+    dist = torch.empty(max(capacity, 1), dtype=torch.float32, device=device)
+    count = ctypes.c_int64(0)
+    with torch.cuda.device(device):
+        _lib.check(lib.mde_graph_shortest_paths(
+            plan.handle, _lib.ptr(w), float(max_length) if max_length is not None else 0.0,
+            ctypes.c_double(frac if retain_fraction < 1.0 else 1.0),
+            ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), capacity, _lib.ptr(edges), _lib.ptr(dist),
+            ctypes.byref(count), _lib.stream_ptr(device)))
+    m = count.value
+    return Graph(edges[:m], dist[:m], n)

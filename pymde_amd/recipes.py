@@ -3,14 +3,16 @@
 ``preserve_distances`` for data matrices [ref: pymde/recipes.py:103-218,
 pymde/preprocess/data_matrix.py:11-88] is built from the GPU pieces of this package: the edge
 sampler (``preprocess.sample_edges``, row f1) and the edge-order distance kernel with
-``d = n_features`` (``mde_distances``, row f4).  ``preserve_neighbors`` for data matrices [ref: recipes.py:221-448] adds
+``d = n_features`` (``mde_distances``, row f4); graph inputs use the batched shortest-path kernel (``graph.shortest_paths``,
+row f3).  ``preserve_neighbors`` for data matrices [ref: recipes.py:221-448] adds
 the exact GPU k-NN graph (``preprocess.k_nearest_neighbors``, row f2) and the spectral initialiser.
-Graph inputs (shortest-path distances, row f3) are not built yet and say so.
+``preserve_neighbors`` on a graph (shortest-path neighbourhoods) is not built yet and says so.
 """
 import torch
 
 from pymde_amd import _lib
 from pymde_amd import constraints
+from pymde_amd import graph as _graph
 from pymde_amd import preprocess
 from pymde_amd import problem
 from pymde_amd import util
@@ -71,18 +73,20 @@ def preserve_distances(data, embedding_dim=2, loss=losses.Absolute, constraint=N
     (rows = items) [ref: recipes.py:103-218].  At most ``max_distances`` pairs are used, sampled
     uniformly; with ``Standardized()`` the distances are rescaled to the constraint's natural
     length.  Call ``.embed()`` on the result."""
-    if not isinstance(data, torch.Tensor) and not hasattr(data, "shape"):
-        raise ValueError("`data` must be a np.ndarray / torch.Tensor data matrix")
-    if hasattr(data, "edges") and not isinstance(data, torch.Tensor):
-        raise NotImplementedError(
-            "preserve_distances on a graph needs shortest-path distances (SURVEY 8f row f3), which "
-            "this package does not build yet")
-    n_items = int(data.shape[0])
+    is_graph = isinstance(data, _graph.Graph)
+    if not is_graph and not isinstance(data, torch.Tensor) and not hasattr(data, "shape"):
+        raise ValueError("`data` must be a np.ndarray/torch.Tensor data matrix, or a pymde_amd.Graph.")
+    n_items = data.n_items if is_graph else int(data.shape[0])
     n_all_edges = n_items * (n_items - 1) / 2
     retain_fraction = max_distances / n_all_edges
     if verbose:
         problem.LOGGER.info(f"Computing {int(min(max_distances, n_all_edges))} distances")
-    graph = distances(data, retain_fraction=retain_fraction, seed=seed, device=device)
+    if is_graph:
+        # original distance = length of the shortest path between the two nodes (row f3)
+        graph = _graph.shortest_paths(data, retain_fraction=retain_fraction,
+                                      seed=0 if seed is None else seed)
+    else:
+        graph = distances(data, retain_fraction=retain_fraction, seed=seed, device=device)
     edges, deviations = graph.edges, graph.distances
     if constraint is None:
         constraint = constraints.Centered()
