@@ -264,6 +264,10 @@ static int pick_group(float avg_degree) {
     g_group_override = e ? atoi(e) : -1;
   }
   if (g_group_override > 0) return g_group_override;
+  // few, very long rows (dense problems such as all-pairs distance graphs): widen the group so
+  // that the grid still fills the chip
+  if (avg_degree >= 1024.f) return 64;
+  if (avg_degree >= 256.f) return 32;
   if (avg_degree >= 48.f) return 16;
   if (avg_degree >= 20.f) return 8;
   return 4;
