@@ -172,6 +172,9 @@ int mde_plan_expand(const mde_plan* plan, const float* in_edge, float* out_half,
  * Per-edge parameters for layout 1 are permuted with mde_plan_expand_layout and flagged with
  * mde_func.layout = 1.  Negative return: error. */
 int mde_plan_layout(mde_plan* plan, int32_t d, void* stream);
+/* Entries of a per-half-edge parameter array in `layout` (layout 1 pads every per-wave tile
+ * slice to whole 64-entry wave iterations, so it is larger than mde_plan_half_edges). */
+int64_t mde_plan_layout_half_edges(const mde_plan* plan, int32_t layout);
 int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in_edge,
                            float* out_half, void* stream);
 

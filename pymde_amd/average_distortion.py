@@ -80,7 +80,8 @@ class EdgePlan(object):
             raise ValueError(
                 "distortion function has %d parameters but the problem has %d edges"
                 % (t.numel(), self.p))
-        out = torch.empty(max(self.half_edges, 1), dtype=torch.float32, device=self.device)
+        size = int(lib.mde_plan_layout_half_edges(self._handle, int(layout)))
+        out = torch.empty(max(size, 1), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(lib.mde_plan_expand_layout(self._handle, int(layout), _lib.ptr(t),
                                                   _lib.ptr(out), _lib.stream_ptr(self.device)))

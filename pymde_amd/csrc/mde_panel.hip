@@ -10,18 +10,17 @@
 //   * vertices are cut into row blocks (R rows: x_v and the gradient accumulators of the
 //     block live in LDS for the whole kernel) and column panels (C vertices: x_u staged in
 //     LDS, one panel at a time, with coalesced 16-byte loads);
-//   * half-edges are grouped into tiles (row block, panel), sorted by row inside a tile, and
-//     stored as one packed uint32 (row_local << 16 | col_local) + one fp32 parameter: the
-//     same 8 streamed bytes per half-edge as the CSR layout;
-//   * one workgroup owns a row block: it walks the panels, and for each tile streams the
-//     packed half-edges, reads x_v / x_u from LDS, evaluates f and f'/d, and accumulates
-//     g (x_v - x_u) into the block's LDS accumulators with ds_add_f32.  Rows are owned by
-//     exactly one workgroup, so the gradient rows it writes at the end are final: no global
-//     atomics, no partial-gradient pass.
-//
-// The summation order inside a row now depends on LDS atomic arbitration, so results are
-// reproducible to fp32 rounding, not bitwise (the CSR kernel stays bitwise reproducible and is
-// used for everything this layout does not cover).
+//   * half-edges are grouped into tiles (row block, panel), sorted by row inside a tile and
+//     split into 16 per-wave row sub-ranges; every (tile, wave) sub-range is padded to whole
+//     wave iterations (64 entries, dummies at the end) and stored interleaved, so a wave
+//     iteration is one coalesced 256-byte load of packed words + one of parameters;
+//   * a packed word holds the two LDS byte addresses directly (row address << 17 | panel
+//     offset): unpacking is one shift and one mask, the LDS region bases are instruction
+//     immediates;
+//   * one 16-wave workgroup owns a row block and each wave owns a fixed range of its rows: the
+//     accumulator update is a plain LDS read-add-write by the only wave that ever touches that
+//     row -- no atomics anywhere, one writer per gradient row, fixed summation order, so the
+//     result is bitwise reproducible run to run.
 #include <hipcub/hipcub.hpp>
 
 #include "mde_common.h"
@@ -30,7 +29,13 @@
 #define COMMA ,
 
 #define MDE_LDS_BYTES 163840
-#define MDE_PANEL_RESERVE 2048  // reduction scratch + slack
+// Static LDS map (bytes): [0, GR) x_v of the block's rows, [GR, XC) their gradient accumulators,
+// [XC, XC + 96 KiB) the x_u panel.  The region bases are compile-time constants below 2^16 so the
+// kernel's LDS instructions carry them as immediate offsets.
+#define MDE_PANEL_GR_OFF 32752
+#define MDE_PANEL_XC_OFF 65504
+#define MDE_PANEL_XC_BYTES 98304
+#define MDE_PANEL_DUMMY ((uint32_t)MDE_PANEL_GR_OFF << 17)  // padding entry: row address past every real row
 
 // ---------------------------------------------------------------- layout construction
 __global__ __launch_bounds__(MDE_BLOCK) void k_panel_keys(int nrows, const int32_t* __restrict__ rowptr,
@@ -53,24 +58,6 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_panel_keys(int nrows, const int32
   }
 }
 
-__global__ __launch_bounds__(MDE_BLOCK) void k_panel_fill(int64_t H, const uint32_t* __restrict__ keys,
-                                                          const uint32_t* __restrict__ vals,
-                                                          const int32_t* __restrict__ nbr,
-                                                          const int32_t* __restrict__ eid, int P_C,
-                                                          int NP, int KR_shift,
-                                                          uint32_t* __restrict__ packed,
-                                                          int32_t* __restrict__ peid) {
-  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < H;
-       i += (int64_t)gridDim.x * MDE_BLOCK) {
-    const uint32_t key = keys[i], q = vals[i];
-    const uint32_t rl = key & ((1u << KR_shift) - 1u);
-    const uint32_t cp = (key >> KR_shift) % (uint32_t)NP;
-    const uint32_t cl = (uint32_t)nbr[q] - cp * (uint32_t)P_C;
-    packed[i] = (rl << 16) | cl;
-    peid[i] = eid[q];
-  }
-}
-
 // tile_ptr[t] = first sorted position whose tile id (key >> shift) >= t, t = 0..ntiles
 __global__ __launch_bounds__(MDE_BLOCK) void k_tile_ptr(int64_t H, uint32_t ntiles, int shift,
                                                         const uint32_t* __restrict__ keys,
@@ -84,11 +71,14 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_tile_ptr(int64_t H, uint32_t ntil
   }
 }
 
-// sub_ptr[t * NW + w] = first sorted position with key >= (t << shift | w * RW): the rows of a
-// tile are split into NW contiguous ranges, one per wave of the workgroup, so that every
-// accumulator row has exactly one writer (no LDS atomics, fixed summation order).
-__global__ __launch_bounds__(MDE_BLOCK) void k_sub_ptr(int64_t H, uint32_t ntiles, int NW, int RW,
-                                                       int shift, const uint32_t* __restrict__ keys,
+// sub_ptr[t * NW + w]: the row-sorted half-edges of tile t are cut into NW contiguous slices of
+// (nearly) equal length, one per wave of the workgroup, each cut moved forward to the next row
+// boundary so that a row's entries never straddle two waves: inside a tile every accumulator
+// row has exactly one writer (no LDS atomics, fixed summation order), tiles are separated by
+// workgroup barriers, and all waves of a tile run the same number of iterations.
+__global__ __launch_bounds__(MDE_BLOCK) void k_sub_ptr(int64_t H, uint32_t ntiles, int NW,
+                                                       const int32_t* __restrict__ tile_ptr,
+                                                       const uint32_t* __restrict__ keys,
                                                        int32_t* __restrict__ sub_ptr) {
   const int64_t total = (int64_t)ntiles * NW;
   for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i <= total;
@@ -98,46 +88,67 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_sub_ptr(int64_t H, uint32_t ntile
       continue;
     }
     const uint32_t t = (uint32_t)(i / NW), w = (uint32_t)(i % NW);
-    const uint64_t target = ((uint64_t)t << shift) | (uint64_t)(w * (uint32_t)RW);
-    int64_t lo = 0, hi = H;
-    while (lo < hi) {
-      const int64_t mid = (lo + hi) >> 1;
-      if ((uint64_t)keys[mid] >= target)
-        hi = mid;
-      else
-        lo = mid + 1;
-    }
-    sub_ptr[i] = (int32_t)lo;
+    const int64_t beg = tile_ptr[t], end = tile_ptr[t + 1];
+    int64_t pos = beg + ((end - beg) * (int64_t)w) / NW;
+    // (keys inside a tile differ only in the row bits, so equal keys == equal rows)
+    while (pos > beg && pos < end && keys[pos] == keys[pos - 1]) ++pos;
+    sub_ptr[i] = (int32_t)pos;
   }
 }
 
-// Within a (tile, wave) sub-range of m row-sorted half-edges processed in K = ceil(m / 64) wave
-// iterations, store element s at iteration s % K, lane s / K: two half-edges of the same row
-// then share an iteration only when the row has more than K entries in the tile, so the common
-// case needs no run folding at all.  Iteration k owns positions [off(k), off(k) + cnt(k)),
-// cnt(k) = m / K + (k < m % K), off(k) = k * (m / K) + min(k, m % K).
-__global__ __launch_bounds__(MDE_BLOCK) void k_interleave(int64_t nsub, const int32_t* __restrict__ sub_ptr,
-                                                          const uint32_t* __restrict__ keys_in,
-                                                          const uint32_t* __restrict__ vals_in,
-                                                          uint32_t* __restrict__ keys_out,
-                                                          uint32_t* __restrict__ vals_out,
-                                                          int32_t* __restrict__ sub_qr) {
+// next_tile[rb * (NP + 1) + cp] = first non-empty panel >= cp of row block rb (NP if none): the
+// kernel skips empty tiles with one scalar load instead of a search loop
+__global__ __launch_bounds__(MDE_BLOCK) void k_next_tile(int NRB, int NP, const int32_t* __restrict__ tile_ptr,
+                                                         int32_t* __restrict__ next_tile) {
+  const int rb = blockIdx.x * MDE_BLOCK + threadIdx.x;
+  if (rb >= NRB) return;
+  int nxt = NP;
+  next_tile[(size_t)rb * (NP + 1) + NP] = NP;
+  for (int cp = NP - 1; cp >= 0; --cp) {
+    const size_t t = (size_t)rb * NP + cp;
+    if (tile_ptr[t] != tile_ptr[t + 1]) nxt = cp;
+    next_tile[(size_t)rb * (NP + 1) + cp] = nxt;
+  }
+}
+
+// K_i = wave iterations of sub-range i (0 for the extra terminal entry)
+__global__ __launch_bounds__(MDE_BLOCK) void k_sub_iters(int64_t nsub, const int32_t* __restrict__ sub_ptr,
+                                                         int32_t* __restrict__ iters) {
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i <= nsub;
+       i += (int64_t)gridDim.x * MDE_BLOCK)
+    iters[i] = (i < nsub) ? (sub_ptr[i + 1] - sub_ptr[i] + 63) >> 6 : 0;
+}
+
+// A (tile, wave) sub-range of m row-sorted half-edges is processed in K = ceil(m / 64) wave
+// iterations and stored padded to 64 K entries starting at 64 * sub_off: element s sits at
+// iteration s % K, lane s / K, so two half-edges of the same row share an iteration only when
+// the row has more than K entries in the tile (the common case needs no run folding) and the
+// dummies of an iteration are its highest lanes.  The packed word is ready-made LDS addressing:
+// (byte address of the row's slot in the padded row arrays) << 17 | byte offset of x_u in the panel.
+__global__ __launch_bounds__(MDE_BLOCK) void k_panel_pack(int64_t nsub, const int32_t* __restrict__ sub_ptr,
+                                                          const int32_t* __restrict__ sub_off,
+                                                          const uint32_t* __restrict__ keys,
+                                                          const uint32_t* __restrict__ vals,
+                                                          const int32_t* __restrict__ nbr,
+                                                          const int32_t* __restrict__ eid, int P_C, int NP,
+                                                          int KR_shift, int d, uint32_t* __restrict__ packed,
+                                                          int32_t* __restrict__ peid) {
   const int lane = threadIdx.x & 63;
   const int64_t w0 = ((int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * MDE_BLOCK) >> 6;
   for (int64_t i = w0; i < nsub; i += nw) {
     const int beg = sub_ptr[i], m = sub_ptr[i + 1] - beg;
-    if (m <= 0) {
-      if (lane == 0) sub_qr[i] = 0;
-      continue;
-    }
-    const int K = (m + 63) >> 6, q = m / K, rem = m % K;
-    if (lane == 0) sub_qr[i] = (rem << 8) | q;  // the kernel never divides
+    if (m <= 0) continue;
+    const int K = (m + 63) >> 6;
+    const int64_t base = (int64_t)sub_off[i] * 64;
     for (int sidx = lane; sidx < m; sidx += 64) {
-      const int k = sidx % K, l = sidx / K;
-      const int pos = beg + k * q + (k < rem ? k : rem) + l;
-      keys_out[pos] = keys_in[beg + sidx];
-      vals_out[pos] = vals_in[beg + sidx];
+      const uint32_t key = keys[beg + sidx], q = vals[beg + sidx];
+      const uint32_t rl = key & ((1u << KR_shift) - 1u);
+      const uint32_t cp = (key >> KR_shift) % (uint32_t)NP;
+      const uint32_t cl = (uint32_t)nbr[q] - cp * (uint32_t)P_C;
+      const int64_t pos = base + (int64_t)(sidx % K) * 64 + sidx / K;
+      packed[pos] = (((rl + (rl >> 5)) * 4u * (uint32_t)d) << 17) | (cl * 4u * (uint32_t)d);
+      peid[pos] = eid[q];
     }
   }
 }
@@ -163,20 +174,18 @@ static bool choose_sizes(const mde_plan* plan, int d, int* P_R, int* P_C) {
   if (d < 1 || d > 4 || nloc <= 0 || plan->H <= 0) return false;
   const int mode = panel_mode();
   if (mode == 0) return false;
-  // rows: about one block per CU (256), multiple of 64, LDS: 2*d*4 bytes per row, at most
-  // ~40 % of the LDS so the panel keeps the rest
+  // rows: about one block per CU (256), multiple of 64; the padded row array (one spare slot
+  // per 32 rows against bank conflicts) must fit its 32752-byte region
   // (a rank that owns only n/N rows keeps the same block height as a full plan -- tiles must
   // not get thinner -- and fills the CUs with Q column groups per row block instead)
   int64_t pr = (plan->n + 255) / 256;
   if (pr > nloc) pr = nloc;
   pr = ((pr + 63) / 64) * 64;
-  // (rows are padded by one slot per 32 against bank conflicts: 33/32 of the space)
-  const int64_t pr_max = ((int64_t)(0.4 * MDE_LDS_BYTES) / (8 * d)) / 64 * 64;
+  const int64_t pr_max = ((int64_t)(MDE_PANEL_GR_OFF / (4 * d)) * 32 / 33) / 64 * 64;
   if (pr > pr_max) pr = pr_max;
   if (pr < 64) pr = 64;
-  int64_t pc = (MDE_LDS_BYTES - MDE_PANEL_RESERVE - (pr + pr / 32) * 8 * d) / (4 * d);
+  int64_t pc = MDE_PANEL_XC_BYTES / (4 * d);  // = MDE_PANEL_STG float4 per thread
   if (pc > 65535) pc = 65535;
-  if (pc * d > 6 * 1024 * 4) pc = (6 * 1024 * 4) / d;  // MDE_PANEL_STG float4 per thread
   pc = (pc / 256) * 256;
   if (pc < 1024) return false;
   if (pc > plan->n) pc = ((plan->n + 255) / 256) * 256;
@@ -206,7 +215,8 @@ static int build_panels(mde_plan* plan, int d, hipStream_t st) {
   uint32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr;
   void* tmp = nullptr;
   uint32_t* packed = nullptr;
-  int32_t *peid = nullptr, *tile_ptr = nullptr, *sub_ptr = nullptr, *sub_qr = nullptr;
+  int32_t *peid = nullptr, *tile_ptr = nullptr, *sub_ptr = nullptr, *sub_off = nullptr, *iters = nullptr;
+  int32_t* next_tile = nullptr;
   hipError_t e = hipSuccess;
   auto fail = [&](hipError_t err, const char* what) {
     if (keys) (void)hipFree(keys);
@@ -218,10 +228,13 @@ static int build_panels(mde_plan* plan, int d, hipStream_t st) {
     if (peid) (void)hipFree(peid);
     if (tile_ptr) (void)hipFree(tile_ptr);
     if (sub_ptr) (void)hipFree(sub_ptr);
-    if (sub_qr) (void)hipFree(sub_qr);
+    if (sub_off) (void)hipFree(sub_off);
+    if (iters) (void)hipFree(iters);
+    if (next_tile) (void)hipFree(next_tile);
     return mde_hip_fail(err, what, __FILE__, __LINE__);
   };
   const size_t hb = (size_t)H * sizeof(uint32_t);
+  const int64_t nsub = (int64_t)ntiles * MDE_PANEL_WAVES;
 #define PB(call)                                   \
   do {                                             \
     e = (call);                                    \
@@ -231,33 +244,50 @@ static int build_panels(mde_plan* plan, int d, hipStream_t st) {
   PB(hipMalloc(&vals, hb));
   PB(hipMalloc(&keys2, hb));
   PB(hipMalloc(&vals2, hb));
-  PB(hipMalloc(&packed, hb));
-  PB(hipMalloc(&peid, hb));
   PB(hipMalloc(&tile_ptr, ((size_t)ntiles + 1) * sizeof(int32_t)));
-  PB(hipMalloc(&sub_ptr, ((size_t)ntiles * MDE_PANEL_WAVES + 1) * sizeof(int32_t)));
-  PB(hipMalloc(&sub_qr, ((size_t)ntiles * MDE_PANEL_WAVES + 1) * sizeof(int32_t)));
+  PB(hipMalloc(&next_tile, (size_t)NRB * (NP + 1) * sizeof(int32_t)));
+  PB(hipMalloc(&sub_ptr, ((size_t)nsub + 1) * sizeof(int32_t)));
+  PB(hipMalloc(&sub_off, ((size_t)nsub + 1) * sizeof(int32_t)));
+  PB(hipMalloc(&iters, ((size_t)nsub + 1) * sizeof(int32_t)));
   hipLaunchKernelGGL(k_panel_keys, dim3(mde_grid(nloc * 16, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st,
                      (int)nloc, plan->rowptr, plan->nbr, P_R, P_C, NP, KR_shift, keys, vals);
   PB(hipGetLastError());
-  size_t tmp_bytes = 0;
+  size_t tmp_bytes = 0, scan_bytes = 0;
   const int end_bit = bits_for_u64((uint64_t)ntiles) + KR_shift;
   PB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)H, 0,
                                         end_bit > 32 ? 32 : end_bit, st));
+  PB(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, iters, sub_off, (int)(nsub + 1), st));
+  if (scan_bytes > tmp_bytes) tmp_bytes = scan_bytes;
   PB(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
   PB(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)H, 0,
                                         end_bit > 32 ? 32 : end_bit, st));
   hipLaunchKernelGGL(k_tile_ptr, dim3(mde_grid(H + 1, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, H,
                      ntiles, KR_shift, keys2, tile_ptr);
   PB(hipGetLastError());
-  const int64_t nsub = (int64_t)ntiles * MDE_PANEL_WAVES;
+  hipLaunchKernelGGL(k_next_tile, dim3((NRB + MDE_BLOCK - 1) / MDE_BLOCK), dim3(MDE_BLOCK), 0, st, NRB, NP,
+                     tile_ptr, next_tile);
+  PB(hipGetLastError());
   hipLaunchKernelGGL(k_sub_ptr, dim3(mde_grid(nsub + 1, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, H,
-                     ntiles, MDE_PANEL_WAVES, P_R / MDE_PANEL_WAVES, KR_shift, keys2, sub_ptr);
+                     ntiles, MDE_PANEL_WAVES, tile_ptr, keys2, sub_ptr);
   PB(hipGetLastError());
-  hipLaunchKernelGGL(k_interleave, dim3(mde_grid(nsub * 64, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st,
-                     nsub, sub_ptr, keys2, vals2, keys, vals, sub_qr);
+  hipLaunchKernelGGL(k_sub_iters, dim3(mde_grid(nsub + 1, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, nsub,
+                     sub_ptr, iters);
   PB(hipGetLastError());
-  hipLaunchKernelGGL(k_panel_fill, dim3(mde_grid(H, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, H, keys,
-                     vals, plan->nbr, plan->eid, P_C, NP, KR_shift, packed, peid);
+  PB(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, iters, sub_off, (int)(nsub + 1), st));
+  int32_t total_iters = 0;
+  PB(hipMemcpyAsync(&total_iters, sub_off + nsub, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  PB(hipStreamSynchronize(st));
+  const int64_t Hp = (int64_t)total_iters * 64;  // padded half-edge count
+  if (total_iters <= 0 || Hp >= ((int64_t)1 << 31) - 64) {
+    (void)fail(hipSuccess, "panel layout");
+    return 0;  // too large for 32-bit positions: the caller keeps the CSR layout
+  }
+  PB(hipMalloc(&packed, (size_t)Hp * sizeof(uint32_t)));
+  PB(hipMalloc(&peid, (size_t)Hp * sizeof(int32_t)));
+  PB(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(packed), (int)MDE_PANEL_DUMMY, (size_t)Hp, st));
+  PB(hipMemsetAsync(peid, 0xFF, (size_t)Hp * sizeof(int32_t), st));
+  hipLaunchKernelGGL(k_panel_pack, dim3(mde_grid(nsub * 64, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st, nsub,
+                     sub_ptr, sub_off, keys2, vals2, plan->nbr, plan->eid, P_C, NP, KR_shift, d, packed, peid);
   PB(hipGetLastError());
   PB(hipStreamSynchronize(st));
 #undef PB
@@ -266,13 +296,15 @@ static int build_panels(mde_plan* plan, int d, hipStream_t st) {
   (void)hipFree(keys2);
   (void)hipFree(vals2);
   (void)hipFree(tmp);
+  (void)hipFree(sub_ptr);
+  (void)hipFree(iters);
+  (void)hipFree(tile_ptr);
   if (L.packed) (void)hipFree(L.packed);
   if (L.eid) (void)hipFree(L.eid);
-  if (L.tile_ptr) (void)hipFree(L.tile_ptr);
-  if (L.sub_ptr) (void)hipFree(L.sub_ptr);
-  if (L.sub_qr) (void)hipFree(L.sub_qr);
-  L.sub_ptr = sub_ptr;
-  L.sub_qr = sub_qr;
+  if (L.next_tile) (void)hipFree(L.next_tile);
+  if (L.sub_off) (void)hipFree(L.sub_off);
+  L.sub_off = sub_off;
+  L.next_tile = next_tile;
   if (L.partial) (void)hipFree(L.partial);
   L.partial = nullptr;
   // column groups: enough workgroups to fill 256 CUs, at least 4 panels per group
@@ -288,16 +320,14 @@ static int build_panels(mde_plan* plan, int d, hipStream_t st) {
     hipError_t pe = hipMalloc(&L.partial, sizeof(float) * (size_t)Q * (size_t)nloc * (size_t)d);
     if (pe != hipSuccess) return mde_hip_fail(pe, "hipMalloc(panel partials)", __FILE__, __LINE__);
   }
-  L.rows_per_wave = P_R / MDE_PANEL_WAVES;
   L.d = d;
   L.rows_per_block = P_R;
   L.cols_per_panel = P_C;
   L.n_row_blocks = NRB;
   L.n_panels = NP;
-  L.H = H;
+  L.H = Hp;
   L.packed = packed;
   L.eid = peid;
-  L.tile_ptr = tile_ptr;
   return 1;
 }
 
@@ -316,7 +346,13 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_expand_panel(int64_t H, const int
                                                             float* __restrict__ out) {
   for (int64_t q = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; q < H;
        q += (int64_t)gridDim.x * MDE_BLOCK)
-    out[q] = in[eid[q]];
+    out[q] = eid[q] >= 0 ? in[eid[q]] : 1.0f;  // padding entries carry a harmless parameter
+}
+
+// number of entries of a per-half-edge parameter array in the given layout
+extern "C" int64_t mde_plan_layout_half_edges(const mde_plan* plan, int32_t layout) {
+  if (!plan) return 0;
+  return (layout == 1 && plan->panel.packed) ? plan->panel.H : plan->H;
 }
 
 extern "C" int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in_edge,
@@ -327,46 +363,92 @@ extern "C" int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, cons
     mde_set_error("mde_plan_expand_layout: the panel layout has not been built");
     return MDE_E_INVALID;
   }
-  if (plan->H == 0) return MDE_OK;
-  hipLaunchKernelGGL(k_expand_panel, dim3(mde_grid(plan->H, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0,
-                     mde_stream(stream), plan->H, plan->panel.eid, in_edge, out_half);
+  if (plan->panel.H == 0) return MDE_OK;
+  hipLaunchKernelGGL(k_expand_panel, dim3(mde_grid(plan->panel.H, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0,
+                     mde_stream(stream), plan->panel.H, plan->panel.eid, in_edge, out_half);
   MDE_LAUNCH_CHECK();
   return MDE_OK;
 }
 
 // ---------------------------------------------------------------- the kernel
-// 1024 threads = 16 waves per workgroup; wave w owns rows [w * RW, (w+1) * RW) of the block:
-// only it reads-modifies-writes their LDS accumulators, so no atomics are needed and the
-// order of additions is fixed by the (sorted) tile order.  Inside one wave iteration lanes
-// that hit the same row are adjacent (tiles are sorted by row): a segmented Hillis-Steele
-// scan over the lanes (shuffles, early exit when no run is longer than the current stride)
-// folds each run into its last lane, which performs the single read-add-write of that row.
+// 1024 threads = 16 waves per workgroup; inside a tile wave w owns the rows of its slice
+// (k_sub_ptr): only it reads-modifies-writes their LDS accumulators between two workgroup
+// barriers, so no atomics are needed and the order of additions is fixed by the (sorted) tile
+// order.  Inside one wave iteration lanes
+// that hit the same row are adjacent (tiles are sorted by row): when that happens (rare, see
+// k_panel_pack) the contributions are folded into the last lane of each run with DPP wave
+// shifts, and that lane performs the single read-add-write of the row.
 //
 // Software pipeline across tiles: while tile k is processed out of LDS, the x_u panel of tile
-// k+1 (STG float4 per thread) and the wave's packed half-edges + parameters of tile k+1
-// (MAXI registers each) are already in flight from L2 / HBM; they are committed to LDS /
-// consumed after the two barriers that separate the tiles.
+// k+1 (STG float4 per thread) and the wave's packed half-edges + parameters of tile k+1 (MAXI
+// registers each, two register sets used alternately) are already in flight from L2 / HBM; they
+// are committed to LDS / consumed after the two barriers that separate the tiles.
 #define MDE_PANEL_BS (64 * MDE_PANEL_WAVES)
-#define MDE_PANEL_STG (6144 / MDE_PANEL_BS)  // float4 staging registers per thread (panel <= 6144 float4)
-#define MDE_PANEL_MAXI (128 / MDE_PANEL_WAVES)  // prefetched wave-iterations per tile
+#define MDE_PANEL_STG (MDE_PANEL_XC_BYTES / 16 / MDE_PANEL_BS)  // float4 staging registers per thread
+#define MDE_PANEL_MAXI 6  // prefetched wave-iterations per (tile, wave); longer sub-ranges load in place
+
+typedef float panel_f4 __attribute__((ext_vector_type(4)));  // plain vector: no struct copies
+
+template <int D>
+struct PanelVec;
+template <>
+struct PanelVec<1> {
+  typedef float T;
+};
+template <>
+struct PanelVec<2> {
+  typedef float2 T;
+};
+template <>
+struct PanelVec<4> {
+  typedef float4 T;
+};
+// D floats at an LDS byte address (aligned to the vector size for D = 1, 2, 4)
+template <int D>
+__device__ __forceinline__ void panel_ld(const char* p, float (&v)[D]) {
+  if constexpr (D == 3) {
+    const float* q = reinterpret_cast<const float*>(p);
+    v[0] = q[0];
+    v[1] = q[1];
+    v[2] = q[2];
+  } else {
+    const typename PanelVec<D>::T t = *reinterpret_cast<const typename PanelVec<D>::T*>(p);
+    const float* q = reinterpret_cast<const float*>(&t);
+#pragma unroll
+    for (int c = 0; c < D; ++c) v[c] = q[c];
+  }
+}
+template <int D>
+__device__ __forceinline__ void panel_st(char* p, const float (&v)[D]) {
+  if constexpr (D == 3) {
+    float* q = reinterpret_cast<float*>(p);
+    q[0] = v[0];
+    q[1] = v[1];
+    q[2] = v[2];
+  } else {
+    typename PanelVec<D>::T t;
+    float* q = reinterpret_cast<float*>(&t);
+#pragma unroll
+    for (int c = 0; c < D; ++c) q[c] = v[c];
+    *reinterpret_cast<typename PanelVec<D>::T*>(p) = t;
+  }
+}
 
 template <int D, class Fn, bool HAS_GRAD>
 __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
-    int nloc, int row_lo, int n, int P_R, int P_C, int NP, int Q, const int32_t* __restrict__ tile_ptr,
-    const int32_t* __restrict__ sub_ptr, const int32_t* __restrict__ sub_qr,
-    const uint32_t* __restrict__ packed, const float* __restrict__ a0, const float* __restrict__ a1,
-    int a0_scalar, int a1_scalar, const float* __restrict__ X, float* __restrict__ grad,
-    float* __restrict__ partial, double* __restrict__ loss_partials, Fn fn, float inv_p,
-    float grad_scale) {
+    int nloc, int row_lo, int n, int P_R, int P_C, int NP, int Q, const int32_t* __restrict__ next_tile,
+    const int32_t* __restrict__ sub_off, const uint32_t* __restrict__ packed,
+    const float* __restrict__ a0, const float* __restrict__ a1, int a0_scalar, int a1_scalar,
+    const float* __restrict__ X, float* __restrict__ grad, float* __restrict__ partial,
+    double* __restrict__ loss_partials, Fn fn, float inv_p, float grad_scale) {
   constexpr int BS = MDE_PANEL_BS, NW = MDE_PANEL_WAVES, STG = MDE_PANEL_STG, MAXI = MDE_PANEL_MAXI;
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  // row arrays are padded by one slot every 32 rows: interleaved tiles make the lanes of an
-  // iteration touch rows at a near-constant stride, which would otherwise pile onto few banks
-  const int PRP = P_R + (P_R >> 5);
-  float* XR = lds;                 // [PRP * D]  x_v of the block's rows
-  float* GR = XR + PRP * D;        // [PRP * D]  gradient accumulators
-  float* XC = GR + PRP * D;        // [P_C * D]  x_u of the current panel
-  double* red = reinterpret_cast<double*>(XC + (size_t)P_C * D);  // [NW]
+  constexpr int GR_OFF = MDE_PANEL_GR_OFF, XC_OFF = MDE_PANEL_XC_OFF;
+  constexpr uint32_t DUMMY = MDE_PANEL_DUMMY;
+  // statically sized: the LDS addresses unpacked from the stream are absolute
+  __shared__ __attribute__((aligned(16))) char L[MDE_PANEL_XC_OFF + MDE_PANEL_XC_BYTES];
+  float* XR = reinterpret_cast<float*>(L);            // x_v of the block's rows (padded slots)
+  float* GR = reinterpret_cast<float*>(L + GR_OFF);   // gradient accumulators (same slots)
+  float* XC = reinterpret_cast<float*>(L + XC_OFF);   // x_u of the current panel
   const int tid = threadIdx.x, lane = tid & 63;
   const unsigned ulane = (unsigned)lane;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keep it scalar
@@ -379,9 +461,9 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
   const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
   const bool a1_arr = a1 && !a1_scalar;
   const float* Xrow = X + (size_t)(row_lo + r0) * D;
-  for (int i = tid; i < PRP * D; i += BS) {
-    XR[i] = 0.0f;
-    GR[i] = 0.0f;
+  {
+    panel_f4* z = reinterpret_cast<panel_f4*>(L);
+    for (int i = tid; i < XC_OFF / 16; i += BS) z[i] = panel_f4{0.f, 0.f, 0.f, 0.f};
   }
   __syncthreads();
   for (int r = tid; r < nr; r += BS) {
@@ -390,123 +472,93 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
     for (int c = 0; c < D; ++c) XR[slot + c] = Xrow[r * D + c];
   }
   float loss = 0.0f;
-  const int32_t* tp = tile_ptr + (size_t)rb * NP;
-  const int32_t* sp_base = sub_ptr + (size_t)rb * NP * NW + wave;
-  const int32_t* qr_base = sub_qr + (size_t)rb * NP * NW + wave;
+  const int32_t* nt = next_tile + (size_t)rb * (NP + 1);
+  const int32_t* sp_base = sub_off + (size_t)rb * NP * NW + wave;
 
-  // one half-edge per lane, split in two stages so that two iterations can be in flight per wave
-  // (their LDS reads / transcendental chains are independent; only the accumulator updates are
-  // ordered): compute() evaluates, commit() folds runs of equal rows and updates the LDS row.
-  struct Item {
-    int rslot, key;
-    float v[D];
-    bool active;
-  };
-  auto compute = [&](bool active, uint32_t pk, float p0, float p1, Item& it) {
-    const int rl = (int)(pk >> 16), cl = (int)(pk & 0xffffu);
-    it.rslot = (rl + (rl >> 5)) * D;
-    float diff[D], ss = 0.0f;
+  // one wave iteration: 64 packed half-edges (padding entries compute on harmless addresses and
+  // are masked out of the loss and of the accumulator update)
+  auto process = [&](uint32_t pk, float p0, float p1) __attribute__((always_inline)) {
+    const bool active = pk != DUMMY;
+    const uint32_t rowaddr = pk >> 17, coladdr = pk & 0x1ffffu;
+    float xr[D], xc[D], v[D], ss = 0.0f;
+    panel_ld<D>(L + rowaddr, xr);
+    panel_ld<D>(L + XC_OFF + coladdr, xc);
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-      diff[c] = XR[it.rslot + c] - XC[cl * D + c];
-      ss = fmaf(diff[c], diff[c], ss);
+      v[c] = xr[c] - xc[c];
+      ss = fmaf(v[c], v[c], ss);
     }
     float f, gd;
     fn.eval(ss, p0, p1, f, gd);
-    const float g = active ? mde_fix_g(gd * inv_p) : 0.0f;
+    const float g = mde_fix_g(gd * inv_p);
     loss += active ? f : 0.0f;
-#pragma unroll
-    for (int c = 0; c < D; ++c) it.v[c] = g * diff[c];
-    // Lanes of one iteration hold ascending rows (row-sorted tile, interleaved storage), so
-    // equal rows are adjacent lanes.  Inactive lanes carry unique negative keys.
-    it.key = active ? rl : (-2 - lane);
-    it.active = active;
-  };
-  auto commit = [&](Item& it) {
     if (!HAS_GRAD) return;
-    const int key = it.key;
-    bool tail = it.active;
+#pragma unroll
+    for (int c = 0; c < D; ++c) v[c] *= g;
+    // Lanes of one iteration hold ascending rows (row-sorted tile, interleaved storage), so equal
+    // rows are adjacent lanes; padding lanes are the highest ones.
+    const int key = (int)rowaddr;
+    bool tail = active;
     const int kprev = __builtin_amdgcn_update_dpp(-1, key, 0x138, 0xf, 0xf, false);  // wave_shr:1
-    if (__any(kprev == key)) {
+    if (__any(kprev == key && active)) {
       // rare: a row has more entries in this tile than the wave has iterations.  Round r adds
       // the ORIGINAL contribution of lane i-r when it has the same row (keys / values shifted
       // one lane per round with DPP wave_shr); the last lane of each run writes.
       int kc = key;
       float sv[D];
 #pragma unroll
-      for (int c = 0; c < D; ++c) sv[c] = it.v[c];
+      for (int c = 0; c < D; ++c) sv[c] = v[c];
 #pragma nounroll
       for (int r = 1; r < 64; ++r) {
         kc = __builtin_amdgcn_update_dpp(-1, kc, 0x138, 0xf, 0xf, false);
         const bool m = (kc == key);
-        if (!__any(m)) break;
+        if (!__any(m && active)) break;
 #pragma unroll
         for (int c = 0; c < D; ++c) {
           sv[c] = __int_as_float(
               __builtin_amdgcn_update_dpp(0, __float_as_int(sv[c]), 0x138, 0xf, 0xf, false));
-          it.v[c] += m ? sv[c] : 0.0f;
+          v[c] += m ? sv[c] : 0.0f;
         }
       }
       const int knext = __builtin_amdgcn_update_dpp(-1, key, 0x130, 0xf, 0xf, false);  // wave_shl:1
-      tail = it.active && (knext != key);
+      tail = active && (knext != key);
     }
     if (tail) {
+      float acc[D];
+      panel_ld<D>(L + GR_OFF + rowaddr, acc);
 #pragma unroll
-      for (int c = 0; c < D; ++c) GR[it.rslot + c] += it.v[c];
+      for (int c = 0; c < D; ++c) acc[c] += v[c];
+      panel_st<D>(L + GR_OFF + rowaddr, acc);
     }
   };
 
-  float4 stg[STG];
-  uint32_t pkn[MAXI];
-  float wn[MAXI];
-  int nbeg = 0, nm = 0, nq = 0, nrem = 0;  // next tile's sub-range: start, size, m / K, m % K
-  // issue every global load of tile `cp` (panel -> staging registers, stream -> pkn / wn)
-  auto prefetch = [&](int cp) {
+  panel_f4 stg[STG];
+  // issue the global loads of panel `cp` into the staging registers.  Exactly STG loads on every
+  // path (indices clamped instead of predicated): the compiler's vmcnt bookkeeping must not depend
+  // on the path taken, or it falls back to waiting for loads that were only just issued.
+  auto load_panel = [&](int cp) __attribute__((always_inline)) {
     const int c0 = cp * P_C;
     const int nc = min(P_C, n - c0);
     const int t4 = (nc * D) >> 2;  // c0 * D * 4 bytes is 16-byte aligned (P_C multiple of 256)
-    const float4* s4 = reinterpret_cast<const float4*>(X + (size_t)c0 * D);
+    const panel_f4* s4 = reinterpret_cast<const panel_f4*>(X + (size_t)c0 * D);
+    if (t4 == STG * BS) {
 #pragma unroll
-    for (int k = 0; k < STG; ++k) {
-      const int i = tid + k * BS;
-      stg[k] = (i < t4) ? s4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const int32_t* sp = sp_base + (size_t)cp * NW;
-    nbeg = __builtin_amdgcn_readfirstlane(sp[0]);
-    nm = __builtin_amdgcn_readfirstlane(sp[1]) - nbeg;
-    const int qr = __builtin_amdgcn_readfirstlane(qr_base[(size_t)cp * NW]);
-    nq = qr & 255;
-    nrem = qr >> 8;
-    // interleaved order (k_interleave): iteration k holds cnt(k) = q + (k < rem) entries
-    const int K = (nm + 63) >> 6;
-    const uint32_t* pb = packed + nbeg;  // wave-uniform bases: scalar address arithmetic
-    const float* ab = a0 + nbeg;
-    int off = 0;
+      for (int k = 0; k < STG; ++k) stg[k] = s4[tid + k * BS];
+    } else {
+      const int last = t4 > 0 ? t4 - 1 : 0;  // (a panel always has >= 4 floats unless n * D < 4)
 #pragma unroll
-    for (int k = 0; k < MAXI; ++k) {
-      const int cnt = (k < K) ? nq + (k < nrem ? 1 : 0) : 0;
-      const bool ok = lane < cnt;
-      const uint32_t* pbo = pb + off;  // uniform: scalar base, the vector offset is just the lane
-      const float* abo = ab + off;
-      pkn[k] = ok ? pbo[ulane] : 0u;
-      wn[k] = (ok && !a0_scalar) ? abo[ulane] : a0s;
-      off += cnt;
+      for (int k = 0; k < STG; ++k) stg[k] = s4[min(tid + k * BS, last)];
     }
   };
-  auto next_nonempty = [&](int cp) {
-    while (cp < cp_hi && tp[cp] == tp[cp + 1]) ++cp;
-    return cp;
-  };
-
-  int cp = next_nonempty(cp_lo);
-  if (cp < cp_hi) prefetch(cp);
-  while (cp < cp_hi) {
+  auto store_panel = [&](int cp) __attribute__((always_inline)) {
     const int c0 = cp * P_C;
     const int nc = min(P_C, n - c0);
-    __syncthreads();  // everyone is done with the previous panel (and XR/GR are initialised)
-    {
-      float4* d4 = reinterpret_cast<float4*>(XC);
-      const int t4 = (nc * D) >> 2;
+    const int t4 = (nc * D) >> 2;
+    panel_f4* d4 = reinterpret_cast<panel_f4*>(XC);
+    if (t4 == STG * BS) {
+#pragma unroll
+      for (int k = 0; k < STG; ++k) d4[tid + k * BS] = stg[k];
+    } else {
 #pragma unroll
       for (int k = 0; k < STG; ++k) {
         const int i = tid + k * BS;
@@ -515,48 +567,92 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
       const float* src = X + (size_t)c0 * D;
       for (int i = (t4 << 2) + tid; i < nc * D; i += BS) XC[i] = src[i];  // < 4 tail floats
     }
-    // this tile's stream registers
-    uint32_t pkc[MAXI];
-    float wc[MAXI];
+  };
+  // issue the loads of this wave's stream of tile `cp`: K wave iterations starting at iteration
+  // b.  All MAXI loads are always issued (indices clamped into the sub-range) so that the
+  // compiler's wait counts stay exact; iterations >= K are never consumed.
+  const unsigned wlane = a0_scalar ? 0u : ulane;
+  const int wstride = a0_scalar ? 0 : 64;
+  auto load_stream = [&](int cp, uint32_t (&pn)[MAXI], float (&wn)[MAXI], int& K, int& b)
+                         __attribute__((always_inline)) {
+    const int32_t* sp = sp_base + (size_t)cp * NW;
+    b = __builtin_amdgcn_readfirstlane(sp[0]);
+    K = __builtin_amdgcn_readfirstlane(sp[1]) - b;
+    const int bb = K > 0 ? b : 0, kmax = K > 0 ? K - 1 : 0;
+    const uint32_t* pb = packed + (size_t)bb * 64;
+    const float* ab = a0 + (size_t)bb * wstride;
 #pragma unroll
     for (int k = 0; k < MAXI; ++k) {
-      pkc[k] = pkn[k];
-      wc[k] = wn[k];
+      const int kk = min(k, kmax);  // wave-uniform: scalar base + the lane as the only vector offset
+      pn[k] = (pb + (size_t)kk * 64)[ulane];
+      wn[k] = (ab + (size_t)kk * wstride)[wlane];
     }
-    const int cbeg = nbeg, cm = nm, cq = nq, crem = nrem;
-    const int cK = (cm + 63) >> 6;
+  };
+  auto next_nonempty = [&](int cp) __attribute__((always_inline)) {  // cp <= NP
+    return __builtin_amdgcn_readfirstlane(nt[cp]);
+  };
+  // one tile: commit its panel, then process the stream while the loads of the next non-empty
+  // tile are issued a few per wave iteration (issuing all 18 right after the barrier makes the 16
+  // waves queue on the CU's single address unit while no wave computes).  After the last tile the
+  // same tile is reloaded, so the number of loads issued does not depend on the path.
+  auto tile_step = [&](int cp, const uint32_t (&pc)[MAXI], const float (&wc)[MAXI], int cK, int cb,
+                       uint32_t (&pn)[MAXI], float (&wn)[MAXI], int& nK, int& nb)
+                       __attribute__((always_inline)) {
+    __syncthreads();  // everyone is done with the previous panel (and XR/GR are initialised)
+    store_panel(cp);
     __syncthreads();
     const int cpn = next_nonempty(cp + 1);
-    if (cpn < cp_hi) prefetch(cpn);  // in flight while this tile is processed
-    int off = 0;
+    const int cpl = cpn < cp_hi ? cpn : cp;
+    // next panel: STG loads, clamped (not predicated) when the panel is the short last one
+    const int c0 = cpl * P_C;
+    const int t4 = (min(P_C, n - c0) * D) >> 2;
+    const int last = t4 > 0 ? t4 - 1 : 0;
+    const bool full = t4 == STG * BS;
+    const panel_f4* s4 = reinterpret_cast<const panel_f4*>(X + (size_t)c0 * D);
+    // next stream slice of this wave
+    const int32_t* sp = sp_base + (size_t)cpl * NW;
+    nb = __builtin_amdgcn_readfirstlane(sp[0]);
+    nK = __builtin_amdgcn_readfirstlane(sp[1]) - nb;
+    const int bb = nK > 0 ? nb : 0, kmax = nK > 0 ? nK - 1 : 0;
+    const uint32_t* pb = packed + (size_t)bb * 64;
+    const float* ab = a0 + (size_t)bb * wstride;
+    constexpr int PPS = (STG + 2) / 3;  // panel loads per slot: all issued in the first 3 slots
 #pragma unroll
-    for (int k = 0; k < MAXI; k += 2) {
-      if (k >= cK) break;
-      const int cnt0 = cq + (k < crem ? 1 : 0);
-      const int cnt1 = (k + 1 < cK) ? cq + (k + 1 < crem ? 1 : 0) : 0;
-      const bool act0 = lane < cnt0, act1 = lane < cnt1;
-      const float p10 = a1_arr ? (act0 ? a1[cbeg + off + lane] : 1.0f) : a1s;
-      const float p11 = a1_arr ? (act1 ? a1[cbeg + off + cnt0 + lane] : 1.0f) : a1s;
-      Item ia, ib;
-      compute(act0, pkc[k], wc[k], p10, ia);
-      compute(act1, pkc[k + 1], wc[k + 1], p11, ib);
-      commit(ia);
-      commit(ib);
-      off += cnt0 + cnt1;
+    for (int k = 0; k < MAXI; ++k) {
+#pragma unroll
+      for (int j = k * PPS; j < (k + 1) * PPS && j < STG; ++j)
+        stg[j] = full ? s4[tid + j * BS] : s4[min(tid + j * BS, last)];
+      {
+        const int kk = min(k, kmax);  // wave-uniform: scalar base + the lane as the only vector offset
+        pn[k] = (pb + (size_t)kk * 64)[ulane];
+        wn[k] = (ab + (size_t)kk * wstride)[wlane];
+      }
+      if (k < cK) {
+        const float p1 = a1_arr ? a1[(size_t)(cb + k) * 64 + ulane] : a1s;
+        process(pc[k], wc[k], p1);
+      }
     }
-    for (int k = MAXI; k < cK; ++k) {  // oversized tiles (skewed degrees): not prefetched
-      const int cnt = cq + (k < crem ? 1 : 0);
-      const int h = cbeg + off + lane;
-      const bool active = lane < cnt;
-      const uint32_t pk = active ? packed[h] : 0u;
-      const float p0 = (active && !a0_scalar) ? a0[h] : a0s;
-      const float p1 = a1_arr ? (active ? a1[h] : 1.0f) : a1s;
-      Item it;
-      compute(active, pk, p0, p1, it);
-      commit(it);
-      off += cnt;
+    for (int k = MAXI; k < cK; ++k) {  // oversized slices (skewed degrees): not prefetched
+      const size_t h = (size_t)(cb + k) * 64 + ulane;
+      const float p0 = a0_scalar ? a0s : a0[h];
+      const float p1 = a1_arr ? a1[h] : a1s;
+      process(packed[h], p0, p1);
     }
-    cp = cpn;
+    return cpn;
+  };
+
+  uint32_t pkA[MAXI], pkB[MAXI];
+  float wA[MAXI], wB[MAXI];
+  int KA = 0, bA = 0, KB = 0, bB = 0;
+  int cp = next_nonempty(cp_lo);
+  if (cp < cp_hi) {
+    load_panel(cp);
+    load_stream(cp, pkA, wA, KA, bA);
+    do {
+      cp = tile_step(cp, pkA, wA, KA, bA, pkB, wB, KB, bB);
+      if (cp >= cp_hi) break;
+      cp = tile_step(cp, pkB, wB, KB, bB, pkA, wA, KA, bA);
+    } while (cp < cp_hi);
   }
   __syncthreads();
   if (HAS_GRAD) {
@@ -570,8 +666,9 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
       for (int c = 0; c < D; ++c) grow[r * D + c] = GR[slot + c] * sc;
     }
   }
-  // block-wide loss partial
-  double v = mde_wave_sum((double)loss);
+  // block-wide loss partial (the x_v region is free now)
+  double* red = reinterpret_cast<double*>(L);
+  const double v = mde_wave_sum((double)loss);
   if (lane == 0) red[wave] = v;
   __syncthreads();
   if (tid == 0) {
@@ -606,23 +703,12 @@ struct PanelArgs {
 template <int D, class Fn>
 static int launch_panel(const PanelArgs& A, const Fn& fn, int* nblocks) {
   const mde_panel_layout& L = A.plan->panel;
-  const size_t prp = (size_t)L.rows_per_block + (size_t)(L.rows_per_block >> 5);
-  const size_t lds = (prp * 2 * D + (size_t)L.cols_per_panel * D) * sizeof(float) +
-                     MDE_PANEL_WAVES * sizeof(double) + 64;
-  static bool attr_set = false;
   auto kern = A.grad ? k_fused_panel<D, Fn, true> : k_fused_panel<D, Fn, false>;
-  static bool attr_set_fwd = false;
-  bool& attr_done = A.grad ? attr_set : attr_set_fwd;
-  if (!attr_done) {
-    MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, MDE_LDS_BYTES));
-    attr_done = true;
-  }
   const int Q = L.col_groups;
   *nblocks = L.n_row_blocks * Q;
-  hipLaunchKernelGGL(kern, dim3(L.n_row_blocks * Q), dim3(MDE_PANEL_BS), lds, A.st,
+  hipLaunchKernelGGL(kern, dim3(L.n_row_blocks * Q), dim3(MDE_PANEL_BS), 0, A.st,
                      (int)(A.plan->row_hi - A.plan->row_lo), (int)A.plan->row_lo, (int)A.plan->n,
-                     L.rows_per_block, L.cols_per_panel, L.n_panels, Q, L.tile_ptr, L.sub_ptr, L.sub_qr, L.packed,
+                     L.rows_per_block, L.cols_per_panel, L.n_panels, Q, L.next_tile, L.sub_off, L.packed,
                      A.a0, A.a1, A.a0_scalar, A.a1_scalar, A.X, A.grad, L.partial, A.plan->partials, fn,
                      A.inv_p, A.grad_scale);
   MDE_LAUNCH_CHECK();

@@ -12,13 +12,12 @@ struct mde_panel_layout {
   int d = 0;            // embedding dimension the tile sizes were chosen for
   int rows_per_block = 0, cols_per_panel = 0;
   int n_row_blocks = 0, n_panels = 0;
-  int64_t H = 0;
-  uint32_t* packed = nullptr;   // [H] (row_local << 16) | col_local
-  int32_t* eid = nullptr;       // [H] original edge id (parameter expansion)
-  int32_t* tile_ptr = nullptr;  // [n_row_blocks * n_panels + 1]
-  int32_t* sub_ptr = nullptr;   // [n_tiles * MDE_PANEL_WAVES + 1] per-wave row sub-ranges of a tile
-  int32_t* sub_qr = nullptr;    // [n_tiles * MDE_PANEL_WAVES] (m % K) << 8 | (m / K), K = ceil(m / 64)
-  int rows_per_wave = 0;
+  int64_t H = 0;                // padded entry count: 64 * (wave iterations of all sub-ranges)
+  uint32_t* packed = nullptr;   // [H] LDS row address << 17 | LDS panel offset (padding: MDE_PANEL_DUMMY)
+  int32_t* eid = nullptr;       // [H] original edge id (parameter expansion), -1 for padding
+  int32_t* next_tile = nullptr; // [n_row_blocks * (n_panels + 1)] first non-empty panel >= cp of a row block
+  int32_t* sub_off = nullptr;   // [n_tiles * MDE_PANEL_WAVES + 1] first wave iteration of each
+                                // (tile, wave) sub-range; entries [64 * sub_off[i], 64 * sub_off[i+1])
   int col_groups = 1;           // Q: workgroups per row block, each walking 1/Q of the panels
   float* partial = nullptr;     // [Q * nloc * d] per-group gradient partials (Q > 1 only)
 };

@@ -56,9 +56,8 @@ extern "C" int mde_plan_destroy(mde_plan* plan) {
   if (plan->partials) (void)hipFree(plan->partials);
   if (plan->panel.packed) (void)hipFree(plan->panel.packed);
   if (plan->panel.eid) (void)hipFree(plan->panel.eid);
-  if (plan->panel.tile_ptr) (void)hipFree(plan->panel.tile_ptr);
-  if (plan->panel.sub_ptr) (void)hipFree(plan->panel.sub_ptr);
-  if (plan->panel.sub_qr) (void)hipFree(plan->panel.sub_qr);
+  if (plan->panel.next_tile) (void)hipFree(plan->panel.next_tile);
+  if (plan->panel.sub_off) (void)hipFree(plan->panel.sub_off);
   if (plan->panel.partial) (void)hipFree(plan->panel.partial);
   delete plan;
   return MDE_OK;

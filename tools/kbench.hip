@@ -146,7 +146,6 @@ int main(int argc, char** argv) {
   float *w, *wh, *X, *grad, *loss;
   CK(hipMalloc(&edges, p * 16));
   CK(hipMalloc(&w, p * 4));
-  CK(hipMalloc(&wh, 2 * p * 4));
   CK(hipMalloc(&X, n * 2 * 4));
   CK(hipMalloc(&grad, n * 2 * 4));
   CK(hipMalloc(&loss, 64));
@@ -176,6 +175,9 @@ int main(int argc, char** argv) {
   CK(hipEventElapsedTime(&ms, a2, b2));
   printf("layout=%d (0 CSR, 1 LDS column panels) layout_build_ms=%.2f\n", layout, ms);
   if (layout < 0) { printf("layout error %s\n", mde_last_error()); return 1; }
+  const int64_t Hl = mde_plan_layout_half_edges(plan, layout);
+  printf("layout entries %lld (%.1f%% padding)\n", (long long)Hl, 100.0 * (Hl - H) / (double)H);
+  CK(hipMalloc(&wh, (size_t)Hl * 4));
   MK(mde_plan_expand_layout(plan, layout, w, wh, st));
 
   const double alg_bytes = 12.0 * p + 2.0 * n * 2 * 4;  // 8 + 4 B/edge + X read + grad write
