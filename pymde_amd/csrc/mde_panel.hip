@@ -379,10 +379,7 @@ extern "C" int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, cons
 // k_panel_pack) the contributions are folded into the last lane of each run with DPP wave
 // shifts, and that lane performs the single read-add-write of the row.
 //
-// Software pipeline across tiles: while tile k is processed out of LDS, the x_u panel of tile
-// k+1 (STG float4 per thread) and the wave's packed half-edges + parameters of tile k+1 (MAXI
-// registers each, two register sets used alternately) are already in flight from L2 / HBM; they
-// are committed to LDS / consumed after the two barriers that separate the tiles.
+// The software pipeline across tiles is described at the staging registers below.
 #define MDE_PANEL_BS (64 * MDE_PANEL_WAVES)
 #define MDE_PANEL_STG (MDE_PANEL_XC_BYTES / 16 / MDE_PANEL_BS)  // float4 staging registers per thread
 #define MDE_PANEL_MAXI 6  // prefetched wave-iterations per (tile, wave); longer sub-ranges load in place
@@ -532,25 +529,43 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
     }
   };
 
-  panel_f4 stg[STG];
-  // issue the global loads of panel `cp` into the staging registers.  Exactly STG loads on every
-  // path (indices clamped instead of predicated): the compiler's vmcnt bookkeeping must not depend
-  // on the path taken, or it falls back to waiting for loads that were only just issued.
-  auto load_panel = [&](int cp) __attribute__((always_inline)) {
-    const int c0 = cp * P_C;
-    const int nc = min(P_C, n - c0);
-    const int t4 = (nc * D) >> 2;  // c0 * D * 4 bytes is 16-byte aligned (P_C multiple of 256)
-    const panel_f4* s4 = reinterpret_cast<const panel_f4*>(X + (size_t)c0 * D);
-    if (t4 == STG * BS) {
-#pragma unroll
-      for (int k = 0; k < STG; ++k) stg[k] = s4[tid + k * BS];
-    } else {
-      const int last = t4 > 0 ? t4 - 1 : 0;  // (a panel always has >= 4 floats unless n * D < 4)
-#pragma unroll
-      for (int k = 0; k < STG; ++k) stg[k] = s4[min(tid + k * BS, last)];
-    }
+  // Pipeline across tiles (all loads are unconditional and clamped, never predicated, so that the
+  // compiler's vmcnt bookkeeping is exact on every path and no wait covers a load just issued):
+  //   * x_u panels are prefetched TWO tiles ahead through two sets of staging registers: while tile
+  //     t is processed out of LDS, panel t+1 already sits in one set and panel t+2 is being loaded
+  //     into the set that tile t's commit has just freed -- a full tile of slack for the L2 / fabric
+  //     latency;
+  //   * the wave's stream registers are refilled in place: right after wave iteration k of tile t
+  //     has consumed its packed word and parameter, the same registers receive iteration k of tile
+  //     t+1;
+  //   * loads are issued a few per wave iteration instead of in one burst after the barrier (the
+  //     16 waves would otherwise queue on the CU's single address unit while nobody computes).
+  panel_f4 stgA[STG], stgB[STG];
+  uint32_t pk[MAXI];
+  float wv[MAXI];
+  const unsigned wlane = a0_scalar ? 0u : ulane;
+  const int wstride = a0_scalar ? 0 : 64;
+  struct PanelSrc {
+    const panel_f4* s4;
+    int last;
+    bool full;
   };
-  auto store_panel = [&](int cp) __attribute__((always_inline)) {
+  auto panel_src = [&](int cp) __attribute__((always_inline)) {
+    const int c0 = cp * P_C;
+    const int t4 = (min(P_C, n - c0) * D) >> 2;  // c0 * D * 4 bytes is 16-byte aligned (P_C multiple of 256)
+    PanelSrc r;
+    r.s4 = reinterpret_cast<const panel_f4*>(X + (size_t)c0 * D);
+    r.last = t4 > 0 ? t4 - 1 : 0;
+    r.full = t4 == STG * BS;
+    return r;
+  };
+  auto load_panel_part = [&](const PanelSrc& src, panel_f4 (&stg)[STG], int j0, int j1)
+                             __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = j0; j < j1 && j < STG; ++j)
+      stg[j] = src.full ? src.s4[tid + j * BS] : src.s4[min(tid + j * BS, src.last)];
+  };
+  auto store_panel = [&](int cp, const panel_f4 (&stg)[STG]) __attribute__((always_inline)) {
     const int c0 = cp * P_C;
     const int nc = min(P_C, n - c0);
     const int t4 = (nc * D) >> 2;
@@ -568,69 +583,53 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
       for (int i = (t4 << 2) + tid; i < nc * D; i += BS) XC[i] = src[i];  // < 4 tail floats
     }
   };
-  // issue the loads of this wave's stream of tile `cp`: K wave iterations starting at iteration
-  // b.  All MAXI loads are always issued (indices clamped into the sub-range) so that the
-  // compiler's wait counts stay exact; iterations >= K are never consumed.
-  const unsigned wlane = a0_scalar ? 0u : ulane;
-  const int wstride = a0_scalar ? 0 : 64;
-  auto load_stream = [&](int cp, uint32_t (&pn)[MAXI], float (&wn)[MAXI], int& K, int& b)
-                         __attribute__((always_inline)) {
+  struct StreamSrc {
+    const uint32_t* pb;
+    const float* ab;
+    int K, b, kmax;
+  };
+  auto stream_src = [&](int cp) __attribute__((always_inline)) {
     const int32_t* sp = sp_base + (size_t)cp * NW;
-    b = __builtin_amdgcn_readfirstlane(sp[0]);
-    K = __builtin_amdgcn_readfirstlane(sp[1]) - b;
-    const int bb = K > 0 ? b : 0, kmax = K > 0 ? K - 1 : 0;
-    const uint32_t* pb = packed + (size_t)bb * 64;
-    const float* ab = a0 + (size_t)bb * wstride;
-#pragma unroll
-    for (int k = 0; k < MAXI; ++k) {
-      const int kk = min(k, kmax);  // wave-uniform: scalar base + the lane as the only vector offset
-      pn[k] = (pb + (size_t)kk * 64)[ulane];
-      wn[k] = (ab + (size_t)kk * wstride)[wlane];
-    }
+    StreamSrc r;
+    r.b = __builtin_amdgcn_readfirstlane(sp[0]);
+    r.K = __builtin_amdgcn_readfirstlane(sp[1]) - r.b;
+    const int bb = r.K > 0 ? r.b : 0;
+    r.kmax = r.K > 0 ? r.K - 1 : 0;
+    r.pb = packed + (size_t)bb * 64;
+    r.ab = a0 + (size_t)bb * wstride;
+    return r;
+  };
+  // slot k of the stream of a tile (index clamped into the slice: slots >= K are never consumed)
+  auto load_stream_slot = [&](const StreamSrc& src, int k) __attribute__((always_inline)) {
+    const int kk = min(k, src.kmax);  // wave-uniform: scalar base + the lane as the only vector offset
+    pk[k] = (src.pb + (size_t)kk * 64)[ulane];
+    wv[k] = (src.ab + (size_t)kk * wstride)[wlane];
   };
   auto next_nonempty = [&](int cp) __attribute__((always_inline)) {  // cp <= NP
     return __builtin_amdgcn_readfirstlane(nt[cp]);
   };
-  // one tile: commit its panel, then process the stream while the loads of the next non-empty
-  // tile are issued a few per wave iteration (issuing all 18 right after the barrier makes the 16
-  // waves queue on the CU's single address unit while no wave computes).  After the last tile the
-  // same tile is reloaded, so the number of loads issued does not depend on the path.
-  auto tile_step = [&](int cp, const uint32_t (&pc)[MAXI], const float (&wc)[MAXI], int cK, int cb,
-                       uint32_t (&pn)[MAXI], float (&wn)[MAXI], int& nK, int& nb)
+  // One tile.  cp: this tile (panel in `scur`), cpn: the next one (panel already in the other
+  // set; may be >= cp_hi).  Loads panel cpn2 (the tile after cpn) into `scur` once it is free.
+  auto tile_step = [&](int cp, int cpn, int cK, int cb, panel_f4 (&scur)[STG], int& nK, int& nb)
                        __attribute__((always_inline)) {
     __syncthreads();  // everyone is done with the previous panel (and XR/GR are initialised)
-    store_panel(cp);
+    store_panel(cp, scur);
     __syncthreads();
-    const int cpn = next_nonempty(cp + 1);
-    const int cpl = cpn < cp_hi ? cpn : cp;
-    // next panel: STG loads, clamped (not predicated) when the panel is the short last one
-    const int c0 = cpl * P_C;
-    const int t4 = (min(P_C, n - c0) * D) >> 2;
-    const int last = t4 > 0 ? t4 - 1 : 0;
-    const bool full = t4 == STG * BS;
-    const panel_f4* s4 = reinterpret_cast<const panel_f4*>(X + (size_t)c0 * D);
-    // next stream slice of this wave
-    const int32_t* sp = sp_base + (size_t)cpl * NW;
-    nb = __builtin_amdgcn_readfirstlane(sp[0]);
-    nK = __builtin_amdgcn_readfirstlane(sp[1]) - nb;
-    const int bb = nK > 0 ? nb : 0, kmax = nK > 0 ? nK - 1 : 0;
-    const uint32_t* pb = packed + (size_t)bb * 64;
-    const float* ab = a0 + (size_t)bb * wstride;
+    const int cpn2 = cpn < cp_hi ? next_nonempty(cpn + 1) : cpn;
+    // past the end: redundant reloads of this tile keep the number of loads path-independent
+    const PanelSrc psrc = panel_src(cpn2 < cp_hi ? cpn2 : cp);
+    const StreamSrc ssrc = stream_src(cpn < cp_hi ? cpn : cp);
+    nK = ssrc.K;
+    nb = ssrc.b;
     constexpr int PPS = (STG + 2) / 3;  // panel loads per slot: all issued in the first 3 slots
 #pragma unroll
     for (int k = 0; k < MAXI; ++k) {
-#pragma unroll
-      for (int j = k * PPS; j < (k + 1) * PPS && j < STG; ++j)
-        stg[j] = full ? s4[tid + j * BS] : s4[min(tid + j * BS, last)];
-      {
-        const int kk = min(k, kmax);  // wave-uniform: scalar base + the lane as the only vector offset
-        pn[k] = (pb + (size_t)kk * 64)[ulane];
-        wn[k] = (ab + (size_t)kk * wstride)[wlane];
-      }
+      load_panel_part(psrc, scur, k * PPS, (k + 1) * PPS);
       if (k < cK) {
         const float p1 = a1_arr ? a1[(size_t)(cb + k) * 64 + ulane] : a1s;
-        process(pc[k], wc[k], p1);
+        process(pk[k], wv[k], p1);
       }
+      load_stream_slot(ssrc, k);
     }
     for (int k = MAXI; k < cK; ++k) {  // oversized slices (skewed degrees): not prefetched
       const size_t h = (size_t)(cb + k) * 64 + ulane;
@@ -638,21 +637,33 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
       const float p1 = a1_arr ? a1[h] : a1s;
       process(packed[h], p0, p1);
     }
-    return cpn;
+    return cpn2;
   };
 
-  uint32_t pkA[MAXI], pkB[MAXI];
-  float wA[MAXI], wB[MAXI];
-  int KA = 0, bA = 0, KB = 0, bB = 0;
   int cp = next_nonempty(cp_lo);
   if (cp < cp_hi) {
-    load_panel(cp);
-    load_stream(cp, pkA, wA, KA, bA);
-    do {
-      cp = tile_step(cp, pkA, wA, KA, bA, pkB, wB, KB, bB);
+    int cpn = next_nonempty(cp + 1);
+    int cK, cb, nK = 0, nb = 0;
+    {
+      load_panel_part(panel_src(cp), stgA, 0, STG);
+      load_panel_part(panel_src(cpn < cp_hi ? cpn : cp), stgB, 0, STG);
+      const StreamSrc s0 = stream_src(cp);
+      cK = s0.K;
+      cb = s0.b;
+#pragma unroll
+      for (int k = 0; k < MAXI; ++k) load_stream_slot(s0, k);
+    }
+    // the first tile is peeled so that the loop is entered in the steady state of the pipeline
+    // (same loads in flight as after any other tile: exact wait counts inside the loop)
+    int cpn2 = tile_step(cp, cpn, cK, cb, stgA, nK, nb);
+    cp = cpn, cpn = cpn2, cK = nK, cb = nb;
+    while (cp < cp_hi) {
+      cpn2 = tile_step(cp, cpn, cK, cb, stgB, nK, nb);
+      cp = cpn, cpn = cpn2, cK = nK, cb = nb;
       if (cp >= cp_hi) break;
-      cp = tile_step(cp, pkB, wB, KB, bB, pkA, wA, KA, bA);
-    } while (cp < cp_hi);
+      cpn2 = tile_step(cp, cpn, cK, cb, stgA, nK, nb);
+      cp = cpn, cpn = cpn2, cK = nK, cb = nb;
+    }
   }
   __syncthreads();
   if (HAS_GRAD) {
