@@ -36,7 +36,7 @@ ALG_BYTES_PER_EDGE = 8 + 4      # two int32 endpoints + one fp32 parameter  (SUR
 # HBM-side bytes per launch of the config-4 kernel from the rocprofv3 PMC passes committed in
 # profiles/r01_pmc_summary.md (separate --pmc runs; FETCH_SIZE doubled for wide coalesced reads as
 # MI355X_MICROARCH.md prescribes, + WRITE_SIZE).  bench.py cannot collect PMC counters itself.
-PMC_TRAFFIC_BYTES = {1: 2 * 430.7e6 + 7.8e6,   # k_fused_panel  (LDS column panels)
+PMC_TRAFFIC_BYTES = {1: 2 * 450.2e6 + 7.8e6,   # k_fused_panel  (LDS column panels, padded stream)
                      0: 4.45e9 + 9.4e6}        # k_fused_small  (CSR; narrow gather line fills, no doubling)
 
 
