@@ -205,6 +205,17 @@ int mde_knn(int64_t n, int32_t nf, const float* data, int32_t k, int32_t* idx_ou
 int mde_graph_shortest_paths(const mde_plan* plan, const float* w, float max_length,
                              double retain_fraction, uint64_t seed, int64_t capacity,
                              int64_t* edges_out, float* dist_out, int64_t* count_host, void* stream);
+/* Edge list of directed neighbour lists: pairs_out[r * k + c] = (r, idx[r][c]); empty slots (idx < 0)
+ * and entries with val > max_value (val may be NULL) become self pairs, which
+ * mde_edges_count_unique drops [ref: preprocess/data_matrix.py:147-175]. */
+int mde_knn_pairs(int64_t n, int32_t k, const int32_t* idx, const float* val, float max_value,
+                  int64_t* pairs_out, void* stream);
+/* k nearest neighbours of every vertex under the graph's shortest-path metric (direct = 0) or among
+ * its graph neighbours by edge length (direct = 1) [ref: preprocess/graph.py:502-587].  plan / w /
+ * max_length as for mde_graph_shortest_paths.  idx_out [n, k] int32 (-1 = fewer than k targets
+ * within max_length), dist_out [n, k] ascending; ties go to the smaller index.  SYNC. */
+int mde_graph_knn(const mde_plan* plan, const float* w, float max_length, int32_t direct, int32_t k,
+                  int32_t* idx_out, float* dist_out, void* stream);
 /* Sample at most num_edges distinct edges i < j uniformly at random from the edges NOT in
  * `exclude` [n_exclude, 2] (NULL / 0: no exclusion); edges_out must hold num_edges rows, sorted by
  * (i, j); *count_host = number written (== num_edges unless the complement is nearly exhausted).
@@ -271,6 +282,8 @@ int mde_right_multiply(int64_t n, int32_t d, int32_t d2, const float* A, const d
 /* out = base + alpha * A M  (base may be NULL or alias out; out may alias A only when d == d2). */
 int mde_right_multiply_add(int64_t n, int32_t d, int32_t d2, const float* A, const double* M,
                            float alpha, const float* base, float* out, void* stream);
+/* Z[r, :] += shift (d device doubles): the translation part of util.align [ref: util.py:302-331]. */
+int mde_shift_rows(int64_t n, int32_t d, const double* shift, float* Z, void* stream);
 /* Z[r, :] *= scale[r]  (row scaling, e.g. the Jacobi preconditioner of the spectral initialiser). */
 int mde_row_scale(int64_t n, int32_t d, const float* scale, float* Z, void* stream);
 /* out[v] = sum of the per-edge weights (plan / CSR order) over the half-edges of row v: the diagonal

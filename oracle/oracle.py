@@ -230,20 +230,94 @@ def deduplicate_edges(edges):
     return np.unique(e, axis=0)
 
 
-def knn_graph(data, k):
-    """Exact k-NN graph of a data matrix: unique edges i < j (sorted) and weights 1 / 2 (mutual)
+def _neighbor_lists_to_graph(nbr, keep):
+    """Directed neighbour lists [n, k] (+ a mask of the entries that count) -> unique edges
+    i < j (sorted) with weights 1 / 2 (mutual) [ref: data_matrix.py:147-178, graph.py:578-587]."""
+    n, k = nbr.shape
+    items = np.repeat(np.arange(n), k)
+    e = np.stack([items, nbr.ravel()], 1)[keep.ravel()]
+    e = np.stack([e.min(1), e.max(1)], 1)
+    uniq, counts = np.unique(e, axis=0, return_counts=True)
+    return uniq.astype(np.int64), counts.astype(np.float32)
+
+
+def knn_graph(data, k, max_distance=None):
+    """Exact k-NN graph of a data matrix: unique edges i < j (sorted) and weights 1 / 2 (mutual);
+    neighbours farther than max_distance do not count
     [ref: preprocess/data_matrix.py:91-178 with the sklearn brute-force branch]."""
     X = np.asarray(data, dtype=np.float64)
-    n = X.shape[0]
     sq = (X ** 2).sum(1)
     D = sq[:, None] + sq[None, :] - 2.0 * X @ X.T
     np.fill_diagonal(D, np.inf)
     nbr = np.argsort(D, axis=1, kind="stable")[:, :k]
-    items = np.repeat(np.arange(n), k)
-    e = np.stack([items, nbr.ravel()], 1)
-    e = np.stack([e.min(1), e.max(1)], 1)
-    uniq, counts = np.unique(e, axis=0, return_counts=True)
-    return uniq.astype(np.int64), counts.astype(np.float32)
+    keep = np.ones(nbr.shape, dtype=bool)
+    if max_distance is not None:
+        keep = np.take_along_axis(D, nbr, 1) <= float(max_distance) ** 2
+    return _neighbor_lists_to_graph(nbr, keep)
+
+
+def graph_knn(n, edges, lengths=None, k=1, max_distance=None, direct=False):
+    """k-NN graph of the nodes of a graph under its shortest-path metric (or, `direct`, among a
+    node's own neighbours by edge length), ties to the smaller index; targets must be at finite
+    positive distance <= max_distance [ref: preprocess/graph.py:502-587]."""
+    import scipy.sparse as sp
+    import scipy.sparse.csgraph as csgraph
+    e = np.asarray(edges)
+    w = np.ones(len(e)) if lengths is None else np.asarray(lengths, dtype=np.float64)
+    D = np.full((n, n), np.inf)
+    if direct:
+        np.minimum.at(D, (e[:, 0], e[:, 1]), w)
+        np.minimum.at(D, (e[:, 1], e[:, 0]), w)
+    else:
+        A = sp.coo_matrix((w, (e[:, 0], e[:, 1])), shape=(n, n))
+        D = csgraph.shortest_path(A.maximum(A.T).tocsr(), directed=False)
+    np.fill_diagonal(D, np.inf)
+    D[~(D > 0)] = np.inf
+    if max_distance is not None:
+        D[D > max_distance] = np.inf
+    nbr = np.argsort(D, axis=1, kind="stable")[:, :k]
+    return _neighbor_lists_to_graph(nbr, np.isfinite(np.take_along_axis(D, nbr, 1)))
+
+
+def pca(Y, m):
+    """sqrt(n) * top-m left singular vectors of the column-centred Y [ref: quadratic.py:16-44]."""
+    Y = np.asarray(Y, dtype=np.float64)
+    U, _, _ = np.linalg.svd(Y - Y.mean(0)[None, :], full_matrices=False)
+    return np.sqrt(float(Y.shape[0])) * U[:, :m]
+
+
+def procrustes(X_source, X_target):
+    """argmin_Q ||X_source Q - X_target||_F, Q orthogonal [ref: util.py:201-205]."""
+    U, _, Vh = np.linalg.svd(np.asarray(X_target, np.float64).T @ np.asarray(X_source, np.float64),
+                             full_matrices=False)
+    return Vh.T @ U.T
+
+
+def align(source, target):
+    """[ref: util.py:302-331]"""
+    S = np.asarray(source, dtype=np.float64)
+    T = np.asarray(target, dtype=np.float64)
+    mean = S.mean(0)
+    S = S - mean
+    norms = np.linalg.norm(S, axis=0)
+    S = S / norms
+    T = T - T.mean(0)
+    T = T / np.linalg.norm(T, axis=0)
+    return (S @ procrustes(S, T)) * norms + mean
+
+
+def rotate(X, degrees):
+    """[ref: util.py:208-299]"""
+    X = np.asarray(X, dtype=np.float64)
+    deg = np.atleast_1d(np.asarray(degrees, dtype=np.float64))
+    if X.shape[1] == 2:
+        t = np.deg2rad(deg[0])
+        return X @ np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]])
+    a, b, g = np.deg2rad(deg)
+    rx = np.array([[1, 0, 0], [0, np.cos(a), np.sin(a)], [0, -np.sin(a), np.cos(a)]])
+    ry = np.array([[np.cos(b), 0, -np.sin(b)], [0, 1, 0], [np.sin(b), 0, np.cos(b)]])
+    rz = np.array([[np.cos(g), np.sin(g), 0], [-np.sin(g), np.cos(g), 0], [0, 0, 1]])
+    return X @ (rx @ ry @ rz)
 
 
 def shortest_path_pairs(n, edges, weights=None, max_length=None):

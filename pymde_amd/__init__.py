@@ -10,8 +10,9 @@ __version__ = "0.1.0"
 from pymde_amd.problem import MDE  # noqa: F401
 from pymde_amd.constraints import Centered, Anchored, Standardized  # noqa: F401
 from pymde_amd.functions import losses, penalties  # noqa: F401
-from pymde_amd.util import all_edges, center, seed  # noqa: F401
+from pymde_amd.util import align, all_edges, center, rotate, seed  # noqa: F401
 from pymde_amd import quadratic  # noqa: F401
 from pymde_amd import preprocess  # noqa: F401
 from pymde_amd.graph import Graph  # noqa: F401
-from pymde_amd.recipes import preserve_distances, preserve_neighbors  # noqa: F401
+from pymde_amd.quadratic import pca  # noqa: F401
+from pymde_amd.recipes import laplacian_embedding, preserve_distances, preserve_neighbors  # noqa: F401

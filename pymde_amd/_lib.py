@@ -52,6 +52,8 @@ SYMBOLS = {
     "mde_edges_deduplicate": (c_i32, [c_i64, c_i64, c_vp, c_vp, ctypes.POINTER(c_i64), c_vp]),
     "mde_edges_count_unique": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, ctypes.POINTER(c_i64), c_vp]),
     "mde_knn": (c_i32, [c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "mde_knn_pairs": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp]),
+    "mde_graph_knn": (c_i32, [c_vp, c_vp, c_f32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "mde_graph_shortest_paths": (c_i32, [c_vp, c_vp, c_f32, ctypes.c_double, ctypes.c_uint64, c_i64,
                                          c_vp, c_vp, ctypes.POINTER(c_i64), c_vp]),
     "mde_sample_edges": (c_i32, [c_i64, c_i64, ctypes.c_uint64, c_vp, c_i64, c_vp,
@@ -70,6 +72,7 @@ SYMBOLS = {
     "mde_gram": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mde_right_multiply": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "mde_right_multiply_add": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp]),
+    "mde_shift_rows": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_vp]),
     "mde_row_scale": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_vp]),
     "mde_weighted_degree": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
     "mde_work_doubles": (c_i64, [c_i32]),

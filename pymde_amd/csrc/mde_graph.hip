@@ -122,6 +122,125 @@ struct GBuf {
   }
 };
 
+// one-hop lengths: dist[b][v] = min over parallel edges (src0 + b) ~ v of w  (one wave per source)
+__global__ __launch_bounds__(MDE_BLOCK) void k_sp_direct(int64_t B, int64_t n, int64_t src0,
+                                                         const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ nbr,
+                                                         const float* __restrict__ w, float max_length,
+                                                         float* __restrict__ dist) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * MDE_BLOCK) >> 6;
+  for (int64_t b = w0; b < B; b += nw) {
+    const int64_t u = src0 + b;
+    float* row = dist + b * n;
+    // parallel edges of one row are rare; a wave walks the row serially per lane stride and
+    // resolves collisions with an integer atomic min on the (non-negative) float bits
+    for (int h = rowptr[u] + lane; h < rowptr[u + 1]; h += 64) {
+      const float len = w ? w[h] : 1.0f;
+      if (len <= max_length && nbr[h] != u)
+        atomicMin(reinterpret_cast<unsigned int*>(row + nbr[h]), __float_as_uint(len));
+    }
+  }
+}
+
+// k nearest targets of every source of the batch by (distance, index): one workgroup per source,
+// k rounds of a block-wide lexicographic arg-min over the distance row (fixed tie-break: index).
+__global__ __launch_bounds__(MDE_BLOCK) void k_sp_topk(int64_t n, int64_t src0, const float* __restrict__ dist,
+                                                       int k, int32_t* __restrict__ idx_out,
+                                                       float* __restrict__ dist_out) {
+  __shared__ float sd[MDE_BLOCK / 64];
+  __shared__ int sj[MDE_BLOCK / 64];
+  __shared__ float bd;
+  __shared__ int bj;
+  const int64_t b = blockIdx.x, src = src0 + b;
+  const float* row = dist + b * n;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float last_d = -1.0f;
+  int last_j = -1;
+  for (int r = 0; r < k; ++r) {
+    float best = MDE_INF_F;
+    int bestj = 0x7fffffff;
+    for (int64_t j = tid; j < n; j += MDE_BLOCK) {
+      const float d = row[j];
+      const bool ok = j != src && d > 0.0f && d < MDE_INF_F &&
+                      (d > last_d || (d == last_d && (int)j > last_j));
+      if (ok && (d < best || (d == best && (int)j < bestj))) {
+        best = d;
+        bestj = (int)j;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float od = __shfl_xor(best, off, 64);
+      const int oj = __shfl_xor(bestj, off, 64);
+      if (od < best || (od == best && oj < bestj)) {
+        best = od;
+        bestj = oj;
+      }
+    }
+    if (lane == 0) {
+      sd[wave] = best;
+      sj[wave] = bestj;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float d0 = sd[0];
+      int j0 = sj[0];
+      for (int q = 1; q < MDE_BLOCK / 64; ++q)
+        if (sd[q] < d0 || (sd[q] == d0 && sj[q] < j0)) {
+          d0 = sd[q];
+          j0 = sj[q];
+        }
+      bd = d0;
+      bj = j0;
+      const bool found = d0 < MDE_INF_F;
+      idx_out[src * k + r] = found ? j0 : -1;
+      dist_out[src * k + r] = found ? d0 : MDE_INF_F;
+    }
+    __syncthreads();
+    last_d = bd;
+    last_j = bj;
+    if (!(last_d < MDE_INF_F)) {
+      // fewer than k reachable targets: the remaining slots are empty
+      for (int q = r + 1 + tid; q < k; q += MDE_BLOCK) {
+        idx_out[src * k + q] = -1;
+        dist_out[src * k + q] = MDE_INF_F;
+      }
+      break;
+    }
+    __syncthreads();
+  }
+}
+
+// dist[b][.] = shortest-path lengths from source src0 + b, b < Bc (relaxed to the fixed point).
+// direct != 0: one-hop lengths only (the graph's own edge lengths; everything else stays INF).
+static int sp_solve_batch(const mde_plan* plan, const float* w, float max_length, int direct, int64_t src0,
+                          int64_t Bc, float* dist, int* changed, int nblk, hipStream_t st) {
+  const int64_t n = plan->n;
+  hipLaunchKernelGGL(k_sp_init, dim3(nblk), dim3(MDE_BLOCK), 0, st, Bc, n, src0, dist);
+  MDE_LAUNCH_CHECK();
+  if (direct) {
+    hipLaunchKernelGGL(k_sp_direct, dim3(mde_grid(Bc * 64, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st, Bc, n,
+                       src0, plan->rowptr, plan->nbr, w, max_length, dist);
+    MDE_LAUNCH_CHECK();
+    return MDE_OK;
+  }
+  for (int64_t sweep = 0; sweep < 4 * n + 8; sweep += 4) {
+    MDE_HIP(hipMemsetAsync(changed, 0, sizeof(int), st));
+    for (int s4 = 0; s4 < 4; ++s4) {
+      hipLaunchKernelGGL(k_sp_relax, dim3(nblk), dim3(MDE_BLOCK), 0, st, Bc, (int)n, plan->rowptr, plan->nbr, w,
+                         max_length, dist, changed);
+      MDE_LAUNCH_CHECK();
+    }
+    int h = 0;
+    MDE_HIP(hipMemcpyAsync(&h, changed, sizeof(int), hipMemcpyDeviceToHost, st));
+    MDE_HIP(hipStreamSynchronize(st));
+    if (!h) break;
+  }
+  return MDE_OK;
+}
+
 // plan: a FULL plan of the graph's edges (its symmetrised CSR is the adjacency); w: per-half-edge
 // edge lengths in plan (CSR) order, or NULL for unit lengths.  Writes at most `capacity` pairs
 // (i < j, sorted by (i, j)) with their shortest-path distances; *count_host = number of pairs (if it
@@ -160,20 +279,8 @@ extern "C" int mde_graph_shortest_paths(const mde_plan* plan, const float* w, fl
   const int nblk = mde_grid(B * n, MDE_BLOCK, 8192);
   for (int64_t src0 = 0; src0 < n; src0 += B) {
     const int64_t Bc = (src0 + B <= n) ? B : n - src0;
-    hipLaunchKernelGGL(k_sp_init, dim3(nblk), dim3(MDE_BLOCK), 0, st, Bc, n, src0, dist.as<float>());
-    MDE_LAUNCH_CHECK();
-    for (int64_t sweep = 0; sweep < 4 * n + 8; sweep += 4) {
-      MDE_HIP(hipMemsetAsync(changed.p, 0, sizeof(int), st));
-      for (int s4 = 0; s4 < 4; ++s4) {
-        hipLaunchKernelGGL(k_sp_relax, dim3(nblk), dim3(MDE_BLOCK), 0, st, Bc, (int)n, plan->rowptr, plan->nbr, w,
-                           max_length, dist.as<float>(), changed.as<int>());
-        MDE_LAUNCH_CHECK();
-      }
-      int h = 0;
-      MDE_HIP(hipMemcpyAsync(&h, changed.p, sizeof(int), hipMemcpyDeviceToHost, st));
-      MDE_HIP(hipStreamSynchronize(st));
-      if (!h) break;
-    }
+    const int rc = sp_solve_batch(plan, w, max_length, 0, src0, Bc, dist.as<float>(), changed.as<int>(), nblk, st);
+    if (rc != MDE_OK) return rc;
     hipLaunchKernelGGL(k_sp_emit, dim3(nblk), dim3(MDE_BLOCK), 0, st, Bc, n, src0, dist.as<float>(), seed, threshold,
                        keep_all, capacity, counter.as<unsigned long long>(), keys.as<uint64_t>(), vals.as<float>());
     MDE_LAUNCH_CHECK();
@@ -202,6 +309,40 @@ extern "C" int mde_graph_shortest_paths(const mde_plan* plan, const float* w, fl
   hipLaunchKernelGGL(k_sp_unpack, dim3(mde_grid((int64_t)total, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, n,
                      (int64_t)total, keys2.as<uint64_t>(), edges_out);
   MDE_LAUNCH_CHECK();
+  MDE_HIP(hipStreamSynchronize(st));
+  return MDE_OK;
+}
+
+// k nearest neighbours of every vertex under the shortest-path metric of the graph (direct == 0) or
+// among its graph neighbours by edge length (direct != 0)  [ref: preprocess/graph.py:502-587].
+// idx_out [n, k] int32 (-1 where fewer than k targets lie within max_length), dist_out [n, k]
+// ascending per row; ties are broken by the smaller index.  SYNC.
+extern "C" int mde_graph_knn(const mde_plan* plan, const float* w, float max_length, int32_t direct, int32_t k,
+                             int32_t* idx_out, float* dist_out, void* stream) {
+  if (!plan || !idx_out || !dist_out || k <= 0) return MDE_E_INVALID;
+  if (plan->row_lo != 0 || plan->row_hi != plan->n) {
+    mde_set_error("mde_graph_knn needs a full (unsharded) plan");
+    return MDE_E_INVALID;
+  }
+  hipStream_t st = mde_stream(stream);
+  const int64_t n = plan->n;
+  if (n >= ((int64_t)1 << 31)) return MDE_E_TOO_LARGE;
+  if (!(max_length > 0.0f)) max_length = MDE_INF_F;
+  int64_t B = ((int64_t)1 << 28) / (n > 0 ? n : 1);
+  if (B < 1) B = 1;
+  if (B > n) B = n;
+  GBuf dist, changed;
+  MDE_HIP(dist.alloc((size_t)B * n * sizeof(float)));
+  MDE_HIP(changed.alloc(sizeof(int)));
+  const int nblk = mde_grid(B * n, MDE_BLOCK, 8192);
+  for (int64_t src0 = 0; src0 < n; src0 += B) {
+    const int64_t Bc = (src0 + B <= n) ? B : n - src0;
+    const int rc = sp_solve_batch(plan, w, max_length, direct, src0, Bc, dist.as<float>(), changed.as<int>(), nblk, st);
+    if (rc != MDE_OK) return rc;
+    hipLaunchKernelGGL(k_sp_topk, dim3((unsigned)Bc), dim3(MDE_BLOCK), 0, st, n, src0, dist.as<float>(), k, idx_out,
+                       dist_out);
+    MDE_LAUNCH_CHECK();
+  }
   MDE_HIP(hipStreamSynchronize(st));
   return MDE_OK;
 }

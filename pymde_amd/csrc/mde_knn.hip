@@ -141,3 +141,27 @@ extern "C" int mde_knn(int64_t n, int32_t nf, const float* data, int32_t k, int3
   MDE_LAUNCH_CHECK();
   return MDE_OK;
 }
+
+// Directed neighbour lists -> edge list for mde_edges_count_unique: pairs_out[r * k + c] = (r, idx[r][c]).
+// Empty slots (idx < 0) and, when `val` is given, entries with val > max_value become the self pair
+// (r, r), which the edge counter drops [ref: data_matrix.py:147-175 -- neighbours beyond max_distance
+// get weight 0 and vanish from the graph].
+__global__ __launch_bounds__(MDE_BLOCK) void k_knn_pairs(int64_t total, int k, const int32_t* __restrict__ idx,
+                                                         const float* __restrict__ val, float max_value,
+                                                         int64_t* __restrict__ pairs) {
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * MDE_BLOCK) {
+    const int64_t r = i / k;
+    int64_t j = idx[i];
+    if (j < 0 || (val && !(val[i] <= max_value))) j = r;
+    reinterpret_cast<longlong2*>(pairs)[i] = make_longlong2((long long)r, (long long)j);
+  }
+}
+extern "C" int mde_knn_pairs(int64_t n, int32_t k, const int32_t* idx, const float* val, float max_value,
+                             int64_t* pairs_out, void* stream) {
+  if (n <= 0 || k <= 0 || !idx || !pairs_out) return MDE_E_INVALID;
+  hipLaunchKernelGGL(k_knn_pairs, dim3(mde_grid(n * k, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, mde_stream(stream),
+                     n * (int64_t)k, k, idx, val, max_value, pairs_out);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}

@@ -480,6 +480,20 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_row_scale(int64_t N, int d, const
        i += (int64_t)gridDim.x * MDE_BLOCK)
     Z[i] *= scale[i / d];
 }
+// Z[r, :] += shift  (shift: d device doubles)
+__global__ __launch_bounds__(MDE_BLOCK) void k_shift_rows(int64_t N, int d, const double* __restrict__ shift,
+                                                          float* __restrict__ Z) {
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N;
+       i += (int64_t)gridDim.x * MDE_BLOCK)
+    Z[i] = (float)((double)Z[i] + shift[i % d]);
+}
+extern "C" int mde_shift_rows(int64_t n, int32_t d, const double* shift, float* Z, void* stream) {
+  if (n <= 0 || d <= 0 || !shift || !Z) return MDE_E_INVALID;
+  hipLaunchKernelGGL(k_shift_rows, dim3(mde_grid(n * d, MDE_BLOCK)), dim3(MDE_BLOCK), 0, mde_stream(stream),
+                     n * d, d, shift, Z);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
 extern "C" int mde_row_scale(int64_t n, int32_t d, const float* scale, float* Z, void* stream) {
   if (n <= 0 || d <= 0 || !scale || !Z) return MDE_E_INVALID;
   hipLaunchKernelGGL(k_row_scale, dim3(mde_grid(n * d, MDE_BLOCK)), dim3(MDE_BLOCK), 0, mde_stream(stream),

@@ -108,3 +108,35 @@ def shortest_paths(graph, retain_fraction=1.0, max_length=None, seed=0, verbose=
             ctypes.byref(count), _lib.stream_ptr(device)))
     m = count.value
     return Graph(edges[:m], dist[:m], n)
+
+
+def k_nearest_neighbors(graph, k, graph_distances=False, max_distance=None, verbose=False):
+    """k-nearest-neighbour graph of the nodes of ``graph`` [ref: graph.py:502-587]: neighbourhoods
+    among a node's own graph neighbours by edge length (the default, as in the reference, and
+    whenever the graph is already complete) or under the shortest-path metric
+    (``graph_distances=True``, what the recipes ask for [ref: generic.py:97-107]), optionally
+    restricted to radius ``max_distance``.  Returns ``(edges, weights)``: weight 2 for mutual
+    neighbours, 1 otherwise.  Ties in distance go to the smaller node index (the reference's
+    ``argsort`` leaves them unspecified)."""
+    from pymde_amd import preprocess
+    if not isinstance(graph, Graph):
+        raise ValueError("`graph` must be a pymde_amd.Graph instance.")
+    lib = _lib.load()
+    plan = graph.plan()
+    device = plan.device
+    n = graph.n_items
+    k = min(int(k), n - 1)
+    if k < 1:
+        raise ValueError("k must be at least 1")
+    if graph.n_edges == graph.n_all_edges:
+        graph_distances = False  # already a full distance matrix
+    unweighted = bool((graph.distances == 1.0).all())
+    w = None if unweighted else plan.expand(graph.distances, 0)
+    idx = torch.empty((n, k), dtype=torch.int32, device=device)
+    dist = torch.empty((n, k), dtype=torch.float32, device=device)
+    with torch.cuda.device(device):
+        _lib.check(lib.mde_graph_knn(plan.handle, _lib.ptr(w),
+                                     float(max_distance) if max_distance is not None else 0.0,
+                                     0 if graph_distances else 1, k, _lib.ptr(idx), _lib.ptr(dist),
+                                     _lib.stream_ptr(device)))
+    return preprocess._neighbor_lists_to_graph(n, k, idx, dist, None, device)

@@ -80,17 +80,38 @@ def dissimilar_edges(n_items, similar_edges, num_edges=None, seed=None):
     return sample_edges(n_items, num_edges, exclude=similar_edges, seed=seed)
 
 
-def k_nearest_neighbors(data, k, max_distance=None, device=None):
+def _neighbor_lists_to_graph(n, k, idx, values, max_value, device):
+    """Directed neighbour lists [n, k] -> unique undirected edges with weights 1 / 2."""
+    lib = _lib.load()
+    pairs = torch.empty((n * k, 2), dtype=torch.int64, device=device)
+    edges = torch.empty_like(pairs)
+    weights = torch.empty(pairs.shape[0], dtype=torch.float32, device=device)
+    count = ctypes.c_int64(0)
+    with torch.cuda.device(device):
+        _lib.check(lib.mde_knn_pairs(n, k, _lib.ptr(idx), _lib.ptr(values) if max_value is not None else None,
+                                     float(max_value) if max_value is not None else 0.0,
+                                     _lib.ptr(pairs), _lib.stream_ptr(device)))
+        _lib.check(lib.mde_edges_count_unique(n, pairs.shape[0], _lib.ptr(pairs), _lib.ptr(edges),
+                                              _lib.ptr(weights), ctypes.byref(count),
+                                              _lib.stream_ptr(device)))
+    return edges[:count.value], weights[:count.value]
+
+
+def k_nearest_neighbors(data, k, max_distance=None, device=None, graph_distances=True):
     """Exact k-nearest-neighbour graph of the rows of a data matrix (Euclidean distance)
-    [ref: preprocess/data_matrix.py:91-178].
+    [ref: preprocess/data_matrix.py:91-178] or of the nodes of a ``Graph`` (shortest-path metric,
+    ``pymde_amd.graph.k_nearest_neighbors``) [ref: preprocess/generic.py dispatch].
 
     Returns ``(edges, weights)`` on the GPU: unique edges i < j sorted by (i, j); the weight is 2
     when i and j are neighbours of each other, 1 when only one is a neighbour of the other.
-    The reference is exact (sklearn brute force) below 10 000 items and approximate
-    (pynndescent) above; this search is exact at every size.  Self matches are excluded by
-    index, so duplicated rows become ordinary zero-distance neighbours."""
-    if max_distance is not None:
-        raise NotImplementedError("max_distance is not supported by the GPU k-NN graph yet")
+    Neighbours farther than ``max_distance`` do not count (an edge whose both directions are too
+    long disappears).  The reference is exact (sklearn brute force) below 10 000 items and
+    approximate (pynndescent) above; this search is exact at every size.  Self matches are
+    excluded by index, so duplicated rows become ordinary zero-distance neighbours."""
+    if hasattr(data, "edges") and hasattr(data, "n_items") and not isinstance(data, torch.Tensor):
+        from pymde_amd import graph as _graph
+        return _graph.k_nearest_neighbors(data, k, graph_distances=graph_distances,
+                                          max_distance=max_distance)
     if not isinstance(data, torch.Tensor):
         data = torch.as_tensor(data)
     if device is None:
@@ -110,16 +131,8 @@ def k_nearest_neighbors(data, k, max_distance=None, device=None):
     with torch.cuda.device(device):
         _lib.check(lib.mde_knn(n, nf, _lib.ptr(data), k, _lib.ptr(idx), _lib.ptr(d2), _lib.ptr(sqn),
                                _lib.stream_ptr(device)))
-    items = torch.arange(n, device=device, dtype=torch.int64).repeat_interleave(k)
-    pairs = torch.stack([items, idx.reshape(-1).to(torch.int64)], dim=1).contiguous()
-    edges = torch.empty_like(pairs)
-    weights = torch.empty(pairs.shape[0], dtype=torch.float32, device=device)
-    count = ctypes.c_int64(0)
-    with torch.cuda.device(device):
-        _lib.check(lib.mde_edges_count_unique(n, pairs.shape[0], _lib.ptr(pairs), _lib.ptr(edges),
-                                              _lib.ptr(weights), ctypes.byref(count),
-                                              _lib.stream_ptr(device)))
-    return edges[:count.value], weights[:count.value]
+    max_d2 = None if max_distance is None else float(max_distance) ** 2
+    return _neighbor_lists_to_graph(n, k, idx, d2, max_d2, device)
 
 
 def _rms(distances):

@@ -182,3 +182,36 @@ def spectral(n_items, embedding_dim, edges, weights, cg=False, max_iter=40, devi
         _, V = _lobpcg(lap, m, iters, tol, device)
         _Ops(n, device, m).center(V)
         return util.proj_standardized(V.contiguous(), demean=False)
+
+
+def pca(Y, embedding_dim, device=None):
+    """PCA embedding of a data matrix: the top ``embedding_dim`` left singular vectors of the
+    column-centred ``Y``, scaled by sqrt(n) [ref: pymde/quadratic.py:16-44].
+
+    The reference takes a full SVD of ``Y`` on the CPU.  Here the k x k Gram matrix of the centred
+    data is formed on the GPU (``mde_center`` + ``mde_gram``), its eigendecomposition (k x k,
+    float64) is done on the host, and ``U = Y V S^-1`` is one ``mde_right_multiply``.  Singular
+    vectors are defined up to sign; each column is oriented so that its largest-magnitude entry
+    of the right singular vector is positive."""
+    if not isinstance(Y, torch.Tensor):
+        Y = torch.as_tensor(Y)
+    if device is None:
+        device = Y.device if Y.is_cuda else util.get_default_device()
+    device = util.require_cuda_device(device)
+    n, k = int(Y.shape[0]), int(Y.shape[1])
+    m = int(embedding_dim)
+    if m > min(n, k):
+        raise ValueError("Embedding dimension must be at most minimum dimension of Y")
+    with torch.no_grad(), torch.cuda.device(device):
+        Yc = Y.detach().to(device=device, dtype=torch.float32).contiguous().clone()
+        ops = _Ops(n, device, k)
+        ops.center(Yc)
+        G = _sym(ops.gram(Yc, Yc))
+        evals, evecs = np.linalg.eigh(G)
+        order = np.argsort(evals)[::-1][:m]
+        sing = np.sqrt(np.maximum(evals[order], 0.0))
+        if np.any(sing <= 1e-12 * max(float(sing.max()), 1e-300)):
+            raise util.SolverError("pca: the centred data matrix has rank below embedding_dim")
+        V = evecs[:, order]
+        V = V * np.sign(V[np.abs(V).argmax(axis=0), np.arange(m)])[None, :]
+        return ops.rmul(Yc, V * (np.sqrt(float(n)) / sing)[None, :])

@@ -4,9 +4,10 @@
 pymde/preprocess/data_matrix.py:11-88] is built from the GPU pieces of this package: the edge
 sampler (``preprocess.sample_edges``, row f1) and the edge-order distance kernel with
 ``d = n_features`` (``mde_distances``, row f4); graph inputs use the batched shortest-path kernel (``graph.shortest_paths``,
-row f3).  ``preserve_neighbors`` for data matrices [ref: recipes.py:221-448] adds
-the exact GPU k-NN graph (``preprocess.k_nearest_neighbors``, row f2) and the spectral initialiser.
-``preserve_neighbors`` on a graph (shortest-path neighbourhoods) is not built yet and says so.
+row f3).  ``preserve_neighbors`` [ref: recipes.py:221-448] adds the exact GPU k-NN graph
+(``preprocess.k_nearest_neighbors`` for data matrices, row f2; ``graph.k_nearest_neighbors`` under the
+shortest-path metric for graphs, row f3) and the spectral initialiser; ``laplacian_embedding``
+[ref: recipes.py:451-503] is the quadratic, standardized special case.
 """
 import torch
 
@@ -107,18 +108,18 @@ def preserve_neighbors(data, embedding_dim=2, attractive_penalty=penalties.Log1p
     """An MDE problem that preserves the k-nearest-neighbour structure of a data matrix
     (rows = items) [ref: recipes.py:221-448]: k-NN graph (weights 1 / 2), optional spectral
     initialisation, uniformly sampled repulsive edges (weight -1), ``PushAndPull`` of the two
-    penalties.  Every stage runs on the GPU (rows f2, a10, f1 of SURVEY section 8).  Graph inputs
-    (shortest-path neighbourhoods, row f3) are not built yet."""
-    if hasattr(data, "edges") and not isinstance(data, torch.Tensor):
-        raise NotImplementedError(
-            "preserve_neighbors on a graph needs shortest-path distances (SURVEY 8f row f3), which "
-            "this package does not build yet")
-    if not isinstance(data, torch.Tensor):
+    penalties.  ``data`` may also be a ``Graph``: neighbourhoods are then taken under its
+    shortest-path metric.  Every stage runs on the GPU (rows f2, f3, a10, f1 of SURVEY section 8)."""
+    is_graph = isinstance(data, _graph.Graph)
+    if not is_graph and not isinstance(data, torch.Tensor):
         data = torch.as_tensor(data)
     if device is None:
-        device = data.device if data.is_cuda else util.get_default_device()
+        if is_graph:
+            device = data.edges.device
+        else:
+            device = data.device if data.is_cuda else util.get_default_device()
     device = util.require_cuda_device(device)
-    n = int(data.shape[0])
+    n = int(data.n_items) if is_graph else int(data.shape[0])
     if n_neighbors is None:
         # the reference's default (recipes.py:300-307): max(min(15, 2 % of the items), 5)
         n_neighbors = int(max(min(15, n * 0.02), 5))
@@ -133,8 +134,12 @@ def preserve_neighbors(data, embedding_dim=2, attractive_penalty=penalties.Log1p
         constraint = constraints.Standardized()
     if verbose:
         problem.LOGGER.info(f"Computing {n_neighbors}-nearest neighbors, with max_distance={max_distance}")
-    edges, weights = preprocess.k_nearest_neighbors(data, k=n_neighbors, max_distance=max_distance,
-                                                    device=device)
+    if is_graph:
+        edges, weights = _graph.k_nearest_neighbors(data, k=n_neighbors, graph_distances=True,
+                                                          max_distance=max_distance, verbose=verbose)
+    else:
+        edges, weights = preprocess.k_nearest_neighbors(data, k=n_neighbors, max_distance=max_distance,
+                                                        device=device)
     if isinstance(constraint, constraints.Anchored):
         edges, weights = _remove_anchor_anchor_edges(edges, weights, constraint.anchors)
     if init == "quadratic":
@@ -173,3 +178,13 @@ def preserve_neighbors(data, embedding_dim=2, attractive_penalty=penalties.Log1p
         mde._X_init = mde._X_init + 1e-4 * torch.randn(mde._X_init.shape, device=device,
                                                        dtype=mde._X_init.dtype)
     return mde
+
+
+def laplacian_embedding(data, embedding_dim=2, n_neighbors=None, max_distance=None, init="quadratic",
+                        device=None, verbose=False):
+    """An MDE problem whose solution is a Laplacian embedding [ref: recipes.py:451-503]: the k-NN
+    graph of ``preserve_neighbors`` with quadratic penalties, no repulsion and the standardization
+    constraint."""
+    return preserve_neighbors(data, embedding_dim=embedding_dim, attractive_penalty=penalties.Quadratic,
+                              repulsive_penalty=None, n_neighbors=n_neighbors, max_distance=max_distance,
+                              init=init, device=device, verbose=verbose)

@@ -144,3 +144,107 @@ def proj_standardized(X, demean=False, inplace=False):
         X.copy_(Z)
         return X
     return Z
+
+
+# ---------------------------------------------------------------- aligning / rotating embeddings
+# [ref: pymde/util.py:201-331].  The n-sized work (column sums, Gram matrices, X @ M) runs in the
+# library's kernels (mde_gram / mde_center / mde_right_multiply / mde_shift_rows); only d x d
+# matrices visit the host.
+def _blocks(X):
+    from pymde_amd import _lib
+    X = X.detach()
+    device = require_cuda_device(X.device)
+    X = X.to(dtype=torch.float32).contiguous()
+    return _lib, _lib.load(), device, X, int(X.shape[0]), int(X.shape[1])
+
+
+def _gram(lib_mod, lib, A, B, work):
+    out = torch.empty((A.shape[1], B.shape[1]), dtype=torch.float64, device=A.device)
+    lib_mod.check(lib.mde_gram(A.shape[0], A.shape[1], B.shape[1], lib_mod.ptr(A), lib_mod.ptr(B),
+                               lib_mod.ptr(out), lib_mod.ptr(work), lib_mod.stream_ptr(A.device)))
+    return out.cpu().numpy()
+
+
+def _right_multiply(lib_mod, lib, A, M):
+    """A @ M for a small host float64 matrix M."""
+    import numpy as np
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    Md = torch.from_numpy(M).to(A.device)
+    torch.cuda.current_stream(A.device).synchronize()
+    out = torch.empty((A.shape[0], M.shape[1]), dtype=torch.float32, device=A.device)
+    lib_mod.check(lib.mde_right_multiply(A.shape[0], A.shape[1], M.shape[1], lib_mod.ptr(A),
+                                         lib_mod.ptr(Md), lib_mod.ptr(out),
+                                         lib_mod.stream_ptr(A.device)))
+    return out
+
+
+def _centered_unit_columns(lib_mod, lib, X, work):
+    """(X - mean) / column norm, the column means and the column norms."""
+    import numpy as np
+    n, d = X.shape
+    ones = torch.ones((n, 1), dtype=torch.float32, device=X.device)
+    mean = _gram(lib_mod, lib, ones, X, work)[0] / float(n)
+    Xc = X.clone()
+    lib_mod.check(lib.mde_center(n, d, lib_mod.ptr(Xc), lib_mod.ptr(work), lib_mod.stream_ptr(X.device)))
+    norms = np.sqrt(np.maximum(np.diag(_gram(lib_mod, lib, Xc, Xc, work)), 0.0))
+    return _right_multiply(lib_mod, lib, Xc, np.diag(1.0 / norms)), mean, norms
+
+
+def procrustes(X_source, X_target):
+    """argmin_Q ||X_source Q - X_target||_F over orthogonal Q [ref: util.py:201-205]; returns the
+    d x d matrix as a float32 tensor on the source's device."""
+    import numpy as np
+    lib_mod, lib, device, S, n, d = _blocks(X_source)
+    T = X_target.detach().to(device=device, dtype=torch.float32).contiguous()
+    with torch.cuda.device(device):
+        work = work_buffer(device, d)
+        M = _gram(lib_mod, lib, T, S, work)  # X_target^T X_source
+    U, _, Vh = np.linalg.svd(M, full_matrices=False)
+    return torch.from_numpy((Vh.T @ U.T).astype(np.float32)).to(device)
+
+
+def align(source, target):
+    """Rotate / reflect ``source`` onto ``target`` (orthogonal Procrustes on the centred,
+    column-normalised embeddings), then restore the source's column scales and mean
+    [ref: util.py:302-331]."""
+    import numpy as np
+    lib_mod, lib, device, S, n, d = _blocks(source)
+    T = target.detach().to(device=device, dtype=torch.float32).contiguous()
+    with torch.cuda.device(device):
+        work = work_buffer(device, d)
+        Sn, mean, norms = _centered_unit_columns(lib_mod, lib, S, work)
+        Tn, _, _ = _centered_unit_columns(lib_mod, lib, T, work)
+        U, _, Vh = np.linalg.svd(_gram(lib_mod, lib, Tn, Sn, work), full_matrices=False)
+        Q = Vh.T @ U.T
+        out = _right_multiply(lib_mod, lib, Sn, Q * norms[None, :])
+        shift = torch.from_numpy(np.ascontiguousarray(mean, dtype=np.float64)).to(device)
+        torch.cuda.current_stream(device).synchronize()
+        lib_mod.check(lib.mde_shift_rows(n, d, lib_mod.ptr(shift), lib_mod.ptr(out),
+                                         lib_mod.stream_ptr(device)))
+    return out
+
+
+def rotate(X, degrees):
+    """Rotate a 2-D embedding by ``degrees`` (scalar) or a 3-D one by three angles about the x, y
+    and z axes in that order [ref: util.py:208-299]."""
+    import numpy as np
+    if X.shape[1] not in (2, 3):
+        raise ValueError("Only 2 or 3 dimensional embeddings can be rotated using this method.")
+    deg = np.atleast_1d(np.asarray(degrees.detach().cpu() if isinstance(degrees, torch.Tensor) else degrees,
+                                   dtype=np.float64))
+    if X.shape[1] == 2:
+        if deg.size != 1:
+            raise ValueError("`degrees` must be a scalar.")
+        t = np.deg2rad(deg[0])
+        R = np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]])
+    else:
+        if deg.size != 3:
+            raise ValueError("`degrees` must be a length-3 tensor.")
+        a, b, g = np.deg2rad(deg)
+        rx = np.array([[1, 0, 0], [0, np.cos(a), np.sin(a)], [0, -np.sin(a), np.cos(a)]])
+        ry = np.array([[np.cos(b), 0, -np.sin(b)], [0, 1, 0], [np.sin(b), 0, np.cos(b)]])
+        rz = np.array([[np.cos(g), np.sin(g), 0], [-np.sin(g), np.cos(g), 0], [0, 0, 1]])
+        R = rx @ ry @ rz
+    lib_mod, lib, device, Xc, n, d = _blocks(X)
+    with torch.cuda.device(device):
+        return _right_multiply(lib_mod, lib, Xc, R)

@@ -18,6 +18,8 @@ Fixtures
   preprocess.npz    deduplicate_edges / sample_edges of the reference
   cycle.npz         BASELINE config 1 scaled down: preserve_distances on a cycle graph,
                     losses.Quadratic, all pairs
+  api.npz           pca / align / rotate, k-NN with max_distance, graph k-NN (shortest-path and
+                    direct), the graphs behind laplacian_embedding and preserve_neighbors(Graph)
 """
 import os
 import shutil
@@ -351,6 +353,67 @@ def gen_preprocess(pymde, torch):
     print("preprocess.npz: dedup", out["dedup"].shape, "sampled", len(s))
 
 
+def gen_api(pymde, torch):
+    """The remaining public helpers around the hot path: pca / align / rotate (util.py,
+    quadratic.py:16-44) and the neighbour graphs of the recipes (graph.py:502-587,
+    data_matrix.py:91-178 with max_distance, recipes.py:221-503)."""
+    import scipy.sparse as sp
+    from pymde.preprocess import data_matrix, graph as rgraph
+    sys.modules["pynndescent"].NNDescent = None
+    rng = np.random.default_rng(2024)
+    out = {}
+    Y = (rng.standard_normal((50, 6)) * np.array([5, 3, 2, 1, 0.5, 0.2])).astype(np.float32)
+    out["pca_Y"] = Y
+    out["pca_out"] = pymde.pca(torch.tensor(Y), 3).numpy()
+    src = rng.standard_normal((40, 3)).astype(np.float32) * np.array([2.0, 1.0, 0.5], dtype=np.float32) + 3.0
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    tgt = ((src - src.mean(0)) @ q + 0.05 * rng.standard_normal((40, 3))).astype(np.float32)
+    out["align_source"], out["align_target"] = src, tgt
+    out["align_out"] = pymde.align(torch.tensor(src), torch.tensor(tgt)).numpy()
+    out["procrustes_out"] = pymde.util.procrustes(torch.tensor(src), torch.tensor(tgt)).numpy()
+    X2 = rng.standard_normal((30, 2)).astype(np.float32)
+    X3 = rng.standard_normal((30, 3)).astype(np.float32)
+    out["rot_X2"], out["rot_X3"] = X2, X3
+    out["rot2_out"] = pymde.rotate(torch.tensor(X2), torch.tensor(30.0)).numpy()
+    out["rot3_out"] = pymde.rotate(torch.tensor(X3), torch.tensor([10.0, 20.0, 30.0])).numpy()
+    # k-NN of a data matrix with a radius
+    kd = rng.standard_normal((60, 5)).astype(np.float32)
+    g = data_matrix.k_nearest_neighbors(kd, k=4, max_distance=1.6)
+    out["knnr_data"] = kd
+    out["knnr_edges"], out["knnr_weights"] = g.edges.numpy(), g.distances.numpy()
+    # k-NN on a weighted graph with distinct lengths (no distance ties)
+    n = 40
+    rows = rng.integers(0, n, 140)
+    cols = rng.integers(0, n, 140)
+    keep = rows != cols
+    rows, cols = rows[keep], cols[keep]
+    A = sp.coo_matrix((rng.uniform(0.5, 2.0, rows.size), (rows, cols)), shape=(n, n)).tocsr()
+    A = A.maximum(A.T)
+    G = pymde.Graph(A.copy())
+    out["g_n"] = np.array(n)
+    out["g_edges"], out["g_lengths"] = G.edges.numpy(), G.distances.numpy()
+    for tag, kw in (("sp", {"graph_distances": True}),
+                    ("spr", {"graph_distances": True, "max_distance": 1.5}),
+                    ("direct", {"graph_distances": False}),
+                    ("directr", {"graph_distances": False, "max_distance": 1.2})):
+        # (a fresh Graph per call: the reference's max_distance masking writes into the adjacency)
+        kg = rgraph.k_nearest_neighbors(pymde.Graph(A.copy()), k=3, **kw)
+        out["gknn_%s_edges" % tag] = kg.edges.numpy()
+        out["gknn_%s_weights" % tag] = kg.distances.numpy()
+    # the graphs the recipes build
+    lap = pymde.laplacian_embedding(torch.tensor(kd), embedding_dim=2, n_neighbors=5, init="random")
+    out["lap_edges"] = lap.edges.numpy()
+    out["lap_weights"] = lap.distortion_function.weights.numpy()
+    out["lap_constraint"] = np.array(type(lap.constraint).__name__)
+    pn = pymde.preserve_neighbors(pymde.Graph(A.copy()), embedding_dim=2, n_neighbors=3, init="random")
+    w = pn.distortion_function.weights.numpy()
+    out["png_edges_pos"] = pn.edges.numpy()[w > 0]
+    out["png_weights_pos"] = w[w > 0]
+    out["png_n_neg"] = np.array(int((w < 0).sum()))
+    np.savez_compressed(os.path.join(HERE, "api.npz"), **out)
+    print("api.npz:", {k: np.asarray(v).shape for k, v in out.items() if k.endswith("edges")})
+
+
 def main():
     pymde = import_reference()
     import torch
@@ -361,6 +424,7 @@ def main():
     gen_spectral(pymde, torch)
     gen_cycle(pymde, torch)
     gen_preprocess(pymde, torch)
+    gen_api(pymde, torch)
 
 
 if __name__ == "__main__":

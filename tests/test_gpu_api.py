@@ -1,0 +1,136 @@
+"""The public helpers around the hot path that complete the reference's API surface: pca, align /
+procrustes / rotate, k-NN with a radius, k-NN on graphs, laplacian_embedding and
+preserve_neighbors on a Graph -- HIP path vs oracle vs the reference's outputs (api.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _orient(A, B):
+    return A * np.sign((A * B).sum(0))[None, :]
+
+
+def _t(a, dtype=torch.float32):
+    return torch.tensor(np.asarray(a), dtype=dtype, device=DEV)
+
+
+def test_pca_matches_reference_and_oracle():
+    import pymde_amd
+    g = load_golden("api")
+    out = pymde_amd.pca(_t(g["pca_Y"]), 3).cpu().numpy()
+    np.testing.assert_allclose(_orient(out, g["pca_out"]), g["pca_out"], atol=2e-4)
+    # ragged widths: 130 features (no MFMA path), 64 features (MFMA Gram), standardized output
+    rng = np.random.default_rng(5)
+    for n, k, m in ((1000, 130, 4), (513, 64, 2), (70, 7, 7)):
+        Y = (rng.standard_normal((n, k)) * np.linspace(3.0, 0.5, k)).astype(np.float32)
+        out = pymde_amd.pca(_t(Y), m).cpu().numpy().astype(np.float64)
+        want = oracle.pca(Y, m)
+        np.testing.assert_allclose(_orient(out, want), want, atol=5e-3)
+        np.testing.assert_allclose(out.T @ out / n, np.eye(m), atol=1e-4)
+    with pytest.raises(ValueError):
+        pymde_amd.pca(_t(g["pca_Y"]), 7)
+
+
+def test_align_procrustes_rotate():
+    import pymde_amd
+    from pymde_amd import util
+    g = load_golden("api")
+    S, T = _t(g["align_source"]), _t(g["align_target"])
+    np.testing.assert_allclose(util.procrustes(S, T).cpu().numpy(), g["procrustes_out"], atol=1e-5)
+    np.testing.assert_allclose(pymde_amd.align(S, T).cpu().numpy(), g["align_out"], atol=5e-5)
+    np.testing.assert_allclose(pymde_amd.rotate(_t(g["rot_X2"]), torch.tensor(30.0)).cpu().numpy(),
+                               g["rot2_out"], atol=1e-6)
+    np.testing.assert_allclose(
+        pymde_amd.rotate(_t(g["rot_X3"]), torch.tensor([10.0, 20.0, 30.0])).cpu().numpy(),
+        g["rot3_out"], atol=1e-6)
+    with pytest.raises(ValueError):
+        pymde_amd.rotate(_t(g["rot_X2"]), torch.tensor([1.0, 2.0]))
+    with pytest.raises(ValueError):
+        pymde_amd.rotate(_t(np.zeros((4, 4))), torch.tensor(1.0))
+    # align undoes an exact rotation + keeps the source's mean and column scales
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((5000, 3)).astype(np.float32)
+    q, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    Xr = ((X - X.mean(0)) @ q).astype(np.float32)
+    np.testing.assert_allclose(pymde_amd.align(_t(X), _t(Xr)).cpu().numpy(), oracle.align(X, Xr), atol=2e-4)
+
+
+def test_knn_with_radius_matches_reference():
+    from pymde_amd import preprocess
+    g = load_golden("api")
+    e, w = preprocess.k_nearest_neighbors(_t(g["knnr_data"]), k=4, max_distance=1.6)
+    np.testing.assert_array_equal(e.cpu().numpy(), g["knnr_edges"])
+    np.testing.assert_array_equal(w.cpu().numpy(), g["knnr_weights"])
+    rng = np.random.default_rng(9)
+    Y = rng.standard_normal((700, 12)).astype(np.float32)
+    e, w = preprocess.k_nearest_neighbors(_t(Y), k=6, max_distance=3.5)
+    we, ww = oracle.knn_graph(Y, 6, max_distance=3.5)
+    np.testing.assert_array_equal(e.cpu().numpy(), we)
+    np.testing.assert_array_equal(w.cpu().numpy(), ww)
+
+
+def test_graph_knn_matches_reference_and_oracle():
+    import pymde_amd
+    from pymde_amd import graph as G
+    g = load_golden("api")
+    n = int(g["g_n"])
+    gr = pymde_amd.Graph.from_edges(_t(g["g_edges"], torch.int64), _t(g["g_lengths"]), n_items=n)
+    for tag, kw in (("sp", {"graph_distances": True}),
+                    ("spr", {"graph_distances": True, "max_distance": 1.5}),
+                    ("direct", {"graph_distances": False})):
+        e, w = G.k_nearest_neighbors(gr, 3, **kw)
+        np.testing.assert_array_equal(e.cpu().numpy(), g["gknn_%s_edges" % tag])
+        np.testing.assert_array_equal(w.cpu().numpy(), g["gknn_%s_weights" % tag])
+    e, w = G.k_nearest_neighbors(gr, 3, graph_distances=False, max_distance=1.2)
+    we, ww = oracle.graph_knn(n, g["g_edges"], g["g_lengths"], k=3, direct=True, max_distance=1.2)
+    np.testing.assert_array_equal(e.cpu().numpy(), we)
+    np.testing.assert_array_equal(w.cpu().numpy(), ww)
+    # larger weighted graph with several components and isolated nodes; unweighted graph (BFS,
+    # distance ties broken by index in both implementations)
+    rng = np.random.default_rng(3)
+    n = 600
+    ed = np.unique(np.sort(rng.integers(0, n - 20, (1500, 2)), 1), axis=0)
+    ed = ed[ed[:, 0] != ed[:, 1]]
+    for lengths in (rng.uniform(0.5, 3.0, len(ed)).astype(np.float32), None):
+        gr = pymde_amd.Graph.from_edges(torch.tensor(ed), None if lengths is None else _t(lengths),
+                                        n_items=n, device=DEV)
+        for kw, okw in (({"graph_distances": True}, {}),
+                        ({"graph_distances": True, "max_distance": 2.5}, {"max_distance": 2.5}),
+                        ({"graph_distances": False}, {"direct": True})):
+            e, w = G.k_nearest_neighbors(gr, 7, **kw)
+            we, ww = oracle.graph_knn(n, gr.edges.cpu().numpy(),
+                                      None if lengths is None else gr.distances.cpu().numpy(), k=7, **okw)
+            np.testing.assert_array_equal(e.cpu().numpy(), we)
+            np.testing.assert_array_equal(w.cpu().numpy(), ww)
+
+
+def test_recipes_laplacian_embedding_and_neighbors_on_graph():
+    import pymde_amd
+    g = load_golden("api")
+    lap = pymde_amd.laplacian_embedding(_t(g["knnr_data"]), embedding_dim=2, n_neighbors=5, init="random")
+    np.testing.assert_array_equal(lap.edges.cpu().numpy(), g["lap_edges"])
+    np.testing.assert_array_equal(lap.distortion_function.weights.cpu().numpy(), g["lap_weights"])
+    assert type(lap.constraint).__name__ == str(g["lap_constraint"])
+    X = lap.embed(max_iter=200, eps=1e-6)
+    n = X.shape[0]
+    Xn = X.cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(Xn.T @ Xn / n, np.eye(2), atol=1e-4)
+    # the quadratic initialisation IS (numerically) the solution of this problem
+    lapq = pymde_amd.laplacian_embedding(_t(g["knnr_data"]), embedding_dim=2, n_neighbors=5)
+    assert float(lapq.average_distortion(lapq._X_init)) <= float(lap.average_distortion(X)) * (1 + 1e-3)
+    n = int(g["g_n"])
+    gr = pymde_amd.Graph.from_edges(_t(g["g_edges"], torch.int64), _t(g["g_lengths"]), n_items=n)
+    pn = pymde_amd.preserve_neighbors(gr, embedding_dim=2, n_neighbors=3, init="random", seed=0)
+    w = pn.distortion_function.weights.cpu().numpy()
+    np.testing.assert_array_equal(pn.edges.cpu().numpy()[w > 0], g["png_edges_pos"])
+    np.testing.assert_array_equal(w[w > 0], g["png_weights_pos"])
+    # the reference samples the negatives and then drops those that hit positive edges
+    assert int(g["png_n_neg"]) <= int((w < 0).sum()) <= len(g["png_edges_pos"])
+    pn.embed(max_iter=50)
+    assert np.isfinite(float(pn.value))

@@ -132,3 +132,48 @@ def test_knn_graph_against_reference():
     e, w = oracle.knn_graph(g["knn_data"], 15)
     np.testing.assert_array_equal(e, g["knn_edges"])
     np.testing.assert_array_equal(w, g["knn_weights"])
+
+
+def _orient(A, B):
+    """Flip the columns of A to the orientation of B (singular vectors are sign-free)."""
+    return A * np.sign((A * B).sum(0))[None, :]
+
+
+def test_api_helpers_against_reference():
+    # pca / procrustes / align / rotate restatements vs the reference's outputs (api.npz)
+    from conftest import load_golden
+    g = load_golden("api")
+    np.testing.assert_allclose(_orient(oracle.pca(g["pca_Y"], 3), g["pca_out"]), g["pca_out"], atol=5e-6)
+    np.testing.assert_allclose(oracle.procrustes(g["align_source"], g["align_target"]),
+                               g["procrustes_out"], atol=1e-6)
+    np.testing.assert_allclose(oracle.align(g["align_source"], g["align_target"]), g["align_out"], atol=2e-5)
+    np.testing.assert_allclose(oracle.rotate(g["rot_X2"], 30.0), g["rot2_out"], atol=1e-6)
+    np.testing.assert_allclose(oracle.rotate(g["rot_X3"], [10.0, 20.0, 30.0]), g["rot3_out"], atol=1e-6)
+
+
+def test_neighbor_graphs_against_reference():
+    # k-NN with a radius (data matrix), graph k-NN (shortest-path / direct), and the graphs the
+    # recipes laplacian_embedding / preserve_neighbors(Graph) build in the reference
+    from conftest import load_golden
+    g = load_golden("api")
+    e, w = oracle.knn_graph(g["knnr_data"], 4, max_distance=1.6)
+    np.testing.assert_array_equal(e, g["knnr_edges"])
+    np.testing.assert_array_equal(w, g["knnr_weights"])
+    n = int(g["g_n"])
+    for tag, kw in (("sp", {}), ("spr", {"max_distance": 1.5}), ("direct", {"direct": True})):
+        e, w = oracle.graph_knn(n, g["g_edges"], g["g_lengths"], k=3, **kw)
+        np.testing.assert_array_equal(e, g["gknn_%s_edges" % tag])
+        np.testing.assert_array_equal(w, g["gknn_%s_weights" % tag])
+    # direct neighbours with a radius: the reference still hands out neighbours beyond the radius to
+    # nodes with fewer than k inside it (argsort over +inf); the restatement keeps the documented
+    # meaning, so its graph is the reference's minus those extra edges
+    e, w = oracle.graph_knn(n, g["g_edges"], g["g_lengths"], k=3, direct=True, max_distance=1.2)
+    ref = set(map(tuple, g["gknn_directr_edges"].tolist()))
+    assert set(map(tuple, e.tolist())) <= ref and len(e) < len(ref)
+    e, w = oracle.knn_graph(g["knnr_data"], 5)
+    np.testing.assert_array_equal(e, g["lap_edges"])
+    np.testing.assert_array_equal(w, g["lap_weights"])
+    assert str(g["lap_constraint"]) == "_Standardized"
+    e, w = oracle.graph_knn(n, g["g_edges"], g["g_lengths"], k=3)
+    np.testing.assert_array_equal(e, g["png_edges_pos"])
+    np.testing.assert_array_equal(w, g["png_weights_pos"])
