@@ -120,7 +120,8 @@ typedef struct mde_func {
   int32_t kind_neg;  /* MDE_F_NONE, or the repulsive branch of a PushAndPull              */
   const float* a0;   /* device; per-edge weights / deviations.  Order: see each call      */
   const float* a1;   /* device; second per-edge array (weighted losses) or NULL           */
-  int32_t a0_scalar; /* 1: a0 points at ONE value broadcast to every edge (nelement()==1) */
+  int32_t a0_scalar; /* 1: a0 points at ONE value broadcast to every edge (nelement()==1);
+                        2: a0 is a codebook stream written by mde_plan_expand_codebook (layout 1) */
   int32_t a1_scalar;
   float s0, s1, s2;  /* scalars of `kind`                                                 */
   float n0, n1, n2;  /* scalars of `kind_neg`                                             */
@@ -175,6 +176,15 @@ int mde_plan_layout(mde_plan* plan, int32_t d, void* stream);
 /* Entries of a per-half-edge parameter array in `layout` (layout 1 pads every per-wave tile
  * slice to whole 64-entry wave iterations, so it is larger than mde_plan_half_edges). */
 int64_t mde_plan_layout_half_edges(const mde_plan* plan, int32_t layout);
+/* Parameter codebook for layout 1 at d = 2: when `in_edge` [p] holds at most 8 distinct values
+ * (k-NN weights 1 / 2, -1 for repulsive pairs, ...) write to out_half
+ * [mde_plan_layout_half_edges(plan, 1)] the packed half-edge words with the value index in their 3
+ * low bits, followed by the 8-entry value table, and set *n_values_host to the number of values;
+ * the fused kernel then streams 4 instead of 8 bytes per half-edge (mde_func.a0 = out_half,
+ * a0_scalar = 2).  *n_values_host = 0: not applicable, nothing written -- use
+ * mde_plan_expand_layout.  Results are identical either way.  SYNC. */
+int mde_plan_expand_codebook(const mde_plan* plan, const float* in_edge, float* out_half,
+                             int32_t* n_values_host, void* stream);
 int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in_edge,
                            float* out_half, void* stream);
 

@@ -87,6 +87,21 @@ class EdgePlan(object):
                                                   _lib.ptr(out), _lib.stream_ptr(self.device)))
         return out
 
+    def expand_codebook(self, per_edge):
+        """Layout 1 only: the codebook form of a per-edge array with at most 8 distinct values
+        (``mde_plan_expand_codebook``), or None when it does not apply."""
+        lib = _lib.load()
+        t = per_edge.detach().to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
+        if t.numel() != self.p:
+            return None
+        size = int(lib.mde_plan_layout_half_edges(self._handle, 1))
+        out = torch.empty(max(size, 1), dtype=torch.float32, device=self.device)
+        nv = ctypes.c_int32(0)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.mde_plan_expand_codebook(self._handle, _lib.ptr(t), _lib.ptr(out),
+                                                    ctypes.byref(nv), _lib.stream_ptr(self.device)))
+        return out if nv.value > 0 else None
+
     def csr(self):
         """(rowptr, nbr, eid) as int32 tensors (copies; for tests and debugging)."""
         lib = _lib.load()
@@ -119,6 +134,7 @@ class Binding(object):
         self._struct = None
         self._keep = None
         self._key = None
+        self.codebook = False
 
     @property
     def fused(self):
@@ -147,9 +163,18 @@ class Binding(object):
                 if a.numel() == 1:
                     return a.detach().to(device=plan.device, dtype=torch.float32).reshape(1).contiguous()
                 return plan.expand(a, layout)
-            a0, a1 = prep(spec.a0), prep(spec.a1)
+            # few distinct first parameters (k-NN weights): 4-byte codebook stream instead of 8 bytes
+            a0 = None
+            if layout == 1 and spec.a0 is not None and spec.a0.numel() > 1:
+                a0 = plan.expand_codebook(spec.a0)
+            self.codebook = a0 is not None
+            if a0 is None:
+                a0 = prep(spec.a0)
+            a1 = prep(spec.a1)
             self._keep = (a0, a1)
             self._struct = spec.to_struct(a0, a1)
+            if self.codebook:
+                self._struct.a0_scalar = 2
             self._struct.layout = layout
             self._key = key
             self.spec = spec

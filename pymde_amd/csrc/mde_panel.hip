@@ -36,6 +36,8 @@
 #define MDE_PANEL_XC_OFF 65504
 #define MDE_PANEL_XC_BYTES 98304
 #define MDE_PANEL_DUMMY ((uint32_t)MDE_PANEL_GR_OFF << 17)  // padding entry: row address past every real row
+#define MDE_PANEL_CB_VALUES 8   // parameter codebook entries (3 free low bits of the packed word at d = 2)
+#define MDE_PANEL_CB_OFF (MDE_PANEL_XC_OFF + MDE_PANEL_XC_BYTES)  // LDS: the value table (32 bytes)
 
 // ---------------------------------------------------------------- layout construction
 __global__ __launch_bounds__(MDE_BLOCK) void k_panel_keys(int nrows, const int32_t* __restrict__ rowptr,
@@ -349,10 +351,134 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_expand_panel(int64_t H, const int
     out[q] = eid[q] >= 0 ? in[eid[q]] : 1.0f;  // padding entries carry a harmless parameter
 }
 
-// number of entries of a per-half-edge parameter array in the given layout
+// number of entries of a per-half-edge parameter array in the given layout (layout 1: the padded
+// stream + MDE_PANEL_CB_VALUES spare entries, where a codebook stream keeps its value table)
 extern "C" int64_t mde_plan_layout_half_edges(const mde_plan* plan, int32_t layout) {
   if (!plan) return 0;
-  return (layout == 1 && plan->panel.packed) ? plan->panel.H : plan->H;
+  return (layout == 1 && plan->panel.packed) ? plan->panel.H + MDE_PANEL_CB_VALUES : plan->H;
+}
+
+// ---------------------------------------------------------------- parameter codebooks
+// Neighbour-graph problems carry very few distinct per-edge parameters (k-NN weights 1 / 2, -1 for
+// repulsive pairs).  At d = 2 the packed word's panel offset is a multiple of 8, so its 3 low bits
+// can hold an index into a table of <= 8 values: the kernel then streams 4 bytes per half-edge
+// instead of 8 (packed word + fp32 parameter) and looks the parameter up in LDS.
+#define MDE_CB_EMPTY 0xFFFFFFFFu  // (a NaN pattern: NaN parameters simply disable the codebook)
+
+// distinct bit patterns of in[0..p): inserted into table[0..8) with compare-and-swap; *overflow is
+// set when a 9th value (or the EMPTY pattern) shows up
+__global__ __launch_bounds__(MDE_BLOCK) void k_codebook_scan(int64_t p, const float* __restrict__ in,
+                                                             unsigned int* __restrict__ table,
+                                                             int* __restrict__ overflow) {
+  __shared__ unsigned int stb[MDE_PANEL_CB_VALUES];
+  if (threadIdx.x < MDE_PANEL_CB_VALUES) stb[threadIdx.x] = MDE_CB_EMPTY;
+  __syncthreads();
+  unsigned int last0 = MDE_CB_EMPTY, last1 = MDE_CB_EMPTY;
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < p;
+       i += (int64_t)gridDim.x * MDE_BLOCK) {
+    const unsigned int v = __float_as_uint(in[i]);
+    if (v == last0 || v == last1) continue;
+    last1 = last0;
+    last0 = v;
+    bool known = false;
+#pragma unroll
+    for (int s = 0; s < MDE_PANEL_CB_VALUES; ++s) known |= (stb[s] == v);
+    if (known) continue;
+    if (v == MDE_CB_EMPTY || *reinterpret_cast<volatile int*>(overflow)) {
+      *overflow = 1;
+      return;
+    }
+    bool placed = false;
+    for (int s = 0; s < MDE_PANEL_CB_VALUES && !placed; ++s) {
+      const unsigned int old = atomicCAS(&table[s], MDE_CB_EMPTY, v);
+      placed = (old == MDE_CB_EMPTY || old == v);
+    }
+    if (!placed) {
+      *overflow = 1;
+      return;
+    }
+    for (int s = 0; s < MDE_PANEL_CB_VALUES; ++s) {  // remember it block-wide
+      const unsigned int old = atomicCAS(&stb[s], MDE_CB_EMPTY, v);
+      if (old == MDE_CB_EMPTY || old == v) break;
+    }
+  }
+}
+
+// out[q] = packed[q] | index of in[eid[q]] in table (padding entries stay MDE_PANEL_DUMMY)
+__global__ __launch_bounds__(MDE_BLOCK) void k_codebook_pack(int64_t H, const uint32_t* __restrict__ packed,
+                                                             const int32_t* __restrict__ eid,
+                                                             const float* __restrict__ in,
+                                                             const unsigned int* __restrict__ table,
+                                                             uint32_t* __restrict__ out) {
+  unsigned int tb[MDE_PANEL_CB_VALUES];
+#pragma unroll
+  for (int s = 0; s < MDE_PANEL_CB_VALUES; ++s) tb[s] = table[s];
+  for (int64_t q = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; q < H;
+       q += (int64_t)gridDim.x * MDE_BLOCK) {
+    uint32_t w = packed[q];
+    if (eid[q] >= 0) {
+      const unsigned int v = __float_as_uint(in[eid[q]]);
+      uint32_t idx = 0;
+#pragma unroll
+      for (int s = 1; s < MDE_PANEL_CB_VALUES; ++s) idx = (tb[s] == v) ? (uint32_t)s : idx;
+      w |= idx;
+    }
+    out[q] = w;
+  }
+}
+
+// Try to put a per-edge parameter array into codebook form for layout 1.  On success
+// (*n_values_host in 1..8) out_half holds the H packed words with the value index in their 3 low
+// bits, followed by the 8-entry value table; pass it as mde_func.a0 with a0_scalar = 2.
+// *n_values_host = 0: not applicable (d != 2, more than 8 distinct values, NaNs) -- nothing is
+// written and the caller uses mde_plan_expand_layout.  SYNC.
+extern "C" int mde_plan_expand_codebook(const mde_plan* plan, const float* in_edge, float* out_half,
+                                        int32_t* n_values_host, void* stream) {
+  if (!plan || !in_edge || !out_half || !n_values_host) return MDE_E_INVALID;
+  *n_values_host = 0;
+  const mde_panel_layout& L = plan->panel;
+  if (!L.packed || L.d != 2 || L.H == 0 || plan->p == 0) return MDE_OK;
+  const char* e = getenv("MDE_CODEBOOK");
+  if (e && atoi(e) == 0) return MDE_OK;
+  hipStream_t st = mde_stream(stream);
+  unsigned int* table = reinterpret_cast<unsigned int*>(out_half) + L.H;  // the spare entries
+  int* overflow = nullptr;
+  MDE_HIP(hipMalloc(&overflow, sizeof(int)));
+  hipError_t err = hipMemsetAsync(overflow, 0, sizeof(int), st);
+  if (err == hipSuccess) err = hipMemsetAsync(table, 0xFF, MDE_PANEL_CB_VALUES * sizeof(unsigned int), st);
+  unsigned int host_tb[MDE_PANEL_CB_VALUES];
+  int host_overflow = 0;
+  if (err == hipSuccess) {
+    hipLaunchKernelGGL(k_codebook_scan, dim3(mde_grid(plan->p, MDE_BLOCK, 2048)), dim3(MDE_BLOCK), 0, st, plan->p,
+                       in_edge, table, overflow);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipMemcpyAsync(host_tb, table, sizeof(host_tb), hipMemcpyDeviceToHost, st);
+  if (err == hipSuccess) err = hipMemcpyAsync(&host_overflow, overflow, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (err == hipSuccess) err = hipStreamSynchronize(st);
+  (void)hipFree(overflow);
+  if (err != hipSuccess) return mde_hip_fail(err, "parameter codebook scan", __FILE__, __LINE__);
+  if (host_overflow) return MDE_OK;
+  // canonical order (the insertion order above depends on scheduling): ascending bit patterns
+  int nv = 0;
+  unsigned int vals[MDE_PANEL_CB_VALUES];
+  for (int s = 0; s < MDE_PANEL_CB_VALUES; ++s)
+    if (host_tb[s] != MDE_CB_EMPTY) vals[nv++] = host_tb[s];
+  if (nv == 0) return MDE_OK;
+  for (int a = 1; a < nv; ++a)
+    for (int b = a; b > 0 && vals[b - 1] > vals[b]; --b) {
+      const unsigned int t = vals[b];
+      vals[b] = vals[b - 1];
+      vals[b - 1] = t;
+    }
+  for (int s = nv; s < MDE_PANEL_CB_VALUES; ++s) vals[s] = MDE_CB_EMPTY;
+  MDE_HIP(hipMemcpyAsync(table, vals, sizeof(vals), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_codebook_pack, dim3(mde_grid(L.H, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, L.H, L.packed,
+                     L.eid, in_edge, table, reinterpret_cast<uint32_t*>(out_half));
+  MDE_LAUNCH_CHECK();
+  MDE_HIP(hipStreamSynchronize(st));  // `vals` is a stack buffer
+  *n_values_host = nv;
+  return MDE_OK;
 }
 
 extern "C" int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in_edge,
@@ -431,7 +557,9 @@ __device__ __forceinline__ void panel_st(char* p, const float (&v)[D]) {
   }
 }
 
-template <int D, class Fn, bool HAS_GRAD>
+// CB: the first parameter comes from a codebook -- `packed` is the stream with value indices in its
+// 3 low bits (mde_plan_expand_codebook), a0 the 8-entry value table; no parameter stream is read.
+template <int D, class Fn, bool HAS_GRAD, bool CB>
 __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
     int nloc, int row_lo, int n, int P_R, int P_C, int NP, int Q, const int32_t* __restrict__ next_tile,
     const int32_t* __restrict__ sub_off, const uint32_t* __restrict__ packed,
@@ -442,7 +570,7 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
   constexpr int GR_OFF = MDE_PANEL_GR_OFF, XC_OFF = MDE_PANEL_XC_OFF;
   constexpr uint32_t DUMMY = MDE_PANEL_DUMMY;
   // statically sized: the LDS addresses unpacked from the stream are absolute
-  __shared__ __attribute__((aligned(16))) char L[MDE_PANEL_XC_OFF + MDE_PANEL_XC_BYTES];
+  __shared__ __attribute__((aligned(16))) char L[MDE_PANEL_CB_OFF + 4 * MDE_PANEL_CB_VALUES];
   float* XR = reinterpret_cast<float*>(L);            // x_v of the block's rows (padded slots)
   float* GR = reinterpret_cast<float*>(L + GR_OFF);   // gradient accumulators (same slots)
   float* XC = reinterpret_cast<float*>(L + XC_OFF);   // x_u of the current panel
@@ -454,7 +582,8 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
   const int cp_lo = (int)(((int64_t)NP * qg) / Q), cp_hi = (int)(((int64_t)NP * (qg + 1)) / Q);
   const int r0 = rb * P_R;
   const int nr = min(P_R, nloc - r0);
-  const float a0s = a0_scalar ? a0[0] : 1.0f;
+  const float a0s = (a0_scalar && !CB) ? a0[0] : 1.0f;
+  if (CB && tid < MDE_PANEL_CB_VALUES) reinterpret_cast<float*>(L + MDE_PANEL_CB_OFF)[tid] = a0[tid];
   const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
   const bool a1_arr = a1 && !a1_scalar;
   const float* Xrow = X + (size_t)(row_lo + r0) * D;
@@ -476,7 +605,8 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
   // are masked out of the loss and of the accumulator update)
   auto process = [&](uint32_t pk, float p0, float p1) __attribute__((always_inline)) {
     const bool active = pk != DUMMY;
-    const uint32_t rowaddr = pk >> 17, coladdr = pk & 0x1ffffu;
+    const uint32_t rowaddr = pk >> 17, coladdr = pk & (CB ? 0x1fff8u : 0x1ffffu);
+    if (CB) p0 = *reinterpret_cast<const float*>(L + MDE_PANEL_CB_OFF + ((pk & 7u) << 2));
     float xr[D], xc[D], v[D], ss = 0.0f;
     panel_ld<D>(L + rowaddr, xr);
     panel_ld<D>(L + XC_OFF + coladdr, xc);
@@ -543,8 +673,8 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
   panel_f4 stgA[STG], stgB[STG];
   uint32_t pk[MAXI];
   float wv[MAXI];
-  const unsigned wlane = a0_scalar ? 0u : ulane;
-  const int wstride = a0_scalar ? 0 : 64;
+  const unsigned wlane = (a0_scalar || CB) ? 0u : ulane;
+  const int wstride = (a0_scalar || CB) ? 0 : 64;
   struct PanelSrc {
     const panel_f4* s4;
     int last;
@@ -603,7 +733,7 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
   auto load_stream_slot = [&](const StreamSrc& src, int k) __attribute__((always_inline)) {
     const int kk = min(k, src.kmax);  // wave-uniform: scalar base + the lane as the only vector offset
     pk[k] = (src.pb + (size_t)kk * 64)[ulane];
-    wv[k] = (src.ab + (size_t)kk * wstride)[wlane];
+    if (!CB) wv[k] = (src.ab + (size_t)kk * wstride)[wlane];
   };
   auto next_nonempty = [&](int cp) __attribute__((always_inline)) {  // cp <= NP
     return __builtin_amdgcn_readfirstlane(nt[cp]);
@@ -627,13 +757,13 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
       load_panel_part(psrc, scur, k * PPS, (k + 1) * PPS);
       if (k < cK) {
         const float p1 = a1_arr ? a1[(size_t)(cb + k) * 64 + ulane] : a1s;
-        process(pk[k], wv[k], p1);
+        process(pk[k], CB ? 0.0f : wv[k], p1);
       }
       load_stream_slot(ssrc, k);
     }
     for (int k = MAXI; k < cK; ++k) {  // oversized slices (skewed degrees): not prefetched
       const size_t h = (size_t)(cb + k) * 64 + ulane;
-      const float p0 = a0_scalar ? a0s : a0[h];
+      const float p0 = (a0_scalar || CB) ? a0s : a0[h];
       const float p1 = a1_arr ? a1[h] : a1s;
       process(packed[h], p0, p1);
     }
@@ -714,13 +844,24 @@ struct PanelArgs {
 template <int D, class Fn>
 static int launch_panel(const PanelArgs& A, const Fn& fn, int* nblocks) {
   const mde_panel_layout& L = A.plan->panel;
-  auto kern = A.grad ? k_fused_panel<D, Fn, true> : k_fused_panel<D, Fn, false>;
+  const bool cb = A.a0_scalar == 2;
+  if (cb && D != 2) {
+    mde_set_error("codebook parameter streams exist for d = 2 only");
+    return MDE_E_INVALID;
+  }
+  auto kern = A.grad ? k_fused_panel<D, Fn, true, false> : k_fused_panel<D, Fn, false, false>;
+  if constexpr (D == 2) {
+    if (cb) kern = A.grad ? k_fused_panel<D, Fn, true, true> : k_fused_panel<D, Fn, false, true>;
+  }
+  // codebook form: a0 = [H packed words | 8 values]
+  const uint32_t* stream = cb ? reinterpret_cast<const uint32_t*>(A.a0) : L.packed;
+  const float* a0 = cb ? A.a0 + L.H : A.a0;
   const int Q = L.col_groups;
   *nblocks = L.n_row_blocks * Q;
   hipLaunchKernelGGL(kern, dim3(L.n_row_blocks * Q), dim3(MDE_PANEL_BS), 0, A.st,
                      (int)(A.plan->row_hi - A.plan->row_lo), (int)A.plan->row_lo, (int)A.plan->n,
-                     L.rows_per_block, L.cols_per_panel, L.n_panels, Q, L.next_tile, L.sub_off, L.packed,
-                     A.a0, A.a1, A.a0_scalar, A.a1_scalar, A.X, A.grad, L.partial, A.plan->partials, fn,
+                     L.rows_per_block, L.cols_per_panel, L.n_panels, Q, L.next_tile, L.sub_off, stream,
+                     a0, A.a1, A.a0_scalar, A.a1_scalar, A.X, A.grad, L.partial, A.plan->partials, fn,
                      A.inv_p, A.grad_scale);
   MDE_LAUNCH_CHECK();
   if (Q > 1 && A.grad) {

@@ -169,13 +169,14 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_colsum(int64_t n, int d, int dp,
   }
 }
 // mean[c] = (sum_b partial[b][c]) / n
-__global__ void k_colsum_final(int nb, int d, int64_t n, const double* __restrict__ partial,
-                               double* __restrict__ mean) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d) return;
+// (one wave per column: lane-strided partial sums + a fixed-order wave reduction)
+__global__ __launch_bounds__(64) void k_colsum_final(int nb, int d, int64_t n, const double* __restrict__ partial,
+                                                     double* __restrict__ mean) {
+  const int c = blockIdx.x;
   double s = 0.0;
-  for (int b = 0; b < nb; ++b) s += partial[(int64_t)b * d + c];
-  mean[c] = s / (double)n;
+  for (int b = threadIdx.x; b < nb; b += 64) s += partial[(int64_t)b * d + c];
+  s = mde_wave_sum(s);
+  if (threadIdx.x == 0) mean[c] = s / (double)n;
 }
 __global__ __launch_bounds__(MDE_BLOCK) void k_sub_mean(int64_t N, int d, float* __restrict__ Z,
                                                         const double* __restrict__ mean) {
@@ -199,7 +200,7 @@ static int center_impl(int64_t n, int d, float* Z, double* work, hipStream_t st)
   int nb = mde_grid(n, rpp * 8, MDE_RED_BLOCKS);
   hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(MDE_BLOCK), 0, st, n, d, dp, Z, partial);
   MDE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_colsum_final, dim3((d + 63) / 64), dim3(64), 0, st, nb, d, n, partial, mean);
+  hipLaunchKernelGGL(k_colsum_final, dim3(d), dim3(64), 0, st, nb, d, n, partial, mean);
   MDE_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sub_mean, dim3(mde_grid(n * d, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, n * d, d, Z,
                      mean);
@@ -317,7 +318,16 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_gram_mfma(int64_t n, int da, int 
   }
 }
 
-// out[q] = sum_c partial[q * nc + c]
+// out[q] = sum_c partial[q * nc + c]: one wave per output entry (small outputs; a serial loop per
+// entry is latency-bound) or one thread per entry (large outputs)
+__global__ __launch_bounds__(64) void k_gram_final_wave(int nc, const double* __restrict__ partial,
+                                                        double* __restrict__ out) {
+  const int64_t q = blockIdx.x;
+  double s = 0.0;
+  for (int c = threadIdx.x; c < nc; c += 64) s += partial[q * nc + c];
+  s = mde_wave_sum(s);
+  if (threadIdx.x == 0) out[q] = s;
+}
 __global__ void k_gram_final(int64_t m, int nc, const double* __restrict__ partial,
                              double* __restrict__ out) {
   for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < m;
@@ -341,7 +351,7 @@ static int gram_impl(int64_t n, int da, int db, const float* A, const float* B, 
     const int nb = mde_grid(n, MDE_BLOCK * 2, MDE_RED_BLOCKS);                                      \
     hipLaunchKernelGGL((k_gram_tiny<DA_, DB_>), dim3(nb), dim3(MDE_BLOCK), 0, st, n, A, B, partial); \
     MDE_LAUNCH_CHECK();                                                                             \
-    hipLaunchKernelGGL(k_gram_final, dim3(1), dim3(64), 0, st, m, nb, partial, out);                \
+    hipLaunchKernelGGL(k_gram_final_wave, dim3((unsigned)m), dim3(64), 0, st, nb, partial, out);    \
     MDE_LAUNCH_CHECK();                                                                             \
     return MDE_OK;                                                                                  \
   }
@@ -378,8 +388,11 @@ static int gram_impl(int64_t n, int da, int db, const float* A, const float* B, 
                        da, db, A, B, rpc, tiles_j, partial);
   }
   MDE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_gram_final, dim3(mde_grid(m, 256, 256)), dim3(256), 0, st, m, (int)nc, partial,
-                     out);
+  if (m <= 65536)
+    hipLaunchKernelGGL(k_gram_final_wave, dim3((unsigned)m), dim3(64), 0, st, (int)nc, partial, out);
+  else
+    hipLaunchKernelGGL(k_gram_final, dim3(mde_grid(m, 256, 256)), dim3(256), 0, st, m, (int)nc, partial,
+                       out);
   MDE_LAUNCH_CHECK();
   return MDE_OK;
 }

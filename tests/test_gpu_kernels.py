@@ -408,6 +408,7 @@ import pymde_amd
 from pymde_amd import _lib
 rng = np.random.default_rng(7)
 for (n, p, d, fname) in [(30000, 400000, 2, 'log1p'), (30000, 400000, 2, 'pushpull'), (50000, 300000, 3, 'quad'),
+                         (30000, 400000, 2, 'log1p_cb'), (70001, 500003, 2, 'pushpull_cb'), (20000, 250000, 3, 'quad_cb'),
                          (20000, 250000, 1, 'absolute'), (70001, 500003, 2, 'pushpull_lr'), (9000, 200000, 4, 'huber')]:
     i = rng.integers(0, n, p); j = (i + 1 + rng.integers(0, n - 1, p)) %% n
     # hub vertices (degree ~ p/20 and p/50): rows with far more entries per tile than a wave has
@@ -423,8 +424,15 @@ for (n, p, d, fname) in [(30000, 400000, 2, 'log1p'), (30000, 400000, 2, 'pushpu
     w = np.where(rng.random(p) < 0.3, -1.0, rng.uniform(0.5, 2.0, p)).astype(np.float32)
     dev = rng.uniform(0.3, 2.0, p).astype(np.float32)
     pen, los = pymde_amd.penalties, pymde_amd.losses
+    if fname.endswith('_cb'):
+        # few distinct weights (a k-NN graph's 1 / 2, -1 for repulsive pairs): at d = 2 the panel
+        # layout streams them as a codebook index inside the packed word
+        w = rng.choice(np.array([-1.0, 1.0, 2.0], dtype=np.float32), size=p, p=[0.3, 0.4, 0.3])
     wt, dt = torch.tensor(w, device='cuda'), torch.tensor(dev, device='cuda')
     f, fd = {
+        'log1p_cb': (pen.Log1p(wt.abs()), oracle.func('LOG1P', np.abs(w), None, (1.5,))),
+        'pushpull_cb': (pen.PushAndPull(wt, pen.Log1p, pen.Log), oracle.func('LOG1P', w, None, (1.5,), 'LOG', (1.0,))),
+        'quad_cb': (pen.Quadratic(wt.abs()), oracle.func('QUADRATIC', np.abs(w))),
         'log1p': (pen.Log1p(wt.abs()), oracle.func('LOG1P', np.abs(w), None, (1.5,))),
         'pushpull': (pen.PushAndPull(wt, pen.Log1p, pen.Log), oracle.func('LOG1P', w, None, (1.5,), 'LOG', (1.0,))),
         'pushpull_lr': (pen.PushAndPull(wt), oracle.func('LOG1P', w, None, (1.5,), 'LOGRATIO', (2.0,))),
@@ -436,6 +444,7 @@ for (n, p, d, fname) in [(30000, 400000, 2, 'log1p'), (30000, 400000, 2, 'pushpu
     Xt = torch.tensor(X, device='cuda', requires_grad=True)
     E = mde.average_distortion(Xt); E.backward()
     assert mde._binding().struct(d).layout == %d, 'unexpected layout'
+    assert mde._binding().codebook == (fname.endswith('_cb') and d == 2 and mde._binding().struct(d).layout == 1), fname
     wE, wg = oracle.average_distortion(edges, X, fd)
     assert abs(float(E) - wE) <= 1e-5 * abs(wE), (fname, float(E), wE)
     err = np.abs(Xt.grad.cpu().numpy() - wg).max()

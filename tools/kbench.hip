@@ -206,6 +206,27 @@ int main(int argc, char** argv) {
     fp.n0 = 1.0f;
     t = time_ms([&]() { MK(mde_average_distortion(plan, X, 2, &fp, 1.0f, grad, loss, st)); }, reps, st);
     printf("fused PushPull(Log1p,Log) d=2 (all w>0): %.3f ms\n", t);
+    if (layout == 1) {
+      float* wcb;
+      CK(hipMalloc(&wcb, (size_t)Hl * 4));
+      int nv = 0;
+      MK(mde_plan_expand_codebook(plan, w, wcb, &nv, st));
+      printf("parameter codebook: %d distinct values\n", nv);
+      if (nv > 0) {
+        mde_func fc = f;
+        fc.a0 = wcb;
+        fc.a0_scalar = 2;
+        t = time_ms([&]() { MK(mde_average_distortion(plan, X, 2, &fc, 1.0f, grad, loss, st)); }, reps, st);
+        CK(hipMemcpy(&hl, loss, 4, hipMemcpyDeviceToHost));
+        printf("fused Log1p d=2, codebook stream (4 B/half-edge): %.3f ms  %.3e edges/s  alg %.2f TB/s (%.1f%% of 8 TB/s)  loss=%.6f\n",
+               t, p / (t * 1e-3), alg_bytes / (t * 1e-3) / 1e12, 100.0 * alg_bytes / (t * 1e-3) / 8e12, hl);
+        mde_func fcp = fc;
+        fcp.kind_neg = MDE_F_LOG;
+        fcp.n0 = 1.0f;
+        t = time_ms([&]() { MK(mde_average_distortion(plan, X, 2, &fcp, 1.0f, grad, loss, st)); }, reps, st);
+        printf("fused PushPull(Log1p,Log) d=2, codebook stream: %.3f ms\n", t);
+      }
+    }
   }
   if (!getenv("MDE_GROUP") && layout == 0) {
     const int* nbr = mde_plan_nbr(plan);

@@ -1,0 +1,254 @@
+// panelprobe.hip -- how fast can 256 workgroups each pull the same table through L2 into LDS?
+// (design probe for the panel kernel's staging path; not part of the product)
+//   ./panelprobe [table_MB] [reps]
+// Variants: A reg-staged (global_load_dwordx4 -> VGPR -> ds_write_b128), one panel ahead
+//           B the same, workgroups of an XCD start at S different panels (stagger)
+//           C LDS-DMA (global_load_lds_dwordx4), two 48 KB half panels, one half ahead
+//           D reg-staged + a 40 KB/tile private stream per workgroup (the half-edge stream)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <stdint.h>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define BS 1024
+#define PANEL_BYTES 98304
+#define STG (PANEL_BYTES / 16 / BS)
+
+__global__ __launch_bounds__(BS) void k_regstage(const f4* __restrict__ X, int NP, int stagger, float* out,
+                                                 const f4* __restrict__ stream, int stream_f4_per_tile) {
+  __shared__ __attribute__((aligned(16))) char L[PANEL_BYTES + 32768];
+  f4* d4 = reinterpret_cast<f4*>(L);
+  const int tid = threadIdx.x;
+  const int start = stagger > 1 ? ((blockIdx.x >> 3) % stagger) * (NP / stagger) : 0;
+  f4 stg[STG];
+  f4 acc = {0, 0, 0, 0};
+  const f4* sp = stream + (size_t)blockIdx.x * NP * stream_f4_per_tile;
+  int cp = start;
+#pragma unroll
+  for (int k = 0; k < STG; ++k) stg[k] = X[(size_t)cp * (PANEL_BYTES / 16) + tid + k * BS];
+  for (int t = 0; t < NP; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < STG; ++k) d4[tid + k * BS] = stg[k];
+    __syncthreads();
+    const int cpn = (cp + 1 == NP) ? 0 : cp + 1;
+#pragma unroll
+    for (int k = 0; k < STG; ++k) stg[k] = X[(size_t)cpn * (PANEL_BYTES / 16) + tid + k * BS];
+    for (int i = tid; i < stream_f4_per_tile; i += BS) acc += sp[(size_t)t * stream_f4_per_tile + i];
+    acc += d4[(tid * 7 + t) & 4095];
+    cp = cpn;
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
+}
+
+__global__ __launch_bounds__(BS) void k_ldsdma(const f4* __restrict__ X, int NP, float* out) {
+  __shared__ __attribute__((aligned(16))) char L[PANEL_BYTES + 32768];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  f4 acc = {0, 0, 0, 0};
+  f4* d4 = reinterpret_cast<f4*>(L);
+  // half panels of 48 KB = 3 x 16 KB; wave w copies 1 KB chunks w, w+16, w+32 of each half
+  auto issue = [&](int half_idx /* global half-panel index */, int buf) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const size_t g = (size_t)half_idx * 3072 + (size_t)(k * 16 + wave) * 64 + lane;  // in f4 units
+      char* dst = L + buf * 49152 + (k * 16 + wave) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + g),
+                                       (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+    }
+  };
+  const int NH = NP * 2;
+  issue(0, 0);
+  for (int h = 0; h < NH; ++h) {
+    const int hn = (h + 1 == NH) ? 0 : h + 1;
+    // the other buffer was consumed before the previous barrier: refill it, then wait for ours
+    issue(hn, (h + 1) & 1);
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    acc += d4[(h & 1) * 3072 + ((tid * 7 + h) & 2047)];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;
+}
+
+
+// E: the panel kernel's exact data movement (no math): panels two tiles ahead through two register
+// sets, a per-wave private stream of SL loads per tile refilled in place one tile ahead.
+// WIDE = 0: dword loads (SL = 12 per lane), WIDE = 1: dwordx4 loads (3 per lane).
+__device__ __forceinline__ float busy(float a, int iters) {
+  for (int i = 0; i < iters; ++i) a = fmaf(a, 1.0000001f, 1e-9f);
+  return a;
+}
+template <int WIDE>
+__global__ __launch_bounds__(BS) void k_kernel_like(const f4* __restrict__ X, int NP, float* out,
+                                                    const float* __restrict__ stream, int work) {
+  __shared__ __attribute__((aligned(16))) char L[PANEL_BYTES + 32768];
+  f4* d4 = reinterpret_cast<f4*>(L);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  f4 sA[STG], sB[STG];
+  float acc = 0.f;
+  constexpr int SL = WIDE ? 3 : 12;
+  float sr[12];
+  // stream: per (workgroup, tile, wave) 12 * 64 floats
+  const float* sp = stream + ((size_t)blockIdx.x * NP * 16 + wave) * 768;
+  auto load_stream = [&](int t) {
+    const float* q = sp + (size_t)t * 16 * 768;
+    if (WIDE) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const f4 v = reinterpret_cast<const f4*>(q)[k * 64 + lane];
+        sr[4 * k] = v.x; sr[4 * k + 1] = v.y; sr[4 * k + 2] = v.z; sr[4 * k + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) sr[k] = q[k * 64 + lane];
+    }
+  };
+  auto load_panel = [&](int cp, f4 (&stg)[STG]) {
+#pragma unroll
+    for (int k = 0; k < STG; ++k) stg[k] = X[(size_t)cp * (PANEL_BYTES / 16) + tid + k * BS];
+  };
+  auto step = [&](int t, f4 (&stg)[STG]) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < STG; ++k) d4[tid + k * BS] = stg[k];
+    __syncthreads();
+    float use = 0.f;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) use += sr[k];
+    acc += use + d4[(tid * 7 + t) & 4095].x;
+    load_panel((t + 2) % NP, stg);
+    load_stream((t + 1) % NP);
+    acc = busy(acc, work);
+  };
+  load_panel(0, sA);
+  load_panel(1, sB);
+  load_stream(0);
+  for (int t = 0; t < NP; t += 2) {
+    step(t, sA);
+    if (t + 1 < NP) step(t + 1, sB);
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+// F: LDS-DMA half panels (one half ahead) + the same private stream; every load is inline asm so
+// that the wait counts are ours (the compiler drains vmcnt to 0 around LDS-DMA otherwise)
+template <int WIDE>
+__global__ __launch_bounds__(BS) void k_dma_stream(const f4* __restrict__ X, int NP, float* out,
+                                                   const float* __restrict__ stream, int work) {
+  __shared__ __attribute__((aligned(16))) char L[PANEL_BYTES + 32768];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  float acc = 0.f;
+  f4* d4 = reinterpret_cast<f4*>(L);
+  float sr[6];
+  f4 sw;
+  float2 sw2;
+  const float* sp = stream + ((size_t)blockIdx.x * NP * 16 + wave) * 768;
+  auto issue = [&](int half_idx, int buf) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const size_t g = (size_t)half_idx * 3072 + (size_t)(k * 16 + wave) * 64 + lane;
+      char* dst = L + buf * 49152 + (k * 16 + wave) * 1024;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + g),
+                                       (__attribute__((address_space(3))) void*)(dst), 16, 0, 0);
+    }
+  };
+  auto issue_stream = [&](int hn) {
+    const float* q = sp + (size_t)(hn >> 1) * 16 * 768 + (hn & 1) * 384;
+    if (WIDE) {
+      const f4* q4 = reinterpret_cast<const f4*>(q) + lane;
+      const float2* q2 = reinterpret_cast<const float2*>(q + 256) + lane;
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(sw) : "v"(q4) : "memory");
+      asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(sw2) : "v"(q2) : "memory");
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const float* qk = q + k * 64 + lane;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(sr[k]) : "v"(qk) : "memory");
+      }
+    }
+  };
+  const int NH = NP * 2;
+  issue(0, 0);
+  issue_stream(0);
+  for (int h = 0; h < NH; ++h) {
+    const int hn = (h + 1 == NH) ? 0 : h + 1;
+    issue(hn, (h + 1) & 1);
+    // in flight: [dma h][stream h][dma h+1] -> everything but the last 3 must have landed
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float use = 0.f;
+    if (WIDE) {
+      asm volatile("" : "+v"(sw), "+v"(sw2));
+      use = sw.x + sw.y + sw.z + sw.w + sw2.x + sw2.y;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        asm volatile("" : "+v"(sr[k]));
+        use += sr[k];
+      }
+    }
+    acc += use + d4[(h & 1) * 3072 + ((tid * 7 + h) & 2047)].x;
+    asm volatile("s_nop 0" ::: "memory");
+    issue_stream(hn);
+    acc = busy(acc, work >> 1);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (acc == 12345.678f) out[0] = acc;
+}
+
+int main(int argc, char** argv) {
+  const int mb = argc > 1 ? atoi(argv[1]) : 8;
+  const int reps = argc > 2 ? atoi(argv[2]) : 10;
+  const int NP = (int)(((size_t)mb << 20) / PANEL_BYTES);
+  const int stream_f4 = 3072;  // 48 KB per tile per workgroup
+  f4 *X, *S;
+  float* out;
+  CK(hipMalloc(&X, (size_t)(NP + 1) * PANEL_BYTES));
+  CK(hipMemset(X, 0, (size_t)(NP + 1) * PANEL_BYTES));
+  CK(hipMalloc(&S, (size_t)256 * NP * stream_f4 * 16));
+  CK(hipMemset(S, 0, (size_t)256 * NP * stream_f4 * 16));
+  CK(hipMalloc(&out, 16));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a));
+  CK(hipEventCreate(&b));
+  auto run = [&](const char* name, auto launch, double bytes) {
+    launch();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int r = 0; r < reps; ++r) launch();
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    ms /= reps;
+    printf("%-44s %.3f ms  %.2f TB/s into LDS (%.1f GB/s per CU), %.2f us per tile\n", name, ms,
+           bytes / (ms * 1e-3) / 1e12, bytes / 256 / (ms * 1e-3) / 1e9, ms * 1e3 / NP);
+  };
+  const double pb = 256.0 * NP * PANEL_BYTES;
+  printf("table %d MB = %d panels of 96 KB, 256 workgroups x 1024 threads\n", mb, NP);
+  run("A reg-staged, in phase", [&]() { hipLaunchKernelGGL(k_regstage, dim3(256), dim3(BS), 0, 0, X, NP, 1, out, S, 0); }, pb);
+  run("B reg-staged, 4 phases per XCD", [&]() { hipLaunchKernelGGL(k_regstage, dim3(256), dim3(BS), 0, 0, X, NP, 4, out, S, 0); }, pb);
+  run("B reg-staged, 16 phases per XCD", [&]() { hipLaunchKernelGGL(k_regstage, dim3(256), dim3(BS), 0, 0, X, NP, 16, out, S, 0); }, pb);
+  run("C LDS-DMA, 48 KB halves, one ahead", [&]() { hipLaunchKernelGGL(k_ldsdma, dim3(256), dim3(BS), 0, 0, X, NP, out); }, pb);
+  run("D reg-staged + 40 KB/tile private stream", [&]() { hipLaunchKernelGGL(k_regstage, dim3(256), dim3(BS), 0, 0, X, NP, 1, out, S, stream_f4); },
+      pb + 256.0 * NP * stream_f4 * 16);
+  const float* Sf = reinterpret_cast<const float*>(S);
+  const double sb = pb + 256.0 * NP * 16 * 768 * 4;
+  const int W = argc > 3 ? atoi(argv[3]) : 160;
+  for (int work : {0, W}) {
+    printf("-- dependent FMAs per thread per tile: %d\n", work);
+    run("E reg panels 2 ahead + dword stream", [&]() { hipLaunchKernelGGL(k_kernel_like<0>, dim3(256), dim3(BS), 0, 0, X, NP, out, Sf, work); }, sb);
+    run("E reg panels 2 ahead + dwordx4 stream", [&]() { hipLaunchKernelGGL(k_kernel_like<1>, dim3(256), dim3(BS), 0, 0, X, NP, out, Sf, work); }, sb);
+    run("F LDS-DMA halves + dword stream", [&]() { hipLaunchKernelGGL(k_dma_stream<0>, dim3(256), dim3(BS), 0, 0, X, NP, out, Sf, work); }, sb);
+    run("F LDS-DMA halves + dwordx4/x2 stream", [&]() { hipLaunchKernelGGL(k_dma_stream<1>, dim3(256), dim3(BS), 0, 0, X, NP, out, Sf, work); }, sb);
+  }
+  return 0;
+}
