@@ -36,8 +36,9 @@ ALG_BYTES_PER_EDGE = 8 + 4      # two int32 endpoints + one fp32 parameter  (SUR
 # HBM-side bytes per launch of the config-4 kernel from the rocprofv3 PMC passes committed in
 # profiles/r01_pmc_summary.md (separate --pmc runs; FETCH_SIZE doubled for wide coalesced reads as
 # MI355X_MICROARCH.md prescribes, + WRITE_SIZE).  bench.py cannot collect PMC counters itself.
-PMC_TRAFFIC_BYTES = {1: 2 * 450.2e6 + 7.8e6,   # k_fused_panel  (LDS column panels, padded stream)
-                     0: 4.45e9 + 9.4e6}        # k_fused_small  (CSR; narrow gather line fills, no doubling)
+PMC_TRAFFIC_BYTES = {(1, True): 2 * 244.6e6 + 7.8e6,   # k_fused_panel, codebook stream (4 B/half-edge)
+                     (1, False): 2 * 450.2e6 + 7.8e6,  # k_fused_panel  (LDS column panels, fp32 parameter stream)
+                     (0, False): 4.45e9 + 9.4e6}       # k_fused_small  (CSR; narrow gather line fills, no doubling)
 
 
 def make_workload(device, n=N_ITEMS, deg=OUT_DEGREE, d=DIM):
@@ -99,12 +100,16 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-codebook", action="store_true",
+                    help="stream the weights as fp32 (8 B/half-edge) even though they take 2 values")
     ap.add_argument("--n", type=int, default=N_ITEMS)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single process: time only the kernel of rank 0 of a W-way shard (no collective)")
     args = ap.parse_args()
 
+    if args.no_codebook:
+        os.environ["MDE_CODEBOOK"] = "0"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -186,10 +191,13 @@ def main():
                                    "penalties.Log1p(1.5), weights in {1,2}" % (n, p),
                        "parallelism": ("vertex-range shards x%d + %s of [grad|loss]" % (world, exchange.mode))
                        if world > 1 else "single GPU",
+                       "parameter_stream": ("codebook: 2 distinct weights ride in the packed half-edge word "
+                                            "(4 B/half-edge)" if binding.codebook
+                                            else "fp32 weight per half-edge (8 B/half-edge)"),
                        "loss": gpu_loss},
             "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BPS / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_BPS,
-                         "traffic": (PMC_TRAFFIC_BYTES.get(int(binding.struct(d).layout))
+                         "traffic": (PMC_TRAFFIC_BYTES.get((int(binding.struct(d).layout), bool(binding.codebook)))
                                      if (world == 1 and n == N_ITEMS) else None),
                          "traffic_source": "profiles/r01_pmc_summary.md (rocprofv3 --pmc, bytes/launch)",
                          "kernel": ("k_fused_panel<2,Log1p> (LDS column panels)" if binding.struct(d).layout == 1

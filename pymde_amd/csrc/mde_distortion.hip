@@ -19,7 +19,8 @@
 double* mde_plan_partials(mde_plan* p);
 float mde_plan_avg_degree(const mde_plan* p);
 int mde_panel_try(mde_plan* plan, const float* X, int d, const mde_func* f, float grad_scale,
-                  float* grad, float inv_p, hipStream_t st, int* nblocks);
+                  float* grad, float inv_p, hipStream_t st, int* nblocks, float* loss_out,
+                  double loss_scale);
 
 // ---------------------------------------------------------------- small-d fused kernel
 // D in {1,2,3,4}: one lane per half-edge, G lanes per row.
@@ -414,20 +415,20 @@ extern "C" int mde_average_distortion(mde_plan* plan, const float* X, int32_t d,
   A.grad_scale = grad_scale;
   A.st = mde_stream(stream);
   A.nblocks = 0;
+  // every edge is seen from both endpoints: weight 1/2; mean over p edges
+  const double scale = p > 0 ? 0.5 / (double)p : 0.0;
   if (f->layout == 1) {
-    // parameters are in column-panel order: the LDS-tiled kernel (mde_panel.hip)
-    rc = mde_panel_try(plan, X, d, f, grad_scale, grad, A.inv_p, A.st, &A.nblocks);
+    // parameters are in column-panel order: the LDS-tiled kernel (mde_panel.hip), which also
+    // reduces the loss (last workgroup to arrive)
+    rc = mde_panel_try(plan, X, d, f, grad_scale, grad, A.inv_p, A.st, &A.nblocks, loss_out, scale);
     if (rc == 0) {
       mde_set_error("mde_func.layout = 1 but the plan has no panel layout for d = %d", d);
       return MDE_E_INVALID;
     }
-    if (rc < 0) return rc;
-  } else {
-    rc = dispatch_fused(A, f);
-    if (rc != MDE_OK) return rc;
+    return rc < 0 ? rc : MDE_OK;
   }
-  // every edge is seen from both endpoints: weight 1/2; mean over p edges
-  const double scale = p > 0 ? 0.5 / (double)p : 0.0;
+  rc = dispatch_fused(A, f);
+  if (rc != MDE_OK) return rc;
   hipLaunchKernelGGL(k_finalize_loss, dim3(1), dim3(MDE_BLOCK), 0, A.st, A.partials, A.nblocks, scale,
                      loss_out);
   MDE_LAUNCH_CHECK();

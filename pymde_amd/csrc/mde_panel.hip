@@ -565,7 +565,8 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
     const int32_t* __restrict__ sub_off, const uint32_t* __restrict__ packed,
     const float* __restrict__ a0, const float* __restrict__ a1, int a0_scalar, int a1_scalar,
     const float* __restrict__ X, float* __restrict__ grad, float* __restrict__ partial,
-    double* __restrict__ loss_partials, Fn fn, float inv_p, float grad_scale) {
+    double* __restrict__ loss_partials, Fn fn, float inv_p, float grad_scale,
+    float* __restrict__ loss_out, double loss_scale) {
   constexpr int BS = MDE_PANEL_BS, NW = MDE_PANEL_WAVES, STG = MDE_PANEL_STG, MAXI = MDE_PANEL_MAXI;
   constexpr int GR_OFF = MDE_PANEL_GR_OFF, XC_OFF = MDE_PANEL_XC_OFF;
   constexpr uint32_t DUMMY = MDE_PANEL_DUMMY;
@@ -807,8 +808,11 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
       for (int c = 0; c < D; ++c) grow[r * D + c] = GR[slot + c] * sc;
     }
   }
-  // block-wide loss partial (the x_v region is free now)
+  // block-wide loss partial (the x_v region is free now), then the loss itself: the last
+  // workgroup to arrive adds the partials of all of them in a fixed order (no second launch)
   double* red = reinterpret_cast<double*>(L);
+  int* last_flag = reinterpret_cast<int*>(L + 256);
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(loss_partials + MDE_MAX_PARTIALS);
   const double v = mde_wave_sum((double)loss);
   if (lane == 0) red[wave] = v;
   __syncthreads();
@@ -816,6 +820,24 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
     double s = 0.0;
     for (int i = 0; i < NW; ++i) s += red[i];
     loss_partials[blockIdx.x] = s;
+    __threadfence();  // publish the partial (and this block's gradient rows) device-wide
+    *last_flag = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (*last_flag) {
+    __threadfence();  // see the other workgroups' partials (L2 is not coherent across XCDs)
+    double t = 0.0;
+    for (int i = tid; i < (int)gridDim.x; i += BS) t += __builtin_nontemporal_load(loss_partials + i);
+    t = mde_wave_sum(t);
+    __syncthreads();
+    if (lane == 0) red[wave] = t;
+    __syncthreads();
+    if (tid == 0) {
+      double s = 0.0;
+      for (int i = 0; i < NW; ++i) s += red[i];
+      *loss_out = (float)(s * loss_scale);
+      *ticket = 0u;  // ready for the next launch (stream order)
+    }
   }
 }
 
@@ -839,6 +861,8 @@ struct PanelArgs {
   float* grad;
   float inv_p, grad_scale;
   hipStream_t st;
+  float* loss_out;
+  double loss_scale;
 };
 
 template <int D, class Fn>
@@ -862,7 +886,7 @@ static int launch_panel(const PanelArgs& A, const Fn& fn, int* nblocks) {
                      (int)(A.plan->row_hi - A.plan->row_lo), (int)A.plan->row_lo, (int)A.plan->n,
                      L.rows_per_block, L.cols_per_panel, L.n_panels, Q, L.next_tile, L.sub_off, stream,
                      a0, A.a1, A.a0_scalar, A.a1_scalar, A.X, A.grad, L.partial, A.plan->partials, fn,
-                     A.inv_p, A.grad_scale);
+                     A.inv_p, A.grad_scale, A.loss_out, A.loss_scale);
   MDE_LAUNCH_CHECK();
   if (Q > 1 && A.grad) {
     const int64_t nlocD = (A.plan->row_hi - A.plan->row_lo) * (int64_t)D;
@@ -882,12 +906,14 @@ static MdeFuncArgs panel_func_args(const mde_func* f) {
   return a;
 }
 
-// Called by mde_average_distortion.  Returns 1 when the panel kernel was launched (nblocks =
-// number of loss partials written), 0 when the caller should use the CSR kernel, < 0 on error.
+// Called by mde_average_distortion.  Returns 1 when the panel kernel was launched (it also writes
+// *loss_out = loss_scale * sum of the workgroups' partials; nblocks = number of partials), 0 when the caller should use the CSR kernel, < 0 on error.
 int mde_panel_try(mde_plan* plan, const float* X, int d, const mde_func* f, float grad_scale,
-                  float* grad, float inv_p, hipStream_t st, int* nblocks) {
+                  float* grad, float inv_p, hipStream_t st, int* nblocks, float* loss_out,
+                  double loss_scale) {
   if (!plan->panel.packed || plan->panel.d != d) return 0;
-  PanelArgs A{plan, X, d, f->a0, f->a1, f->a0_scalar, f->a1_scalar, grad, inv_p, grad_scale, st};
+  PanelArgs A{plan, X, d, f->a0, f->a1, f->a0_scalar, f->a1_scalar, grad, inv_p, grad_scale, st,
+              loss_out, loss_scale};
   const MdeFuncArgs a = panel_func_args(f);
   const int ea = mde_exp_class(f->s0), en = mde_exp_class(f->n0);
   int rc = MDE_OK;

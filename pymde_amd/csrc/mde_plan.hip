@@ -242,7 +242,9 @@ extern "C" int mde_plan_create(int64_t n, int64_t p, const int64_t* edges, int64
   } while (0)
 
   PLAN_HIP(hipMalloc(&plan->rowptr, (nloc + 1) * sizeof(int32_t)));
-  PLAN_HIP(hipMalloc(&plan->partials, MDE_MAX_PARTIALS * sizeof(double)));
+  // (+1: the slot after the partials is the arrival counter of the in-kernel loss reduction)
+  PLAN_HIP(hipMalloc(&plan->partials, (MDE_MAX_PARTIALS + 1) * sizeof(double)));
+  PLAN_HIP(hipMemsetAsync(plan->partials + MDE_MAX_PARTIALS, 0, sizeof(double), st));
   int32_t Hlocal = 0;
   if (H2 > 0) {
     const size_t bytes = (size_t)H2 * sizeof(uint32_t);
