@@ -200,8 +200,9 @@ def main():
                          "traffic": (PMC_TRAFFIC_BYTES.get((int(binding.struct(d).layout), bool(binding.codebook)))
                                      if (world == 1 and n == N_ITEMS) else None),
                          "traffic_source": "profiles/r01_pmc_summary.md (rocprofv3 --pmc, bytes/launch)",
-                         "kernel": ("k_fused_panel<2,Log1p> (LDS column panels)" if binding.struct(d).layout == 1
-                                    else "k_fused_small<2,G,Log1p> (CSR)") + " + 1-block loss finalize",
+                         "kernel": ("k_fused_panel<2,Log1p> (LDS column panels, loss reduced in the same launch)"
+                                    if binding.struct(d).layout == 1
+                                    else "k_fused_small<2,G,Log1p> (CSR) + 1-block loss finalize"),
                          "kernel_ms": k_ms, "alg_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline:
