@@ -204,6 +204,50 @@ __global__ __launch_bounds__(BS) void k_dma_stream(const f4* __restrict__ X, int
   if (acc == 12345.678f) out[0] = acc;
 }
 
+
+// G: data movement of a taller-row-block design: PB-byte panels (two ahead, PB/16/1024 float4 per
+// thread), NT tiles per workgroup, SL dword stream loads per lane per tile, one ahead
+template <int PB, int SL>
+__global__ __launch_bounds__(BS) void k_tall(const f4* __restrict__ X, int NT, int first, float* out,
+                                             const float* __restrict__ stream) {
+  __shared__ __attribute__((aligned(16))) char L[PB];
+  f4* d4 = reinterpret_cast<f4*>(L);
+  constexpr int ST = PB / 16 / BS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  f4 sA[ST], sB[ST];
+  float acc = 0.f;
+  float sr[SL];
+  const float* sp = stream + ((size_t)blockIdx.x * NT * 16 + wave) * (SL * 64);
+  auto load_stream = [&](int t) {
+    const float* q = sp + (size_t)t * 16 * (SL * 64);
+#pragma unroll
+    for (int k = 0; k < SL; ++k) sr[k] = q[k * 64 + lane];
+  };
+  auto load_panel = [&](int cp, f4 (&stg)[ST]) {
+#pragma unroll
+    for (int k = 0; k < ST; ++k) stg[k] = X[(size_t)cp * (PB / 16) + tid + k * BS];
+  };
+  auto step = [&](int t, f4 (&stg)[ST]) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ST; ++k) d4[tid + k * BS] = stg[k];
+    __syncthreads();
+    float use = 0.f;
+#pragma unroll
+    for (int k = 0; k < SL; ++k) use += sr[k];
+    acc += use + d4[(tid * 7 + t) & (PB / 16 - 1)].x;
+    load_panel(first + (t + 2) % NT, stg);
+    load_stream((t + 1) % NT);
+  };
+  load_panel(first, sA);
+  load_panel(first + 1, sB);
+  load_stream(0);
+  for (int t = 0; t < NT; t += 2) {
+    step(t, sA);
+    if (t + 1 < NT) step(t + 1, sB);
+  }
+  if (acc == 12345.678f) out[0] = acc;
+}
 int main(int argc, char** argv) {
   const int mb = argc > 1 ? atoi(argv[1]) : 8;
   const int reps = argc > 2 ? atoi(argv[2]) : 10;
@@ -249,6 +293,19 @@ int main(int argc, char** argv) {
     run("E reg panels 2 ahead + dwordx4 stream", [&]() { hipLaunchKernelGGL(k_kernel_like<1>, dim3(256), dim3(BS), 0, 0, X, NP, out, Sf, work); }, sb);
     run("F LDS-DMA halves + dword stream", [&]() { hipLaunchKernelGGL(k_dma_stream<0>, dim3(256), dim3(BS), 0, 0, X, NP, out, Sf, work); }, sb);
     run("F LDS-DMA halves + dwordx4/x2 stream", [&]() { hipLaunchKernelGGL(k_dma_stream<1>, dim3(256), dim3(BS), 0, 0, X, NP, out, Sf, work); }, sb);
+  }
+  {
+    // 8 MB table as 256 panels of 32 KB; 128 row blocks x 2 column groups: each workgroup walks 128
+    // panels; stream 3.3 MB per workgroup = 26 KB per tile = 6.5 -> 7 dwords per lane (fp32 stream)
+    // or 4 (codebook)
+    const int NT = 128;
+    auto first = [&]() { return 0; };
+    (void)first;
+    const double pbytes = 256.0 * NT * 32768;
+    run("G tall rows: 32 KB panels x128, 7 dword stream", [&]() { hipLaunchKernelGGL((k_tall<32768, 7>), dim3(256), dim3(BS), 0, 0, X, NT, 0, out, Sf); }, pbytes + 256.0 * NT * 16 * 7 * 256);
+    run("G tall rows: 32 KB panels x128, 4 dword stream", [&]() { hipLaunchKernelGGL((k_tall<32768, 4>), dim3(256), dim3(BS), 0, 0, X, NT, 0, out, Sf); }, pbytes + 256.0 * NT * 16 * 4 * 256);
+    run("G current:   96 KB panels x85, 6 dword stream", [&]() { hipLaunchKernelGGL((k_tall<98304, 6>), dim3(256), dim3(BS), 0, 0, X, NP, 0, out, Sf); }, pb + 256.0 * NP * 16 * 6 * 256);
+    run("G current:   96 KB panels x85, 12 dword stream", [&]() { hipLaunchKernelGGL((k_tall<98304, 12>), dim3(256), dim3(BS), 0, 0, X, NP, 0, out, Sf); }, pb + 256.0 * NP * 16 * 12 * 256);
   }
   return 0;
 }
