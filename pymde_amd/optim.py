@@ -78,7 +78,10 @@ class _Engine(object):
         self.X_trial = torch.empty_like(self.X)
         # gradient buffer with one trailing float: [grad | loss] is what a multi-GPU
         # evaluation all-reduces in a single collective
-        self.gbuf = torch.zeros(self.N + 1, dtype=torch.float32, device=dev)
+        # (a second trailing word holds the status flag of the constraint kernels, so that one
+        # small copy brings back both)
+        self.gtail = torch.zeros(self.N + 2, dtype=torch.float32, device=dev)
+        self.gbuf = self.gtail[:self.N + 1]
         self.g = self.gbuf[:self.N].view(self.n, self.d)
         self.loss_dev = self.gbuf[self.N:]
         self.g_prev = torch.empty_like(self.X)
@@ -86,9 +89,13 @@ class _Engine(object):
         self.work = util.work_buffer(dev, self.d)
         self.board = torch.zeros(512, dtype=torch.float64, device=dev)
         self.host = torch.zeros(512, dtype=torch.float64).pin_memory()
-        self.status = torch.zeros(1, dtype=torch.int32, device=dev)
-        self.host_loss = torch.zeros(1, dtype=torch.float32).pin_memory()
-        self.host_status = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.status = self.gtail[self.N + 1:].view(torch.int32)
+        self.host_tail = torch.zeros(2, dtype=torch.float32).pin_memory()
+        self.host_loss = self.host_tail[:1]
+        self.host_status = self.host_tail[1:].view(torch.int32)
+        # the solve runs on the stream that is current now; its handle is looked up once
+        self._stream_obj = torch.cuda.current_stream(dev)
+        self._stream = ctypes.c_void_p(self._stream_obj.cuda_stream)
         handle = ctypes.c_void_p()
         _lib.check(self.lib.mde_lbfgs_create(self.N, int(memory_size), ctypes.byref(handle)))
         self.lbfgs = handle
@@ -100,7 +107,7 @@ class _Engine(object):
             self.lbfgs = None
 
     def stream(self):
-        return _lib.stream_ptr(self.device)
+        return self._stream
 
     # ---- vector kernels
     def axpy(self, alpha, x, y, out):
@@ -114,9 +121,8 @@ class _Engine(object):
     def read_board(self, count):
         """One device->host read-back of the first ``count`` doubles plus the loss."""
         self.host[:count].copy_(self.board[:count], non_blocking=True)
-        self.host_loss.copy_(self.loss_dev, non_blocking=True)
-        self.host_status.copy_(self.status, non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()
+        self.host_tail.copy_(self.gtail[self.N:], non_blocking=True)
+        self._stream_obj.synchronize()
         vals = self.host[:count].numpy().copy()
         return vals, float(self.host_loss[0])
 
@@ -156,6 +162,8 @@ class _NativeProblem(object):
         self.binding = binding
         self.constraint = constraint
         self.reducer = reducer  # multi-GPU: all-reduce of [grad | loss]
+        # the function's parameters are fixed for the duration of a solve: bind them once
+        self.fstruct = binding.struct(engine.d) if binding.fused else None
         if isinstance(constraint, _constraints._Standardized):
             self.kind = "standardized"
         elif isinstance(constraint, _constraints._Centered):
@@ -183,7 +191,9 @@ class _NativeProblem(object):
         if self.reducer is not None:
             e.gbuf.zero_()
         if self.binding.fused:
-            ad.fused_evaluate(self.binding, X, e.g, e.loss_dev)
+            _lib.check(lib.mde_average_distortion(
+                self.binding.plan.handle, _lib.ptr(X), e.d, ctypes.byref(self.fstruct), 1.0,
+                _lib.ptr(e.g), _lib.ptr(e.loss_dev), e.stream()))
         else:
             grad, value = ad._unfused(self.binding, X, True)
             e.g.copy_(grad)
