@@ -61,6 +61,7 @@ class SolveStats(object):
 
 # indices into the statistics board (mde_vec_stats)
 _GD, _GG, _G1, _GMAX, _NONFINITE, _DD, _DMAX, _XX, _LOSS = range(9)
+_DIR = 16  # offset (doubles) of the direction statistics written by update_direction
 
 
 class _Engine(object):
@@ -132,7 +133,10 @@ class _Engine(object):
         self.memory.reset()
 
     def update_direction(self, t_prev):
-        """Stage (y, s), decide acceptance, form the new direction; returns stats of (g, d)."""
+        """Stage (y, s), decide acceptance, form the new direction.  The statistics of (g, d) are
+        left in the second half of the board (``_DIR`` doubles in): they are not needed before the
+        first trial evaluation of the line search has been enqueued, so they travel with its
+        read-back instead of costing a synchronisation of their own."""
         c = self.memory.count
         ndots = 4 + 5 * c
         _lib.check(self.lib.mde_lbfgs_stage(self.lbfgs, _lib.ptr(self.g), _lib.ptr(self.g_prev),
@@ -145,11 +149,10 @@ class _Engine(object):
         m = self.memory.count
         cs_arr = (ctypes.c_float * max(m, 1))(*[float(v) for v in cs])
         cy_arr = (ctypes.c_float * max(m, 1))(*[float(v) for v in cy])
+        dir_board = ctypes.c_void_p(self.board.data_ptr() + 8 * _DIR)
         _lib.check(self.lib.mde_lbfgs_combine(self.lbfgs, _lib.ptr(self.g), float(c_g), cs_arr, cy_arr,
-                                              _lib.ptr(self.dir), _lib.ptr(self.board),
+                                              _lib.ptr(self.dir), dir_board,
                                               _lib.ptr(self.work), self.stream()))
-        vals, _ = self.read_board(8)
-        return vals
 
 
 class _NativeProblem(object):
@@ -330,34 +333,49 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
             e.axpy(0.0, e.g, e.g, e.g_prev)         # g_prev <- g
             e.stats(e.g, e.dir, None)
             vals, _ = e.read_board(8)
-        else:
-            vals = e.update_direction(t)
-        gtd = vals[_GD]
-        d_norm2 = math.sqrt(vals[_DD])
-        d_max = vals[_DMAX]
-        # initial step (lbfgs.py:521-524), lr = 1
-        if n_iter == 1:
+            gtd, d_norm2, d_max = vals[_GD], math.sqrt(vals[_DD]), vals[_DMAX]
             g1 = vals[_G1]
-            t = min(1.0, 1.0 / g1) if g1 > 0 else 1.0
+            t = min(1.0, 1.0 / g1) if g1 > 0 else 1.0   # initial step (lbfgs.py:521-524), lr = 1
         else:
+            e.update_direction(t)
             t = 1.0
 
         last_eval = {"t": None}
 
-        def phi(tt):
+        def phi(tt, extra=0):
             e.axpy(tt, e.dir, e.X, e.X_trial)
             problem.retract(e.X_trial)
             problem.value_and_grad(e.X_trial)
             e.stats(e.g, e.dir, e.X_trial)
-            v, f = e.read_board(8)
+            v, f = e.read_board(8 + extra)
             last_eval["t"] = tt
             last_eval["gg"] = v[_GG]
             last_eval["xx"] = v[_XX]
-            return f, v[_GD], v[_NONFINITE] == 0
+            return (f, v[_GD], v[_NONFINITE] == 0), v
+
+        if n_iter > 1:
+            # the first trial point is enqueued before the direction statistics are known; both
+            # come back in one read
+            if use_line_search:
+                first, v = phi(t, extra=_DIR)
+            else:
+                first = None
+                v, _ = e.read_board(_DIR + 8)
+            dv = v[_DIR:_DIR + 8]
+            gtd, d_norm2, d_max = dv[_GD], math.sqrt(dv[_DD]), dv[_DMAX]
+        else:
+            first = None
+
+        def phi_ls(tt, _cache=[first, t]):
+            if _cache[0] is not None and tt == _cache[1]:
+                out, _cache[0] = _cache[0], None
+                return out
+            _cache[0] = None
+            return phi(tt)[0]
 
         if use_line_search:
             try:
-                loss_new, t, _ = _host.strong_wolfe(phi, t, loss, gtd, d_max)
+                loss_new, t, _ = _host.strong_wolfe(phi_ls, t, loss, gtd, d_max)
             except _host.LineSearchError as err:
                 raise util.SolverError(str(err))
             cached_loss = loss_new
