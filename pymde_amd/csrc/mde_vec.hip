@@ -781,7 +781,7 @@ extern "C" int mde_lbfgs_stage(mde_lbfgs* o, const float* g, float* g_prev, cons
   if (!o || !g || !g_prev || !d || !dots || !work) return MDE_E_INVALID;
   hipStream_t st = mde_stream(stream);
   const int64_t N = o->N;
-  const int nb = mde_grid(N, MDE_BLOCK * 4, 512);
+  const int nb = mde_grid(N, MDE_BLOCK * 2, 2048);  // >= 8 waves per SIMD-quad in flight: ~20 streams to hide
   double* partial = work + MDE_SMALL_DOUBLES;
   float* s_new = o->S(o->spare);
   float* y_new = o->Y(o->spare);
