@@ -121,6 +121,20 @@ MDE_DEV void mde_eval(float ss, float a0, float a1, const MdeScalars& S, float& 
     f = fmaxf(0.0f, v);
     const float sub = (v > 0.0f) ? 1.0f : ((v == 0.0f) ? 0.5f : 0.0f);  // torch.max tie -> 1/2
     gd = sub * a0 * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_LOG1P && ECLS == 2) {  // penalties.py:310-321, exponent 1.5
+    // d^1.5 = ss * d^-1/2 and f'/d = 1.5 w d^-1/2 / (1 + d^1.5): one rsq replaces a sqrt, a
+    // reciprocal and three multiplies.  v_mul_legacy (0 * inf = 0) keeps d = 0 exact: f = 0 and
+    // gd = inf, which the caller maps to 1 like the reference's NaN.
+    const float d = mde_sqrt(ss);
+    const float rs = __builtin_amdgcn_rsqf(d);
+    float pe;
+    // (s_nop: the hazard recogniser does not look inside inline asm, and rs comes straight out of
+    // the transcendental unit)
+    asm("s_nop 0\n\tv_mul_legacy_f32 %0, %1, %2" : "=v"(pe) : "v"(ss), "v"(rs));
+    const float t = 1.0f + pe;
+    const float rt = mde_rcp(t);
+    f = a0 * fmaf(pe - (t - 1.0f), rt, mde_log(t));
+    gd = (1.5f * a0) * rs * rt;
   } else if constexpr (KIND == MDE_F_LOG1P) {  // penalties.py:310-321
     const float d = mde_sqrt(ss);
     const float e = mde_expo<ECLS>(S.s0);

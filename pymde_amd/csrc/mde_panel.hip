@@ -752,7 +752,9 @@ __global__ __launch_bounds__(MDE_PANEL_BS) void k_fused_panel(
     const StreamSrc ssrc = stream_src(cpn < cp_hi ? cpn : cp);
     nK = ssrc.K;
     nb = ssrc.b;
-    constexpr int PPS = (STG + 2) / 3;  // panel loads per slot: all issued in the first 3 slots
+    // panel loads per slot: all issued in the first 3 slots (spreading them over all 6 measured
+    // 8 % slower: the last ones then land too close to the next commit)
+    constexpr int PPS = (STG + 2) / 3;
 #pragma unroll
     for (int k = 0; k < MAXI; ++k) {
       load_panel_part(psrc, scur, k * PPS, (k + 1) * PPS);
