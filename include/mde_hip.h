@@ -332,6 +332,18 @@ int mde_lbfgs_commit(mde_lbfgs* o, int32_t accept);
  * stats as mde_vec_stats(g, d_out, NULL).  cs, cy: HOST arrays of mde_lbfgs_count floats. */
 int mde_lbfgs_combine(mde_lbfgs* o, const float* g, float c_g, const float* cs, const float* cy,
                       float* d_out, double* stats, double* work, void* stream);
+/* Device-driven variant: the whole direction update of one iteration without a host round trip
+ * [ref: lbfgs.py:468-507].  mde_lbfgs_dev_reset empties the history (lbfgs.py:378-388);
+ * mde_lbfgs_dev_step stages y = g - g_prev, s = t d (and sets g_prev <- g), accepts the pair iff
+ * y.s > 1e-10 (dropping the oldest when the history is full), runs the two-loop recursion in
+ * coefficient form on the device and writes the new direction to d_out (may alias d) and the
+ * statistics of (g, d_out) to stats as mde_vec_stats(g, d_out, NULL) does.  ASYNC.  Do not mix with
+ * the host-driven stage / commit / combine calls on one object.  mde_lbfgs_dev_info reads back the
+ * number of stored pairs and whether the last pair was accepted (tests; SYNC). */
+int mde_lbfgs_dev_reset(mde_lbfgs* o, void* stream);
+int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, const float* d, float t,
+                       float* d_out, double* stats, double* work, void* stream);
+int mde_lbfgs_dev_info(const mde_lbfgs* o, int32_t* count_host, int32_t* accepted_host, void* stream);
 
 #ifdef __cplusplus
 }

@@ -667,6 +667,22 @@ struct LbPtrs {
   int count;
 };
 
+// Device-resident bookkeeping of mde_lbfgs_dev_step: the Gram matrices of the stored pairs, the
+// slot permutation and the direction coefficients never visit the host.
+#define MDE_LB_MAX 63
+#define MDE_LB_LD 64
+struct LbDev {
+  int count;                  // stored pairs
+  int accepted;               // 1: the last staged pair was stored (y.s > 1e-10, lbfgs.py:472)
+  int order[MDE_LB_LD];       // permutation of the history+1 slots: [0, count) oldest first, [count] = spare
+  double H;                   // y.s / y.y of the newest pair (lbfgs.py:486)
+  double SY[MDE_LB_LD * MDE_LB_LD];  // SY[i][j] = s_i . y_j
+  double YY[MDE_LB_LD * MDE_LB_LD];  // YY[i][j] = y_i . y_j
+  float c_g;                  // d = c_g g + sum_j cs[j] s_j + cy[j] y_j
+  float cs[MDE_LB_LD];
+  float cy[MDE_LB_LD];
+};
+
 struct mde_lbfgs {
   int64_t N = 0;
   int history = 0;
@@ -675,6 +691,7 @@ struct mde_lbfgs {
   int count = 0;
   int spare = 0;
   bool staged = false;
+  struct LbDev* dev = nullptr;  // device-resident bookkeeping of the device-driven step
   float* S(int slot) const { return buf + (int64_t)(2 * slot) * N; }
   float* Y(int slot) const { return buf + (int64_t)(2 * slot + 1) * N; }
 };
@@ -691,12 +708,19 @@ extern "C" int mde_lbfgs_create(int64_t N, int32_t history, mde_lbfgs** out) {
   }
   o->count = 0;
   o->spare = 0;
+  e = hipMalloc(&o->dev, sizeof(LbDev));
+  if (e != hipSuccess) {
+    (void)hipFree(o->buf);
+    delete o;
+    return mde_hip_fail(e, "hipMalloc(lbfgs device state)", __FILE__, __LINE__);
+  }
   *out = o;
   return MDE_OK;
 }
 extern "C" int mde_lbfgs_destroy(mde_lbfgs* o) {
   if (!o) return MDE_OK;
   if (o->buf) (void)hipFree(o->buf);
+  if (o->dev) (void)hipFree(o->dev);
   delete o;
   return MDE_OK;
 }
@@ -838,6 +862,315 @@ extern "C" int mde_lbfgs_commit(mde_lbfgs* o, int32_t accept) {
     while (used[sp]) ++sp;
     o->spare = sp;
   }
+  return MDE_OK;
+}
+
+// ---------------------------------------------------------------- device-driven step
+// The same history update and two-loop recursion with every decision taken on the device: the
+// stage kernel finds its slots through LbDev, k_lbfgs_direction folds the staged dots into the Gram
+// matrices (accept / drop oldest, lbfgs.py:472-486) and runs the recursion in coefficient form
+// (lbfgs.py:490-507), the combine kernel reads the coefficients from LbDev.  No host read-back.
+__global__ void k_lbfgs_dev_reset(LbDev* __restrict__ dv, int history) {
+  const int t = threadIdx.x;
+  if (t <= history) dv->order[t] = t;
+  if (t == 0) {
+    dv->count = 0;
+    dv->accepted = 0;
+    dv->H = 1.0;
+    dv->c_g = -1.0f;
+  }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(MDE_BLOCK) void k_lbfgs_stage_dev(int64_t N, const float* __restrict__ g,
+                                                               float* __restrict__ g_prev,
+                                                               const float* __restrict__ d, float t,
+                                                               float* __restrict__ buf,
+                                                               const LbDev* __restrict__ dv, int done,
+                                                               double* __restrict__ partial) {
+  __shared__ double smem[8];
+  const int count = dv->count;
+  if (!FIRST && done >= count) return;
+  int pc = count - done;
+  if (pc > MDE_LB_GROUP) pc = MDE_LB_GROUP;
+  if (pc < 0) pc = 0;
+  const int spare = dv->order[count];
+  float* s_new = buf + (int64_t)(2 * spare) * N;
+  float* y_new = buf + (int64_t)(2 * spare + 1) * N;
+  const float* ps[MDE_LB_GROUP];
+  const float* py[MDE_LB_GROUP];
+#pragma unroll
+  for (int j = 0; j < MDE_LB_GROUP; ++j) {
+    const int slot = (j < pc) ? dv->order[done + j] : spare;
+    ps[j] = buf + (int64_t)(2 * slot) * N;
+    py[j] = buf + (int64_t)(2 * slot + 1) * N;
+  }
+  double base[4] = {0, 0, 0, 0};
+  double acc[MDE_LB_GROUP][5];
+#pragma unroll
+  for (int j = 0; j < MDE_LB_GROUP; ++j)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) acc[j][q] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N;
+       i += (int64_t)gridDim.x * MDE_BLOCK) {
+    const float gv = g[i];
+    float yv, sv;
+    if constexpr (FIRST) {
+      yv = gv - g_prev[i];
+      sv = t * d[i];
+      y_new[i] = yv;
+      s_new[i] = sv;
+      g_prev[i] = gv;
+      base[0] = fma((double)yv, (double)sv, base[0]);
+      base[1] = fma((double)yv, (double)yv, base[1]);
+      base[2] = fma((double)sv, (double)gv, base[2]);
+      base[3] = fma((double)yv, (double)gv, base[3]);
+    } else {
+      yv = y_new[i];
+      sv = s_new[i];
+    }
+#pragma unroll
+    for (int j = 0; j < MDE_LB_GROUP; ++j) {
+      if (j < pc) {
+        const double sj = ps[j][i], yj = py[j][i];
+        acc[j][0] = fma(sj, (double)yv, acc[j][0]);  // s_j . y*
+        acc[j][1] = fma(yj, (double)yv, acc[j][1]);  // y_j . y*
+        acc[j][2] = fma((double)sv, yj, acc[j][2]);  // s* . y_j
+        acc[j][3] = fma(sj, (double)gv, acc[j][3]);  // s_j . g
+        acc[j][4] = fma(yj, (double)gv, acc[j][4]);  // y_j . g
+      }
+    }
+  }
+  const int nb = gridDim.x, b = blockIdx.x;
+  if constexpr (FIRST) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double r = mde_block_sum(base[q], smem);
+      if (threadIdx.x == 0) partial[(int64_t)q * nb + b] = r;
+    }
+  }
+  const int qbase = 4 + 5 * done;
+#pragma unroll
+  for (int j = 0; j < MDE_LB_GROUP; ++j) {
+    if (j < pc) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        const double r = mde_block_sum(acc[j][q], smem);
+        if (threadIdx.x == 0) partial[(int64_t)(qbase + 5 * j + q) * nb + b] = r;
+      }
+    }
+  }
+}
+
+// dots[q] = sum_b partial[q * nb + b] for the 4 + 5 count rows that were written
+__global__ void k_lbfgs_reduce_dev(int nb, const double* __restrict__ partial, const LbDev* __restrict__ dv,
+                                   double* __restrict__ dots) {
+  __shared__ double smem[8];
+  const int q = blockIdx.x;
+  if (q >= 4 + 5 * dv->count) return;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) s += partial[(int64_t)q * nb + b];
+  const double r = mde_block_sum(s, smem);
+  if (threadIdx.x == 0) dots[q] = r;
+}
+
+// One wave.  Lane j owns column j of everything; the Gram matrices sit in LDS while they are edited.
+__global__ __launch_bounds__(64) void k_lbfgs_direction(LbDev* __restrict__ dv, const double* __restrict__ dots,
+                                                        int history) {
+  __shared__ double SY[MDE_LB_LD * MDE_LB_LD];
+  __shared__ double YY[MDE_LB_LD * MDE_LB_LD];
+  const int j = threadIdx.x;
+  const int c = dv->count;
+  for (int i = 0; i < c; ++i) {
+    SY[i * MDE_LB_LD + j] = (j < c) ? dv->SY[i * MDE_LB_LD + j] : 0.0;
+    YY[i * MDE_LB_LD + j] = (j < c) ? dv->YY[i * MDE_LB_LD + j] : 0.0;
+  }
+  const double ys = dots[0], yy = dots[1], sg_new = dots[2], yg_new = dots[3];
+  // per stored pair j: s_j.y*, y_j.y*, s*.y_j, s_j.g, y_j.g
+  double s_old_ynew = 0, y_old_ynew = 0, snew_y_old = 0, Sg = 0, Yg = 0;
+  if (j < c) {
+    s_old_ynew = dots[4 + 5 * j + 0];
+    y_old_ynew = dots[4 + 5 * j + 1];
+    snew_y_old = dots[4 + 5 * j + 2];
+    Sg = dots[4 + 5 * j + 3];
+    Yg = dots[4 + 5 * j + 4];
+  }
+  const bool accepted = ys > 1e-10;  // lbfgs.py:472
+  int m = c;
+  double H = dv->H;
+  __syncthreads();
+  if (accepted) {
+    // append row / column c
+    if (j < c) {
+      SY[j * MDE_LB_LD + c] = s_old_ynew;
+      SY[c * MDE_LB_LD + j] = snew_y_old;
+      YY[j * MDE_LB_LD + c] = y_old_ynew;
+      YY[c * MDE_LB_LD + j] = y_old_ynew;
+    }
+    if (j == c) {
+      SY[c * MDE_LB_LD + c] = ys;
+      YY[c * MDE_LB_LD + c] = yy;
+      Sg = sg_new;
+      Yg = yg_new;
+    }
+    __syncthreads();
+    m = c + 1;
+    H = ys / yy;  // lbfgs.py:486
+    if (c == history) {
+      // drop the oldest pair (lbfgs.py:474-478): shift everything up / left by one
+      double rowS[MDE_LB_MAX + 1], rowY[MDE_LB_MAX + 1];
+      for (int i = 1; i < m; ++i) {
+        rowS[i] = (j + 1 < m) ? SY[i * MDE_LB_LD + j + 1] : 0.0;
+        rowY[i] = (j + 1 < m) ? YY[i * MDE_LB_LD + j + 1] : 0.0;
+      }
+      __syncthreads();
+      for (int i = 1; i < m; ++i) {
+        SY[(i - 1) * MDE_LB_LD + j] = rowS[i];
+        YY[(i - 1) * MDE_LB_LD + j] = rowY[i];
+      }
+      Sg = __shfl_down(Sg, 1, 64);
+      Yg = __shfl_down(Yg, 1, 64);
+      m = history;
+      __syncthreads();
+    }
+  }
+  // two-loop recursion in coefficient form: q = -g + sum cq_j y_j ; r = H q + sum cr_j s_j
+  const double rho = (j < m) ? 1.0 / SY[j * MDE_LB_LD + j] : 0.0;
+  double cq = 0.0, al = 0.0, cr = 0.0;
+  for (int i = m - 1; i >= 0; --i) {
+    const double part = (j < m) ? cq * SY[i * MDE_LB_LD + j] : 0.0;
+    const double sq = -__shfl(Sg, i, 64) + mde_wave_sum(part);
+    const double a = __shfl(rho, i, 64) * sq;
+    if (j == i) {
+      al = a;
+      cq = -a;
+    }
+  }
+  for (int i = 0; i < m; ++i) {
+    const double p1 = (j < m) ? cq * YY[i * MDE_LB_LD + j] : 0.0;
+    const double p2 = (j < m) ? cr * SY[j * MDE_LB_LD + i] : 0.0;
+    const double yq = -__shfl(Yg, i, 64) + mde_wave_sum(p1);
+    const double yr = H * yq + mde_wave_sum(p2);
+    if (j == i) cr = al - rho * yr;
+  }
+  // write back
+  if (j < m) {
+    dv->cs[j] = (float)cr;
+    dv->cy[j] = (float)(H * cq);
+  }
+  if (accepted) {
+    for (int i = 0; i < m; ++i) {
+      if (j < m) {
+        dv->SY[i * MDE_LB_LD + j] = SY[i * MDE_LB_LD + j];
+        dv->YY[i * MDE_LB_LD + j] = YY[i * MDE_LB_LD + j];
+      }
+    }
+    // slot permutation: the spare becomes the newest pair; when full, the oldest slot is the new spare
+    int ord = (j <= history) ? dv->order[j] : 0;
+    if (c == history) {
+      const int first = __shfl(ord, 0, 64);
+      const int next = __shfl_down(ord, 1, 64);
+      ord = (j < history) ? next : first;
+    }
+    __syncthreads();
+    if (j <= history) dv->order[j] = ord;
+  }
+  if (j == 0) {
+    dv->count = m;
+    dv->accepted = accepted ? 1 : 0;
+    dv->H = H;
+    dv->c_g = (float)(-H);
+  }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(MDE_BLOCK) void k_lbfgs_combine_dev(int64_t N, const float* __restrict__ g,
+                                                                 const float* __restrict__ buf,
+                                                                 const LbDev* __restrict__ dv, int done,
+                                                                 float* __restrict__ out) {
+  const int count = dv->count;
+  if (!FIRST && done >= count) return;
+  int pc = count - done;
+  if (pc > MDE_LB_GROUP) pc = MDE_LB_GROUP;
+  if (pc < 0) pc = 0;
+  const float c_g = dv->c_g;
+  const float* ps[MDE_LB_GROUP];
+  const float* py[MDE_LB_GROUP];
+  float cs[MDE_LB_GROUP], cy[MDE_LB_GROUP];
+#pragma unroll
+  for (int j = 0; j < MDE_LB_GROUP; ++j) {
+    const int slot = (j < pc) ? dv->order[done + j] : 0;
+    ps[j] = buf + (int64_t)(2 * slot) * N;
+    py[j] = buf + (int64_t)(2 * slot + 1) * N;
+    cs[j] = (j < pc) ? dv->cs[done + j] : 0.f;
+    cy[j] = (j < pc) ? dv->cy[done + j] : 0.f;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N;
+       i += (int64_t)gridDim.x * MDE_BLOCK) {
+    float v = FIRST ? c_g * g[i] : out[i];
+#pragma unroll
+    for (int j = 0; j < MDE_LB_GROUP; ++j)
+      if (j < pc) v = fmaf(cy[j], py[j][i], fmaf(cs[j], ps[j][i], v));
+    out[i] = v;
+  }
+}
+
+extern "C" int mde_lbfgs_dev_reset(mde_lbfgs* o, void* stream) {
+  if (!o || !o->dev) return MDE_E_INVALID;
+  hipLaunchKernelGGL(k_lbfgs_dev_reset, dim3(1), dim3(64), 0, mde_stream(stream), o->dev, o->history);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+// One whole L-BFGS direction update without a host round trip: stage (y = g - g_prev, s = t d,
+// g_prev <- g), accept / reject, two-loop recursion, d_out = the new direction, stats as
+// mde_vec_stats(g, d_out, NULL).  ASYNC.  (The host-driven mde_lbfgs_stage / commit / combine act on
+// the host-side bookkeeping and must not be mixed with this on one object.)
+extern "C" int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, const float* d, float t,
+                                  float* d_out, double* stats, double* work, void* stream) {
+  if (!o || !o->dev || !g || !g_prev || !d || !d_out || !stats || !work) return MDE_E_INVALID;
+  hipStream_t st = mde_stream(stream);
+  const int64_t N = o->N;
+  const int nb = mde_grid(N, MDE_BLOCK * 2, 2048);
+  double* partial = work + MDE_SMALL_DOUBLES;
+  double* dots = work;  // the small area: 4 + 5 * 63 doubles at most
+  const int groups = (o->history + MDE_LB_GROUP - 1) / MDE_LB_GROUP;
+  for (int gidx = 0; gidx < groups; ++gidx) {
+    if (gidx == 0)
+      hipLaunchKernelGGL((k_lbfgs_stage_dev<true>), dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t,
+                         o->buf, o->dev, 0, partial);
+    else
+      hipLaunchKernelGGL((k_lbfgs_stage_dev<false>), dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t,
+                         o->buf, o->dev, gidx * MDE_LB_GROUP, partial);
+    MDE_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_lbfgs_reduce_dev, dim3(4 + 5 * o->history), dim3(MDE_BLOCK), 0, st, nb, partial,
+                     o->dev, dots);
+  MDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_lbfgs_direction, dim3(1), dim3(64), 0, st, o->dev, dots, o->history);
+  MDE_LAUNCH_CHECK();
+  for (int gidx = 0; gidx < groups; ++gidx) {
+    if (gidx == 0)
+      hipLaunchKernelGGL((k_lbfgs_combine_dev<true>), dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, o->buf, o->dev, 0,
+                         d_out);
+    else
+      hipLaunchKernelGGL((k_lbfgs_combine_dev<false>), dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, o->buf, o->dev,
+                         gidx * MDE_LB_GROUP, d_out);
+    MDE_LAUNCH_CHECK();
+  }
+  return vec_stats_impl(N, g, d_out, nullptr, stats, work + MDE_SMALL_DOUBLES, st);
+}
+
+// copies of the device bookkeeping for tests: count, accepted
+extern "C" int mde_lbfgs_dev_info(const mde_lbfgs* o, int32_t* count_host, int32_t* accepted_host,
+                                  void* stream) {
+  if (!o || !o->dev || !count_host || !accepted_host) return MDE_E_INVALID;
+  hipStream_t st = mde_stream(stream);
+  int h[2] = {0, 0};
+  MDE_HIP(hipMemcpyAsync(h, o->dev, sizeof(h), hipMemcpyDeviceToHost, st));
+  MDE_HIP(hipStreamSynchronize(st));
+  *count_host = h[0];
+  *accepted_host = h[1];
   return MDE_OK;
 }
 

@@ -100,7 +100,6 @@ class _Engine(object):
         handle = ctypes.c_void_p()
         _lib.check(self.lib.mde_lbfgs_create(self.N, int(memory_size), ctypes.byref(handle)))
         self.lbfgs = handle
-        self.memory = _host.LbfgsMemory(memory_size)
 
     def close(self):
         if self.lbfgs is not None:
@@ -129,30 +128,18 @@ class _Engine(object):
 
     # ---- L-BFGS memory
     def reset_memory(self):
-        self.lib.mde_lbfgs_reset(self.lbfgs)
-        self.memory.reset()
+        _lib.check(self.lib.mde_lbfgs_dev_reset(self.lbfgs, self.stream()))
 
     def update_direction(self, t_prev):
-        """Stage (y, s), decide acceptance, form the new direction.  The statistics of (g, d) are
-        left in the second half of the board (``_DIR`` doubles in): they are not needed before the
-        first trial evaluation of the line search has been enqueued, so they travel with its
-        read-back instead of costing a synchronisation of their own."""
-        c = self.memory.count
-        ndots = 4 + 5 * c
-        _lib.check(self.lib.mde_lbfgs_stage(self.lbfgs, _lib.ptr(self.g), _lib.ptr(self.g_prev),
-                                            _lib.ptr(self.dir), float(t_prev), _lib.ptr(self.board),
-                                            _lib.ptr(self.work), self.stream()))
-        dots, _ = self.read_board(ndots)
-        accepted, Sg, Yg = self.memory.absorb(dots)
-        _lib.check(self.lib.mde_lbfgs_commit(self.lbfgs, 1 if accepted else 0))
-        c_g, cs, cy = self.memory.direction_coefficients(Sg, Yg)
-        m = self.memory.count
-        cs_arr = (ctypes.c_float * max(m, 1))(*[float(v) for v in cs])
-        cy_arr = (ctypes.c_float * max(m, 1))(*[float(v) for v in cy])
+        """Stage (y, s), accept or reject the pair, run the two-loop recursion and form the new
+        direction -- all on the device (``mde_lbfgs_dev_step``), no read-back.  The statistics of
+        (g, d) are left in the second half of the board (``_DIR`` doubles in): they are not needed
+        before the first trial evaluation of the line search has been enqueued, so they travel
+        with its read-back."""
         dir_board = ctypes.c_void_p(self.board.data_ptr() + 8 * _DIR)
-        _lib.check(self.lib.mde_lbfgs_combine(self.lbfgs, _lib.ptr(self.g), float(c_g), cs_arr, cy_arr,
-                                              _lib.ptr(self.dir), dir_board,
-                                              _lib.ptr(self.work), self.stream()))
+        _lib.check(self.lib.mde_lbfgs_dev_step(self.lbfgs, _lib.ptr(self.g), _lib.ptr(self.g_prev),
+                                               _lib.ptr(self.dir), float(t_prev), _lib.ptr(self.dir),
+                                               dir_board, _lib.ptr(self.work), self.stream()))
 
 
 class _NativeProblem(object):

@@ -253,3 +253,74 @@ def test_spectral_initialiser(golden_spectral):
     torch.manual_seed(0)
     emb = quadratic.spectral(n, m, mde.edges, torch.tensor(g["mid_weights"], device=DEV))
     assert float(mde.average_distortion(emb)) == pytest.approx(float(g["mid_value"]), rel=1e-3)
+
+
+def test_device_driven_lbfgs_step_matches_explicit_two_loop():
+    """mde_lbfgs_dev_step (history update, acceptance test and two-loop recursion all on the
+    device) against the explicit recursion of lbfgs.py:468-507 in float64, incl. the history
+    wrap-around (more than 8 pairs: two kernel groups) and a rejected pair (y.s <= 1e-10)."""
+    import ctypes
+    from pymde_amd import _lib, util
+    lib = _lib.load()
+    rng = np.random.default_rng(0)
+    N = 3001
+    A = rng.standard_normal((60, N))
+    diag = rng.uniform(0.5, 2.0, N)
+
+    def grad(x):  # SPD quadratic: y.s > 0
+        return diag * x + A.T @ (A @ x) / 60.0
+
+    for hist in (3, 10):
+        h = ctypes.c_void_p()
+        _lib.check(lib.mde_lbfgs_create(N, hist, ctypes.byref(h)))
+        st = _lib.stream_ptr(torch.device(DEV))
+        _lib.check(lib.mde_lbfgs_dev_reset(h, st))
+        work = util.work_buffer(torch.device(DEV), 2)
+        board = torch.zeros(64, dtype=torch.float64, device=DEV)
+        x = rng.standard_normal(N)
+        g_prev_np = grad(x)
+        d_np = -g_prev_np
+        g_prev = torch.tensor(g_prev_np, dtype=torch.float32, device=DEV)
+        d = torch.tensor(d_np, dtype=torch.float32, device=DEV)
+        S, Y = [], []
+        Hd = 1.0
+        for step in range(14):
+            t = 0.3
+            s32 = np.float32(t) * d.cpu().numpy()
+            reject = step == 11
+            if not reject:
+                x = x + s32.astype(np.float64)
+            g_np = grad(x).astype(np.float32) if not reject else g_prev.cpu().numpy().copy()
+            g = torch.tensor(g_np, device=DEV)
+            y32 = g_np - g_prev.cpu().numpy()
+            _lib.check(lib.mde_lbfgs_dev_step(h, _lib.ptr(g), _lib.ptr(g_prev), _lib.ptr(d), t,
+                                              _lib.ptr(d), _lib.ptr(board), _lib.ptr(work), st))
+            cnt, acc = ctypes.c_int32(0), ctypes.c_int32(0)
+            _lib.check(lib.mde_lbfgs_dev_info(h, ctypes.byref(cnt), ctypes.byref(acc), st))
+            ys = float(np.dot(y32.astype(np.float64), s32.astype(np.float64)))
+            assert bool(acc.value) == (ys > 1e-10) == (not reject)
+            if ys > 1e-10:
+                S.append(s32.astype(np.float64))
+                Y.append(y32.astype(np.float64))
+                if len(S) > hist:
+                    S.pop(0)
+                    Y.pop(0)
+                Hd = ys / float(np.dot(Y[-1], Y[-1]))
+            assert cnt.value == len(S)
+            # explicit two-loop recursion
+            q = -g_np.astype(np.float64)
+            ro = [1.0 / Y[i].dot(S[i]) for i in range(len(S))]
+            al = [0.0] * len(S)
+            for i in range(len(S) - 1, -1, -1):
+                al[i] = S[i].dot(q) * ro[i]
+                q -= al[i] * Y[i]
+            r = q * Hd
+            for i in range(len(S)):
+                r += (al[i] - Y[i].dot(r) * ro[i]) * S[i]
+            got = d.cpu().numpy().astype(np.float64)
+            assert np.abs(got - r).max() <= 2e-5 * np.abs(r).max(), (hist, step)
+            assert torch.equal(g_prev, g)                       # g_prev <- g
+            b = board.cpu().numpy()
+            assert b[0] == pytest.approx(float(np.dot(g_np.astype(np.float64), got)), rel=1e-6)   # g.d
+            assert b[5] == pytest.approx(float(np.dot(got, got)), rel=1e-6)                       # d.d
+        _lib.check(lib.mde_lbfgs_destroy(h))
