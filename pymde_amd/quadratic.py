@@ -29,29 +29,64 @@ from pymde_amd.functions import penalties
 
 
 class _Ops(object):
-    """Thin wrappers over the C ABI for [n, k] float32 blocks on one device."""
+    """Thin wrappers over the C ABI for [n, k] float32 blocks on one device.
+
+    Small matrices cross the PCIe bus through pinned staging buffers: a Gram matrix costs one
+    asynchronous copy + one stream synchronisation, a right-multiplication none (its matrix is
+    staged in a ring of pinned buffers; a ring entry is reused only after a later
+    synchronisation has retired the copy that read it)."""
+
+    _RING = 16
 
     def __init__(self, n, device, kmax):
         self.lib = _lib.load()
         self.n = int(n)
         self.device = device
         self.work = util.work_buffer(device, max(kmax, 4))
+        self._stream_obj = torch.cuda.current_stream(device)
+        self._stream_ptr = _lib.stream_ptr(device)
+        self._host_out = torch.empty(max(kmax, 4) ** 2, dtype=torch.float64).pin_memory()
+        self._ring_cap = min(max(kmax, 4), 64) ** 2   # larger matrices take the synchronous path
+        self._ring = [torch.empty(self._ring_cap, dtype=torch.float64).pin_memory()
+                      for _ in range(self._RING)]
+        self._ring_next = 0      # next ring entry to use
+        self._ring_used = 0      # entries handed out since the last synchronisation
 
     def _stream(self):
-        return _lib.stream_ptr(self.device)
+        return self._stream_ptr
 
     def gram(self, A, B):
-        out = torch.empty((A.shape[1], B.shape[1]), dtype=torch.float64, device=self.device)
-        _lib.check(self.lib.mde_gram(self.n, A.shape[1], B.shape[1], _lib.ptr(A), _lib.ptr(B),
+        da, db = A.shape[1], B.shape[1]
+        out = torch.empty(da * db, dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mde_gram(self.n, da, db, _lib.ptr(A), _lib.ptr(B),
                                      _lib.ptr(out), _lib.ptr(self.work), self._stream()))
-        return out.cpu().numpy()
+        host = self._host_out[:da * db]
+        host.copy_(out, non_blocking=True)
+        self._stream_obj.synchronize()
+        self._ring_used = 0
+        return host.numpy().reshape(da, db).copy()
+
+    def _upload(self, M):
+        """Small host float64 matrix -> device, without waiting for the copy."""
+        if M.size > self._ring_cap:
+            Md = torch.from_numpy(M).to(self.device)
+            self._stream_obj.synchronize()   # the pageable source must outlive the copy
+            return Md.reshape(-1)
+        if self._ring_used >= self._RING:
+            self._stream_obj.synchronize()
+            self._ring_used = 0
+        buf = self._ring[self._ring_next][:M.size]
+        self._ring_next = (self._ring_next + 1) % self._RING
+        self._ring_used += 1
+        buf.numpy()[:] = M.reshape(-1)
+        Md = torch.empty(M.size, dtype=torch.float64, device=self.device)
+        Md.copy_(buf, non_blocking=True)
+        return Md
 
     def rmul(self, A, M, alpha=1.0, base=None, out=None):
         """out = base + alpha * A @ M  (M: small host float64 matrix)."""
         M = np.ascontiguousarray(M, dtype=np.float64)
-        # small host matrix -> device; keep the upload ordered before its host buffer can go away
-        Md = torch.from_numpy(M).to(self.device)
-        torch.cuda.current_stream(self.device).synchronize()
+        Md = self._upload(M)
         if out is None:
             out = torch.empty((self.n, M.shape[1]), dtype=torch.float32, device=self.device)
         _lib.check(self.lib.mde_right_multiply_add(self.n, A.shape[1], M.shape[1], _lib.ptr(A),
@@ -118,20 +153,11 @@ def _lobpcg(lap, k, max_iter, tol, device):
     ops = _Ops(n, device, 3 * k)
 
     def orthonormal(blocks):
-        """Orthonormal basis of the span of the given [n, *] blocks (explicit vectors)."""
-        sizes = [b.shape[1] for b in blocks]
-        offs = np.cumsum([0] + sizes)
-        m = int(offs[-1])
-        G = np.zeros((m, m))
-        for a in range(len(blocks)):
-            for b in range(a, len(blocks)):
-                G[offs[a]:offs[a + 1], offs[b]:offs[b + 1]] = ops.gram(blocks[a], blocks[b])
-        G = np.triu(G) + np.triu(G, 1).T
-        M = _orthonormalizer(G)
-        out = None
-        for a, blk in enumerate(blocks):
-            out = ops.rmul(blk, M[offs[a]:offs[a + 1], :], base=out, out=out)
-        # one re-orthonormalisation pass removes the fp32 error of the first
+        """Orthonormal basis of the span of the given [n, *] blocks (explicit vectors): one Gram
+        matrix of the concatenated block, one right-multiplication, then one re-orthonormalisation
+        pass that removes the fp32 error of the first."""
+        S = blocks[0] if len(blocks) == 1 else torch.cat(blocks, dim=1).contiguous()
+        out = ops.rmul(S, _orthonormalizer(_sym(ops.gram(S, S))))
         return ops.rmul(out, _orthonormalizer(ops.gram(out, out)))
 
     X = orthonormal([ops.center(torch.randn((n, k), device=device, dtype=torch.float32))])
