@@ -143,8 +143,13 @@ def _sym(A):
     return 0.5 * (A + A.T)
 
 
-def _lobpcg(lap, k, max_iter, tol, device):
+def _lobpcg(lap, k, max_iter, tol, device, scale_by_operator=False):
     """Block LOBPCG for the k smallest non-trivial eigenpairs of the Laplacian.
+
+    Convergence: ``||r_i|| <= tol |theta_i|`` per Ritz pair, or, with ``scale_by_operator``, the
+    test of ``torch.lobpcg`` that the reference's GPU branch runs (quadratic.py:109-116):
+    ``||r_i|| <= tol (||L X_0||_F + |theta_i| ||X_0||_F)`` -- residuals measured against the scale
+    of the operator rather than against the (small) eigenvalue itself.
 
     Every iteration builds an explicitly orthonormal basis Q of span[X, W, P] and applies L to
     it afresh, so the Rayleigh-Ritz matrices always belong to the vectors actually held (no
@@ -165,14 +170,21 @@ def _lobpcg(lap, k, max_iter, tol, device):
         raise util.SolverError("spectral: the random start block is rank deficient")
     P = None
     theta = None
+    op_norm = None
     for _ in range(max_iter):
         LX = lap.apply(X)
+        if scale_by_operator and op_norm is None:
+            op_norm = float(np.sqrt(max(np.trace(ops.gram(LX, LX)), 0.0)))
         A = _sym(ops.gram(X, LX))
         theta, C = np.linalg.eigh(A)
         X, LX = ops.rmul(X, C), ops.rmul(LX, C)       # Ritz vectors of the current block
         R = ops.rmul(X, np.diag(theta), alpha=-1.0, base=LX)   # residual L X - X diag(theta)
         rnorm = np.sqrt(np.maximum(np.diag(ops.gram(R, R)), 0.0))
-        if np.all(rnorm <= tol * np.maximum(np.abs(theta), 1e-12)):
+        if scale_by_operator:
+            bound = tol * (op_norm + np.abs(theta) * np.sqrt(float(k)))
+        else:
+            bound = tol * np.maximum(np.abs(theta), 1e-12)
+        if np.all(rnorm <= bound):
             break
         W = ops.center(ops.row_scale(R, lap.inv_degree))  # Jacobi-preconditioned, orthogonal to 1
         Q = orthonormal([X, W] if P is None else [X, W, P])
@@ -192,9 +204,11 @@ def spectral(n_items, embedding_dim, edges, weights, cg=False, max_iter=40, devi
     """Spectral embedding: the ``embedding_dim`` bottom non-trivial Laplacian eigenvectors,
     centred and standardized.
 
-    ``cg`` is accepted for signature compatibility (quadratic.py:122-124): both settings run the
-    device LOBPCG; ``cg=False`` iterates to a tight tolerance (the reference's Lanczos branch),
-    ``cg=True`` stops after ``max_iter`` iterations at most.
+    Both settings of ``cg`` run the device LOBPCG.  ``cg=False`` iterates to a tight tolerance
+    relative to the eigenvalues (the accuracy of the reference's Lanczos branch,
+    quadratic.py:84-92); ``cg=True`` is the reference's GPU branch (quadratic.py:109-116): at most
+    ``max_iter`` iterations with ``torch.lobpcg``'s default test, residuals below sqrt(float32 eps)
+    relative to the scale of the operator.
     """
     if device is None:
         device = edges.device if isinstance(edges, torch.Tensor) and edges.is_cuda else \
@@ -202,10 +216,10 @@ def spectral(n_items, embedding_dim, edges, weights, cg=False, max_iter=40, devi
     device = util.require_cuda_device(device)
     n, m = int(n_items), int(embedding_dim)
     iters = max(int(max_iter), 1) if cg else max(5 * n, 200)
-    tol = 1e-3 if cg else 1e-5
+    tol = float(np.sqrt(np.finfo(np.float32).eps)) if cg else 1e-5
     with torch.no_grad(), torch.cuda.device(device):
         lap = _Laplacian(n, edges, weights, device)
-        _, V = _lobpcg(lap, m, iters, tol, device)
+        _, V = _lobpcg(lap, m, iters, tol, device, scale_by_operator=bool(cg))
         _Ops(n, device, m).center(V)
         return util.proj_standardized(V.contiguous(), demean=False)
 

@@ -16,8 +16,8 @@ def tm(f, *a, **k):
 (e, w), t = tm(preprocess.k_nearest_neighbors, data, 15); print("kNN %.3f s (2nd)" % t)
 import pymde_amd.quadratic as q
 orig = q._lobpcg
-def counted(lap, k, max_iter, tol, device):
-    t0 = time.time(); out = orig(lap, k, max_iter, tol, device); torch.cuda.synchronize()
+def counted(*a, **kw):
+    t0 = time.time(); out = orig(*a, **kw); torch.cuda.synchronize()
     print("  lobpcg: %.3f s" % (time.time() - t0)); return out
 q._lobpcg = counted
 X, t = tm(quadratic.spectral, n, 2, e, w, cg=True, max_iter=1000, device=dev); print("spectral %.3f s" % t)
