@@ -5,7 +5,7 @@
 // cores (v_mfma_f32_32x32x2_f32, exact f32): a 256-thread workgroup owns 64 query rows and walks
 // the candidates 64 at a time; each wave accumulates one 32x32 quadrant of the 64x64 tile over the
 // features, staged through LDS in 32-wide chunks (rows padded to 33 floats: conflict-free operand
-// reads).  The tile of squared distances is parked in LDS and one thread per query row merges its
+// reads; the next chunk's global loads overlap the current chunk's MFMAs).  The tile of squared distances is parked in LDS and one thread per query row merges its
 // 64 candidates into the row's sorted top-k list (insertion only when a candidate beats the current
 // k-th best, which becomes rare quickly).  Self matches are excluded by index.
 #include "mde_common.h"
@@ -57,18 +57,33 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_knn(int n, int nf, int k, const f
     f32x16 acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
-    for (int k0 = 0; k0 < nf; k0 += KNN_KB) {
-      __syncthreads();
-      // stage 64 x 32 chunks of the query rows and of the candidate rows (coalesced along features)
+    // feature chunks of KNN_KB: the next chunk's global loads are issued before the MFMAs of the
+    // current one and committed to LDS after them (register double buffering), so the matrix
+    // cores do not wait for the staging latency
+    constexpr int STG = (KNN_BM * KNN_KB) / MDE_BLOCK;
+    float ra[STG], rb[STG];
+    auto fetch = [&](int k0) {
 #pragma unroll
-      for (int q = 0; q < (KNN_BM * KNN_KB) / MDE_BLOCK; ++q) {
+      for (int q = 0; q < STG; ++q) {
         const int e = tid + q * MDE_BLOCK;
         const int r = e >> 5, c = e & 31;
         const int gr = row0 + r, gc = col0 + r, f = k0 + c;
-        sA[r * KNN_KBP + c] = (gr < n && f < nf) ? X[(int64_t)gr * nf + f] : 0.0f;
-        sB[r * KNN_KBP + c] = (gc < n && f < nf) ? X[(int64_t)gc * nf + f] : 0.0f;
+        ra[q] = (gr < n && f < nf) ? X[(int64_t)gr * nf + f] : 0.0f;
+        rb[q] = (gc < n && f < nf) ? X[(int64_t)gc * nf + f] : 0.0f;
+      }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < nf; k0 += KNN_KB) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < STG; ++q) {
+        const int e = tid + q * MDE_BLOCK;
+        const int r = e >> 5, c = e & 31;
+        sA[r * KNN_KBP + c] = ra[q];
+        sB[r * KNN_KBP + c] = rb[q];
       }
       __syncthreads();
+      if (k0 + KNN_KB < nf) fetch(k0 + KNN_KB);
       const float* pa = sA + (wi * 32 + li) * KNN_KBP + lk;
       const float* pb = sB + (wj * 32 + li) * KNN_KBP + lk;
 #pragma unroll
