@@ -220,7 +220,7 @@ static int build_panels(mde_plan* plan, int d, hipStream_t st) {
   int32_t *peid = nullptr, *tile_ptr = nullptr, *sub_ptr = nullptr, *sub_off = nullptr, *iters = nullptr;
   int32_t* next_tile = nullptr;
   hipError_t e = hipSuccess;
-  auto fail = [&](hipError_t err, const char* what) {
+  auto release = [&]() {
     if (keys) (void)hipFree(keys);
     if (vals) (void)hipFree(vals);
     if (keys2) (void)hipFree(keys2);
@@ -233,6 +233,9 @@ static int build_panels(mde_plan* plan, int d, hipStream_t st) {
     if (sub_off) (void)hipFree(sub_off);
     if (iters) (void)hipFree(iters);
     if (next_tile) (void)hipFree(next_tile);
+  };
+  auto fail = [&](hipError_t err, const char* what) {
+    release();
     return mde_hip_fail(err, what, __FILE__, __LINE__);
   };
   const size_t hb = (size_t)H * sizeof(uint32_t);
@@ -281,7 +284,7 @@ static int build_panels(mde_plan* plan, int d, hipStream_t st) {
   PB(hipStreamSynchronize(st));
   const int64_t Hp = (int64_t)total_iters * 64;  // padded half-edge count
   if (total_iters <= 0 || Hp >= ((int64_t)1 << 31) - 64) {
-    (void)fail(hipSuccess, "panel layout");
+    release();
     return 0;  // too large for 32-bit positions: the caller keeps the CSR layout
   }
   PB(hipMalloc(&packed, (size_t)Hp * sizeof(uint32_t)));
