@@ -87,3 +87,41 @@ def test_distances_reproducibility(n_items):         # test_recipes.py:138-160
         if prev is not None:
             assert torch.equal(cur[0], prev[0]) and torch.equal(cur[1], prev[1])
         prev = cur
+
+
+def _assert_close_up_to_sign(x, y, rtol=1e-4, atol=1e-5):
+    try:
+        np.testing.assert_allclose(x, y, rtol=rtol, atol=atol)
+    except AssertionError:
+        np.testing.assert_allclose(-x, y, rtol=rtol, atol=atol)
+
+
+def test_pca():                                      # test_quadratic.py:10-64
+    import pymde_amd
+    torch.random.manual_seed(0)
+    np.random.seed(0)
+    for n, k in ((5, 5), (5, 4), (4, 5)):
+        Y = np.random.randn(n, k).astype(np.float32)
+        Y -= Y.mean(axis=0)
+        top = min(n, k) - 1 if n <= k else k - 1      # the centred matrix has rank <= n - 1
+        for m in range(1, top + 1):
+            X = pymde_amd.pca(torch.tensor(Y, device=DEV), m).cpu().numpy()
+            np.testing.assert_allclose(1.0 / n * X.T @ X, np.eye(m), rtol=1e-4, atol=2e-5)
+            U, _, _ = np.linalg.svd(Y)
+            X_unscaled = 1.0 / np.sqrt(n) * X
+            for col in range(m):
+                _assert_close_up_to_sign(X_unscaled[:, col], U[:, col], rtol=1e-3, atol=1e-4)
+        with pytest.raises(ValueError, match=r"Embedding dimension must be at most.*"):
+            pymde_amd.pca(torch.tensor(Y, device=DEV), min(n, k) + 1)
+
+
+def test_rng():                                      # test_util.py:74-83
+    from pymde_amd import util
+    util.seed(0)
+    tensor = torch.randn((10, 5))
+    from_random_state = np.random.randn(10, 5)
+    from_rng = util.np_rng().standard_normal((10, 5))
+    util.seed(0)
+    assert torch.equal(tensor, torch.randn((10, 5)))
+    np.testing.assert_array_equal(from_random_state, np.random.randn(10, 5))
+    np.testing.assert_array_equal(from_rng, util.np_rng().standard_normal((10, 5)))
