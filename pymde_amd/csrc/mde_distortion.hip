@@ -18,7 +18,7 @@
 
 double* mde_plan_partials(mde_plan* p);
 float mde_plan_avg_degree(const mde_plan* p);
-int mde_panel_try(mde_plan* plan, const float* X, int d, const mde_func* f, float grad_scale,
+int mde_ring_try(mde_plan* plan, const float* X, int d, const mde_func* f, float grad_scale,
                   float* grad, float inv_p, hipStream_t st, int* nblocks, float* loss_out,
                   double loss_scale);
 
@@ -418,11 +418,11 @@ extern "C" int mde_average_distortion(mde_plan* plan, const float* X, int32_t d,
   // every edge is seen from both endpoints: weight 1/2; mean over p edges
   const double scale = p > 0 ? 0.5 / (double)p : 0.0;
   if (f->layout == 1) {
-    // parameters are in column-panel order: the LDS-tiled kernel (mde_panel.hip), which also
+    // parameters are in LDS-ring order: the LDS-resident kernel (mde_ring.hip), which also
     // reduces the loss (last workgroup to arrive)
-    rc = mde_panel_try(plan, X, d, f, grad_scale, grad, A.inv_p, A.st, &A.nblocks, loss_out, scale);
+    rc = mde_ring_try(plan, X, d, f, grad_scale, grad, A.inv_p, A.st, &A.nblocks, loss_out, scale);
     if (rc == 0) {
-      mde_set_error("mde_func.layout = 1 but the plan has no panel layout for d = %d", d);
+      mde_set_error("mde_func.layout = 1 but the plan has no LDS-ring layout for d = %d", d);
       return MDE_E_INVALID;
     }
     return rc < 0 ? rc : MDE_OK;

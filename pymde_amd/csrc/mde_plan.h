@@ -2,23 +2,21 @@
 #pragma once
 #include "mde_common.h"
 
-// Column-panel layout for the LDS-tiled small-d kernel (built lazily, per embedding dim).
-// Half-edges are grouped into tiles (row block rb, column panel cp), sorted by row inside a
-// tile; tile t = rb * n_panels + cp covers [tile_ptr[t], tile_ptr[t+1]).
-#ifndef MDE_PANEL_WAVES
-#define MDE_PANEL_WAVES 16  // waves per workgroup of the panel kernel (64 * WAVES threads)
-#endif
-struct mde_panel_layout {
-  int d = 0;            // embedding dimension the tile sizes were chosen for
-  int rows_per_block = 0, cols_per_panel = 0;
-  int n_row_blocks = 0, n_panels = 0;
-  int64_t H = 0;                // padded entry count: 64 * (wave iterations of all sub-ranges)
-  uint32_t* packed = nullptr;   // [H] LDS row address << 17 | LDS panel offset (padding: MDE_PANEL_DUMMY)
+// LDS-ring layout of the small-d kernel (mde_ring.hip; built lazily, per embedding dim).
+// A 1024-thread workgroup (row block rb, column group qg) runs MDE_RING_NCW consumer waves; the
+// stream of consumer wave w is the wave iterations [wave_iter[s], wave_iter[s + 1]) with
+// s = (rb * col_groups + qg) * NCW + w, 64 packed half-edges each, chunk-major.
+struct mde_ring_layout {
+  int d = 0;                    // embedding dimension the sizes were chosen for
+  int rows_per_block = 0, n_row_blocks = 0;
+  int col_groups = 1;           // Q: workgroups per row block, each walking 1/Q of the chunks
+  int chunk_cols = 0, n_chunks = 0;
+  int64_t n_iters = 0;          // wave iterations of all streams
+  int64_t H = 0;                // padded entry count = 64 * n_iters
+  uint32_t* packed = nullptr;   // [H] LDS row address << 17 | ring byte offset
   int32_t* eid = nullptr;       // [H] original edge id (parameter expansion), -1 for padding
-  int32_t* next_tile = nullptr; // [n_row_blocks * (n_panels + 1)] first non-empty panel >= cp of a row block
-  int32_t* sub_off = nullptr;   // [n_tiles * MDE_PANEL_WAVES + 1] first wave iteration of each
-                                // (tile, wave) sub-range; entries [64 * sub_off[i], 64 * sub_off[i+1])
-  int col_groups = 1;           // Q: workgroups per row block, each walking 1/Q of the panels
+  uint32_t* hdr = nullptr;      // [n_iters] chunk window, fold rounds and padding flag of an iteration
+  int32_t* wave_iter = nullptr; // [n_row_blocks * col_groups * NCW + 1]
   float* partial = nullptr;     // [Q * nloc * d] per-group gradient partials (Q > 1 only)
 };
 
@@ -29,5 +27,5 @@ struct mde_plan {
   int32_t* eid = nullptr;
   double* partials = nullptr;  // [MDE_MAX_PARTIALS] loss partial sums of the fused kernel
   float avg_degree = 0.f;
-  mde_panel_layout panel;      // empty until mde_plan_build_panels succeeds
+  mde_ring_layout ring;        // empty until mde_plan_layout builds it
 };

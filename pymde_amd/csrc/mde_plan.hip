@@ -46,6 +46,7 @@ extern "C" const int32_t* mde_plan_eid(const mde_plan* p) { return p ? p->eid : 
 
 // internal accessor used by the kernel translation unit
 double* mde_plan_partials(mde_plan* p) { return p->partials; }
+void mde_ring_release(mde_plan* plan);  // mde_ring.hip
 float mde_plan_avg_degree(const mde_plan* p) { return p->avg_degree; }
 
 extern "C" int mde_plan_destroy(mde_plan* plan) {
@@ -54,11 +55,7 @@ extern "C" int mde_plan_destroy(mde_plan* plan) {
   if (plan->nbr) (void)hipFree(plan->nbr);
   if (plan->eid) (void)hipFree(plan->eid);
   if (plan->partials) (void)hipFree(plan->partials);
-  if (plan->panel.packed) (void)hipFree(plan->panel.packed);
-  if (plan->panel.eid) (void)hipFree(plan->panel.eid);
-  if (plan->panel.next_tile) (void)hipFree(plan->panel.next_tile);
-  if (plan->panel.sub_off) (void)hipFree(plan->panel.sub_off);
-  if (plan->panel.partial) (void)hipFree(plan->panel.partial);
+  mde_ring_release(plan);
   delete plan;
   return MDE_OK;
 }
@@ -242,9 +239,10 @@ extern "C" int mde_plan_create(int64_t n, int64_t p, const int64_t* edges, int64
   } while (0)
 
   PLAN_HIP(hipMalloc(&plan->rowptr, (nloc + 1) * sizeof(int32_t)));
-  // (+1: the slot after the partials is the arrival counter of the in-kernel loss reduction)
-  PLAN_HIP(hipMalloc(&plan->partials, (MDE_MAX_PARTIALS + 1) * sizeof(double)));
-  PLAN_HIP(hipMemsetAsync(plan->partials + MDE_MAX_PARTIALS, 0, sizeof(double), st));
+  // (+2: the slot after the partials is the arrival counter of the in-kernel loss reduction, the
+  // one after it a scratch flag of mde_plan_expand_codebook)
+  PLAN_HIP(hipMalloc(&plan->partials, (MDE_MAX_PARTIALS + 2) * sizeof(double)));
+  PLAN_HIP(hipMemsetAsync(plan->partials + MDE_MAX_PARTIALS, 0, 2 * sizeof(double), st));
   int32_t Hlocal = 0;
   if (H2 > 0) {
     const size_t bytes = (size_t)H2 * sizeof(uint32_t);

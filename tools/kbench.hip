@@ -6,6 +6,7 @@
 // probes: stream-only, gather-only, one-sided + global fp32 atomics.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <vector>
@@ -173,7 +174,7 @@ int main(int argc, char** argv) {
   CK(hipEventRecord(b2, st));
   CK(hipEventSynchronize(b2));
   CK(hipEventElapsedTime(&ms, a2, b2));
-  printf("layout=%d (0 CSR, 1 LDS column panels) layout_build_ms=%.2f\n", layout, ms);
+  printf("layout=%d (0 CSR, 1 LDS ring) layout_build_ms=%.2f\n", layout, ms);
   if (layout < 0) { printf("layout error %s\n", mde_last_error()); return 1; }
   const int64_t Hl = mde_plan_layout_half_edges(plan, layout);
   printf("layout entries %lld (%.1f%% padding)\n", (long long)Hl, 100.0 * (Hl - H) / (double)H);
@@ -227,6 +228,37 @@ int main(int argc, char** argv) {
         printf("fused PushPull(Log1p,Log) d=2, codebook stream: %.3f ms\n", t);
       }
     }
+  }
+  if (layout == 1) {
+    // correctness: the LDS-ring result against the CSR kernel on the same plan
+    float *wh0, *grad0, *loss0;
+    CK(hipMalloc(&wh0, (size_t)H * 4));
+    CK(hipMalloc(&grad0, n * 2 * 4));
+    CK(hipMalloc(&loss0, 64));
+    MK(mde_plan_expand_layout(plan, 0, w, wh0, st));
+    mde_func f0 = f;
+    f0.a0 = wh0;
+    f0.layout = 0;
+    MK(mde_average_distortion(plan, X, 2, &f0, 1.0f, grad0, loss0, st));
+    MK(mde_average_distortion(plan, X, 2, &f, 1.0f, grad, loss, st));
+    CK(hipStreamSynchronize(st));
+    std::vector<float> g1(n * 2), g0(n * 2);
+    float l1, l0;
+    CK(hipMemcpy(g1.data(), grad, n * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(g0.data(), grad0, n * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&l1, loss, 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&l0, loss0, 4, hipMemcpyDeviceToHost));
+    double maxd = 0, maxg = 0;
+    int64_t bad = 0;
+    for (int64_t i = 0; i < n * 2; ++i) {
+      const double dd = fabs((double)g1[i] - (double)g0[i]);
+      if (!(dd <= 1e30)) ++bad;
+      maxd = std::max(maxd, dd);
+      maxg = std::max(maxg, fabs((double)g0[i]));
+    }
+    printf("check vs CSR kernel: loss %.8f vs %.8f, max |dgrad| %.3e (max |grad| %.3e, rel %.2e), non-finite %lld  %s\n",
+           l1, l0, maxd, maxg, maxd / maxg, (long long)bad,
+           (maxd <= 1e-4 * maxg && fabs(l1 - l0) <= 1e-5 * fabs(l0) && bad == 0) ? "OK" : "MISMATCH");
   }
   if (!getenv("MDE_GROUP") && layout == 0) {
     const int* nbr = mde_plan_nbr(plan);
