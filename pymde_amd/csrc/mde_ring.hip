@@ -48,12 +48,20 @@
 #define MDE_RING_CTRL_CB (MDE_RING_CTRL_OFF + 96)     // float[8]: parameter codebook
 #define MDE_RING_NCW 14            // consumer waves
 #define MDE_RING_NPROD 2           // producer waves
+#ifndef MDE_RING_STAGE
+#define MDE_RING_STAGE 0            // 1: producers stage chunks through VGPRs (in flight in registers), 0: LDS-DMA
+#endif
 #define MDE_RING_BS 1024
-#define MDE_RING_DEPTH 3           // chunks in flight per producer
+#ifndef MDE_RING_DEPTH
+#define MDE_RING_DEPTH 2           // chunks in flight per producer (<= 3)
+#endif
 #ifndef MDE_RING_PF
 #define MDE_RING_PF 8              // stream slots prefetched per consumer wave
 #endif
 #define MDE_RING_CB_VALUES 8
+#ifndef MDE_RING_DMA_IMM
+#define MDE_RING_DMA_IMM 1
+#endif
 #define MDE_RING_DONE 0x7fffffff
 
 // chunk geometry per embedding dimension: CBYTES bytes (PIECES x 1 KiB DMA pieces) per chunk
@@ -62,7 +70,12 @@ __host__ __device__ constexpr int ring_chunk_bytes(int d) { return ring_chunk_co
 __host__ __device__ constexpr int ring_slots(int d) { return MDE_RING_BYTES / ring_chunk_bytes(d); }
 // an iteration may reference chunks m .. m + span, span <= S - NPROD * DEPTH: the producers keep
 // their full depth in flight while the slowest consumer sits on its window
-__host__ __device__ constexpr int ring_max_span(int d) { return ring_slots(d) - MDE_RING_NPROD * MDE_RING_DEPTH; }
+__host__ __device__ constexpr int ring_max_span(int d) {
+#ifdef MDE_RING_SPAN
+  return MDE_RING_SPAN;
+#endif
+  return MDE_RING_STAGE ? ring_slots(d) - MDE_RING_NPROD - 2 : ring_slots(d) - MDE_RING_NPROD * MDE_RING_DEPTH;
+}
 
 // header word of a wave iteration: [15:0] m = lowest chunk referenced, [19:16] span (highest = m +
 // span), [25:20] DPP fold rounds (longest run of equal rows - 1), [26] the iteration has padding
@@ -127,46 +140,138 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_seg(int64_t H, uint32_t nseg
   }
 }
 
-// Cut each (block, group, wave) stream into wave iterations of <= 64 consecutive entries whose
-// chunks span at most SPAN (the ring holds them all at once).  FILL = false counts, FILL = true
-// writes the source range of every iteration.
+// Cut each (block, group, wave) stream into wave iterations: up to 64 entries, taken in stream
+// order, whose chunks lie within SPAN of the oldest one (the ring holds them all at once).  An
+// entry whose row already has an earlier entry in the same iteration is deferred to the next
+// one (at most `defer` times, then it goes out regardless): the kernel's common case is an
+// iteration of 64 distinct rows -- every lane does its own read-add-write, no folding -- and a
+// row's entries still reach its accumulator in stream order.  Lanes freed by deferred entries
+// are refilled from the stream (a few rounds), so iterations stay full.
+// One wave per stream; FILL = false counts the iterations, FILL = true writes, per iteration, the
+// sorted positions of its entries, their number and the oldest chunk still needed (it_m).
+#ifndef MDE_RING_DEFER
+#define MDE_RING_DEFER 2
+#endif
+#define MDE_RING_CARRY 192  // deferred entries a stream can hold (more: they go out with duplicates)
 template <bool FILL>
-__global__ __launch_bounds__(MDE_BLOCK) void k_ring_iters(int nseg, const int32_t* __restrict__ seg,
-                                                          const uint32_t* __restrict__ keys, uint32_t JM, int SPAN,
-                                                          int32_t* __restrict__ iters,
-                                                          const int32_t* __restrict__ iter_base,
-                                                          int32_t* __restrict__ it_src, int32_t* __restrict__ it_cnt) {
-  const int i = blockIdx.x * MDE_BLOCK + threadIdx.x;
+__global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* __restrict__ seg,
+                                                      const int32_t* __restrict__ bounds,
+                                                      const uint32_t* __restrict__ keys,
+                                                      const uint32_t* __restrict__ vals,
+                                                      const int32_t* __restrict__ hrow, uint32_t JM, int SPAN,
+                                                      int R, int Q, int NC, int32_t* __restrict__ iters,
+                                                      const int32_t* __restrict__ iter_base,
+                                                      int32_t* __restrict__ it_ent, int32_t* __restrict__ it_cnt,
+                                                      int32_t* __restrict__ it_m) {
+  __shared__ int flag[4096];                // per row of the block: priority of the entry that holds it
+  __shared__ int cq_pos[2][MDE_RING_CARRY]; // deferred entries (sorted position), double buffered
+  __shared__ int cq_age[2][MDE_RING_CARRY];
+  __shared__ int em[64];                    // entries of the iteration being formed
+  const int i = blockIdx.x, lane = threadIdx.x;
   if (i >= nseg) return;
-  int pos = seg[i];
-  const int end = seg[i + 1];
-  int out = FILL ? iter_base[i] : 0;
-  while (pos < end) {
-    int take = min(64, end - pos);
-    const uint32_t lim = (keys[pos] & JM) + (uint32_t)SPAN;
-    if ((keys[pos + take - 1] & JM) > lim) {
-      int a = 1, b = take - 1;  // largest t in [1, take) with chunk(pos + t - 1) <= lim
-      while (a < b) {
-        const int mid = (a + b + 1) >> 1;
-        if ((keys[pos + mid - 1] & JM) <= lim) a = mid; else b = mid - 1;
+  for (int r = lane; r < 4096; r += 64) flag[r] = 0x7fffffff;
+  __syncthreads();
+  const int beg = seg[i], end = seg[i + 1];
+  const int rb = (i / MDE_RING_NCW) / Q, w = i % MDE_RING_NCW;
+  // few rows per wave (small problems): most entries of an iteration collide anyway -- no deferral
+  const int nrows = bounds[rb * (MDE_RING_NCW + 1) + w + 1] - bounds[rb * (MDE_RING_NCW + 1) + w];
+  const int defer = nrows >= 160 ? MDE_RING_DEFER : 0;
+  const int first = FILL ? iter_base[i] : 0;
+  int out = first, next = beg, nc = 0, cur = 0;
+  int last_chunk = (int)(((int64_t)((i / MDE_RING_NCW) % Q) * NC + Q - 1) / Q);
+  while (nc > 0 || next < end) {
+    const int m = (int)(keys[nc > 0 ? cq_pos[cur][0] : next] & JM);  // oldest candidate's chunk
+    const int lim = m + SPAN;
+    int nem = 0, nnew = 0;  // emitted so far, deferred so far (into buffer cur ^ 1)
+    // offer a batch of candidates (stream order = ascending priority); prio0 keeps later batches
+    // behind earlier ones on a row's flag
+    auto offer = [&](int pos, int age, int prio) {
+      int row = 0;
+      if (pos >= 0) {
+        row = hrow[vals[pos]] - rb * R;
+        atomicMin(&flag[row], prio);
       }
-      take = a;
+      __syncthreads();
+      const bool room = true;
+      const bool win = pos >= 0 && (flag[row] == prio || age >= defer);
+      (void)room;
+      // winners beyond the 64th wait as well (they keep their turn: age unchanged)
+      const unsigned long long wm = __ballot(win);
+      const int widx = nem + __popcll(wm & ((1ull << lane) - 1ull));
+      const bool emit = win && widx < 64;
+      if (emit) em[widx] = pos;
+      const bool lose = pos >= 0 && !emit;
+      const unsigned long long lm = __ballot(lose);
+      const int lidx = nnew + __popcll(lm & ((1ull << lane) - 1ull));
+      if (lose && lidx < MDE_RING_CARRY) {
+        cq_pos[cur ^ 1][lidx] = pos;
+        cq_age[cur ^ 1][lidx] = win ? age : age + 1;
+      }
+      // (overflow of the deferral queue cannot happen: a batch is only offered while
+      // nnew + 64 <= MDE_RING_CARRY)
+      nem += __popcll(__ballot(emit));
+      nnew += __popcll(lm);
+      __syncthreads();
+    };
+    int prio = 0;
+    // the deferred entries first, 64 at a time
+    for (int c0 = 0; c0 < nc; c0 += 64) {
+      const int k = c0 + lane;
+      offer(k < nc ? cq_pos[cur][k] : -1, k < nc ? cq_age[cur][k] : 0, prio + lane);
+      prio += 64;
     }
+    // then new entries while lanes are free and the window allows (a few rounds: entries that
+    // collide leave their lane to the next ones)
+    for (int round = 0; round < 4 && nem < 64 && next < end && nnew + 64 <= MDE_RING_CARRY; ++round) {
+      const int want = 64 - nem;
+      const int cand = next + lane;
+      const bool take = lane < want && cand < end && (int)(keys[cand] & JM) <= lim;
+      const int ntake = __popcll(__ballot(take));
+      if (ntake == 0) break;
+      offer(take ? cand : -1, 0, prio + lane);
+      prio += 64;
+      next += ntake;
+    }
+    // the rows taken in this iteration are released
+    if (lane < nem) flag[hrow[vals[em[lane]]] - rb * R] = 0x7fffffff;
+    for (int k = lane; k < nnew; k += 64) flag[hrow[vals[cq_pos[cur ^ 1][k]]] - rb * R] = 0x7fffffff;
     if (FILL) {
-      it_src[out] = pos;
-      it_cnt[out] = take;
+      if (lane < nem) it_ent[(size_t)out * 64 + lane] = em[lane];
+      if (lane == 0) {
+        it_cnt[out] = nem;
+        it_m[out] = m;
+      }
+    }
+    if (nem > 0) last_chunk = (int)(keys[em[nem - 1]] & JM);
+    // (em is in stream order within a batch but a deferred entry may follow... keep the maximum)
+    {
+      int mx = lane < nem ? (int)(keys[em[lane]] & JM) : 0;
+      mx = mde_wave_max(mx);
+      if (nem > 0) last_chunk = mx;
+      if (FILL && lane == 0 && nem > 0) it_cnt[out] = nem | (mx << 8);
     }
     ++out;
-    pos += take;
+    nc = nnew;
+    cur ^= 1;
+    __syncthreads();
   }
-  if (!FILL) iters[i] = out;
+  // a stream is stored in blocks of 4 iterations (one 16-byte load per lane): pad with empty ones
+  while ((out - first) & 3) {
+    if (FILL && lane == 0) {
+      it_cnt[out] = 0 | (last_chunk << 8);
+      it_m[out] = last_chunk;
+    }
+    ++out;
+  }
+  if (!FILL && lane == 0) iters[i] = out;
 }
 
 // One wave per iteration: sort its <= 64 entries by row (stable, so a row's entries keep their
 // chunk-major order), pad to 64 with dummies in the highest lanes, write packed words, edge ids
 // and the header.
-__global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int32_t* __restrict__ it_src,
+__global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int32_t* __restrict__ it_ent,
                                                          const int32_t* __restrict__ it_cnt,
+                                                         const int32_t* __restrict__ it_m,
                                                          const uint32_t* __restrict__ keys,
                                                          const uint32_t* __restrict__ vals,
                                                          const int32_t* __restrict__ hrow,
@@ -179,14 +284,15 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int3
   const int64_t nw = ((int64_t)gridDim.x * MDE_BLOCK) >> 6;
   const uint32_t JM = (1u << JB) - 1u;
   for (int64_t it = w0; it < nit; it += nw) {
-    const int src = __builtin_amdgcn_readfirstlane(it_src[it]);
-    const int cnt = __builtin_amdgcn_readfirstlane(it_cnt[it]);
+    const int cw = __builtin_amdgcn_readfirstlane(it_cnt[it]);  // entries | newest chunk << 8
+    const int cnt = cw & 0xff;
     const bool act = lane < cnt;
     uint32_t key = 0, q = 0;
     int rl = 0x7fffffff;
     if (act) {
-      key = keys[src + lane];
-      q = vals[src + lane];
+      const int pos = it_ent[(size_t)it * 64 + lane];
+      key = keys[pos];
+      q = vals[pos];
       const int rb = (int)((key >> JB) / MDE_RING_NCW) / Q;
       rl = hrow[q] - rb * R;
     }
@@ -198,20 +304,44 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int3
       same += (rt == rl);
     }
     const int run = mde_wave_max(act ? same : 0);
-    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);          // entries are chunk-major
-    const uint32_t need = (uint32_t)__builtin_amdgcn_readlane((int)j, cnt - 1);
-    const size_t base = (size_t)it * 64;
+    // chunk window of the iteration: the oldest chunk its stream still needs (deferred entries
+    // included) .. the newest chunk it references (entries are in stream order, chunk-major)
+    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(it_m[it]);
+    const uint32_t need = max((uint32_t)(cw >> 8), m);
+    // element (iteration it, lane l) of a stream lives at ((it / 4) * 64 + l) * 4 + it % 4
+    const size_t base = ((size_t)(it >> 2) * 64) * 4 + (size_t)(it & 3);
     if (act) {
       const uint32_t col = (uint32_t)nbr[q];
       const uint32_t ring = ((j % (uint32_t)S) * (uint32_t)C + (col - j * (uint32_t)C)) * 4u * (uint32_t)d;
-      packed[base + rank] = (((uint32_t)rl * 4u * (uint32_t)d) << 17) | ring;
-      peid[base + rank] = eid[q];
+      packed[base + (size_t)rank * 4] = (((uint32_t)rl * 4u * (uint32_t)d) << 17) | ring;
+      peid[base + (size_t)rank * 4] = eid[q];
     } else {
       // padding: the dummy row slot, a resident column (first of chunk m)
-      packed[base + lane] = (((uint32_t)R * 4u * (uint32_t)d) << 17) | ((m % (uint32_t)S) * (uint32_t)C * 4u * (uint32_t)d);
-      peid[base + lane] = -1;
+      packed[base + (size_t)lane * 4] =
+          (((uint32_t)R * 4u * (uint32_t)d) << 17) | ((m % (uint32_t)S) * (uint32_t)C * 4u * (uint32_t)d);
+      peid[base + (size_t)lane * 4] = -1;
     }
-    if (lane == 0) hdr[it] = MDE_RING_HDR(m, need - m, min(run - 1, 63), cnt < 64);
+    if (lane == 0) hdr[it] = MDE_RING_HDR(m, need - m, max(0, min(run - 1, 63)), cnt < 64);
+  }
+}
+
+// stats[0] = iterations with fold rounds, stats[1] = iterations with padding, stats[2] = sum of rounds
+__global__ __launch_bounds__(MDE_BLOCK) void k_ring_stats(int64_t nit, const uint32_t* __restrict__ hdr,
+                                                          unsigned long long* __restrict__ stats) {
+  unsigned long long a = 0, b = 0, c = 0;
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < nit; i += (int64_t)gridDim.x * MDE_BLOCK) {
+    const uint32_t h = hdr[i];
+    a += ((h >> 20) & 63u) != 0;
+    b += (h >> 26) & 1u;
+    c += (h >> 20) & 63u;
+  }
+  a = mde_wave_sum(a);
+  b = mde_wave_sum(b);
+  c = mde_wave_sum(c);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&stats[0], a);
+    atomicAdd(&stats[1], b);
+    atomicAdd(&stats[2], c);
   }
 }
 
@@ -297,12 +427,12 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   const uint32_t JM = (1u << z.JB) - 1u;
   uint32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr, *packed = nullptr, *hdr = nullptr;
   int32_t *hrow = nullptr, *bounds = nullptr, *seg = nullptr, *iters = nullptr, *iter_base = nullptr;
-  int32_t *it_src = nullptr, *it_cnt = nullptr, *peid = nullptr;
+  int32_t *it_ent = nullptr, *it_cnt = nullptr, *it_m = nullptr, *peid = nullptr;
   float* partial = nullptr;
   void* tmp = nullptr;
   hipError_t e = hipSuccess;
   auto release = [&](bool all) {
-    void* scratch[] = {keys, vals, keys2, vals2, hrow, bounds, seg, iters, it_src, it_cnt, tmp};
+    void* scratch[] = {keys, vals, keys2, vals2, hrow, bounds, seg, iters, it_ent, it_cnt, it_m, tmp};
     for (void* p : scratch)
       if (p) (void)hipFree(p);
     if (all) {
@@ -347,8 +477,8 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
                      z.JB, keys2, seg);
   RB(hipGetLastError());
   RB(hipMemsetAsync(iters, 0, ((size_t)nseg + 1) * sizeof(int32_t), st));
-  hipLaunchKernelGGL(k_ring_iters<false>, dim3((nseg + MDE_BLOCK - 1) / MDE_BLOCK), dim3(MDE_BLOCK), 0, st, nseg, seg,
-                     keys2, JM, ring_max_span(d), iters, nullptr, nullptr, nullptr);
+  hipLaunchKernelGGL(k_ring_schedule<false>, dim3(nseg), dim3(64), 0, st, nseg, seg, bounds, keys2, vals2, hrow, JM,
+                     ring_max_span(d), z.R, z.Q, z.NC, iters, nullptr, nullptr, nullptr, nullptr);
   RB(hipGetLastError());
   RB(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, iters, iter_base, nseg + 1, st));
   int32_t total_iters = 0;
@@ -359,20 +489,33 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     release(true);
     return 0;  // too large for 32-bit positions: the caller keeps the CSR layout
   }
-  RB(hipMalloc(&it_src, (size_t)total_iters * sizeof(int32_t)));
+  RB(hipMalloc(&it_ent, (size_t)total_iters * 64 * sizeof(int32_t)));
   RB(hipMalloc(&it_cnt, (size_t)total_iters * sizeof(int32_t)));
+  RB(hipMalloc(&it_m, (size_t)total_iters * sizeof(int32_t)));
   RB(hipMalloc(&packed, (size_t)Hp * sizeof(uint32_t)));
   RB(hipMalloc(&peid, (size_t)Hp * sizeof(int32_t)));
   RB(hipMalloc(&hdr, (size_t)total_iters * sizeof(uint32_t)));
   if (z.Q > 1) RB(hipMalloc(&partial, sizeof(float) * (size_t)z.Q * (size_t)nloc * (size_t)d));
-  hipLaunchKernelGGL(k_ring_iters<true>, dim3((nseg + MDE_BLOCK - 1) / MDE_BLOCK), dim3(MDE_BLOCK), 0, st, nseg, seg,
-                     keys2, JM, ring_max_span(d), nullptr, iter_base, it_src, it_cnt);
+  hipLaunchKernelGGL(k_ring_schedule<true>, dim3(nseg), dim3(64), 0, st, nseg, seg, bounds, keys2, vals2, hrow, JM,
+                     ring_max_span(d), z.R, z.Q, z.NC, nullptr, iter_base, it_ent, it_cnt, it_m);
   RB(hipGetLastError());
   hipLaunchKernelGGL(k_ring_pack, dim3(mde_grid((int64_t)total_iters * 64, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st,
-                     (int64_t)total_iters, it_src, it_cnt, keys2, vals2, hrow, plan->nbr, plan->eid, z.R, z.Q, z.C,
+                     (int64_t)total_iters, it_ent, it_cnt, it_m, keys2, vals2, hrow, plan->nbr, plan->eid, z.R, z.Q, z.C,
                      z.S, z.JB, d, packed, peid, hdr);
   RB(hipGetLastError());
   RB(hipStreamSynchronize(st));
+  if (getenv("MDE_RING_STATS")) {
+    unsigned long long* dstat = reinterpret_cast<unsigned long long*>(iters);  // scratch, >= 3 words
+    unsigned long long hstat[3] = {0, 0, 0};
+    RB(hipMemsetAsync(dstat, 0, sizeof(hstat), st));
+    hipLaunchKernelGGL(k_ring_stats, dim3(256), dim3(MDE_BLOCK), 0, st, (int64_t)total_iters, hdr, dstat);
+    RB(hipMemcpyAsync(hstat, dstat, sizeof(hstat), hipMemcpyDeviceToHost, st));
+    RB(hipStreamSynchronize(st));
+    fprintf(stderr, "[mde ring] d=%d R=%d NRB=%d Q=%d chunks=%d x %d cols, %d iterations for %lld half-edges (%.1f%% padding), "
+            "%.1f%% with fold rounds (mean %.2f), %.1f%% with padding lanes\n", d, z.R, z.NRB, z.Q, z.NC, z.C, total_iters,
+            (long long)H, 100.0 * ((double)Hp - (double)H) / (double)H, 100.0 * hstat[0] / total_iters,
+            hstat[0] ? (double)hstat[2] / hstat[0] : 0.0, 100.0 * hstat[1] / total_iters);
+  }
 #undef RB
   release(false);
   mde_ring_layout& L = plan->ring;
@@ -408,7 +551,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_expand_ring(int64_t H, const int3
                                                            float* __restrict__ out) {
   for (int64_t q = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; q < H;
        q += (int64_t)gridDim.x * MDE_BLOCK)
-    out[q] = eid[q] >= 0 ? in[eid[q]] : 1.0f;  // padding entries carry a harmless parameter
+    out[q] = eid[q] >= 0 ? in[eid[q]] : 0.0f;  // padding entries: weight 0 (f = 0 for every penalty)
 }
 
 // number of entries of a per-half-edge parameter array in the given layout (layout 1: the padded
@@ -421,8 +564,9 @@ extern "C" int64_t mde_plan_layout_half_edges(const mde_plan* plan, int32_t layo
 // ---------------------------------------------------------------- parameter codebooks
 // Neighbour-graph problems carry very few distinct per-edge parameters (k-NN weights 1 / 2, -1 for
 // repulsive pairs).  At d = 2 the packed word's ring offset is a multiple of 8, so its 3 low bits
-// can hold an index into a table of <= 8 values: the kernel then streams 4 bytes per half-edge
-// instead of 8 (packed word + fp32 parameter) and looks the parameter up in LDS.
+// can hold an index into a table of 8 values: the kernel then streams 4 bytes per half-edge
+// instead of 8 (packed word + fp32 parameter) and looks the parameter up in LDS.  Entry 0 is the
+// weight 0 of padding lanes, entries 1..7 the (at most 7) distinct values of the array.
 #define MDE_CB_EMPTY 0xFFFFFFFFu  // (a NaN pattern: NaN parameters simply disable the codebook)
 
 // distinct bit patterns of in[0..p): inserted into table[0..8) with compare-and-swap; *overflow is
@@ -449,7 +593,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_codebook_scan(int64_t p, const fl
       return;
     }
     bool placed = false;
-    for (int s = 0; s < MDE_RING_CB_VALUES && !placed; ++s) {
+    for (int s = 1; s < MDE_RING_CB_VALUES && !placed; ++s) {
       const unsigned int old = atomicCAS(&table[s], MDE_CB_EMPTY, v);
       placed = (old == MDE_CB_EMPTY || old == v);
     }
@@ -481,14 +625,14 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_codebook_pack(int64_t H, const ui
       uint32_t idx = 0;
 #pragma unroll
       for (int s = 1; s < MDE_RING_CB_VALUES; ++s) idx = (tb[s] == v) ? (uint32_t)s : idx;
-      w |= idx;
+      w |= idx;  // (padding entries keep index 0 = weight 0)
     }
     out[q] = w;
   }
 }
 
 // Try to put a per-edge parameter array into codebook form for layout 1.  On success
-// (*n_values_host in 1..8) out_half holds the H packed words with the value index in their 3 low
+// (*n_values_host in 1..7) out_half holds the H packed words with the value index in their 3 low
 // bits, followed by the 8-entry value table; pass it as mde_func.a0 with a0_scalar = 2.
 // *n_values_host = 0: not applicable (d != 2, more than 8 distinct values, NaNs) -- nothing is
 // written and the caller uses mde_plan_expand_layout.  SYNC.
@@ -521,16 +665,17 @@ extern "C" int mde_plan_expand_codebook(const mde_plan* plan, const float* in_ed
   // canonical order (the insertion order above depends on scheduling): ascending bit patterns
   int nv = 0;
   unsigned int vals[MDE_RING_CB_VALUES];
-  for (int s = 0; s < MDE_RING_CB_VALUES; ++s)
-    if (host_tb[s] != MDE_CB_EMPTY) vals[nv++] = host_tb[s];
+  vals[0] = 0u;  // +0.0f: the padding lanes' weight
+  for (int s = 1; s < MDE_RING_CB_VALUES; ++s)
+    if (host_tb[s] != MDE_CB_EMPTY) vals[1 + nv++] = host_tb[s];
   if (nv == 0) return MDE_OK;
-  for (int a = 1; a < nv; ++a)
-    for (int b = a; b > 0 && vals[b - 1] > vals[b]; --b) {
+  for (int a = 2; a <= nv; ++a)
+    for (int b = a; b > 1 && vals[b - 1] > vals[b]; --b) {
       const unsigned int t = vals[b];
       vals[b] = vals[b - 1];
       vals[b - 1] = t;
     }
-  for (int s = nv; s < MDE_RING_CB_VALUES; ++s) vals[s] = MDE_CB_EMPTY;
+  for (int s = nv + 1; s < MDE_RING_CB_VALUES; ++s) vals[s] = MDE_CB_EMPTY;
   MDE_HIP(hipMemcpyAsync(table, vals, sizeof(vals), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_codebook_pack, dim3(mde_grid(L.H, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, L.H, L.packed,
                      L.eid, in_edge, table, reinterpret_cast<uint32_t*>(out_half));
@@ -556,6 +701,9 @@ extern "C" int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, cons
 }
 
 // ---------------------------------------------------------------- the kernel
+typedef uint32_t ring_u4 __attribute__((ext_vector_type(4)));
+typedef float ring_f4 __attribute__((ext_vector_type(4)));
+
 template <int D>
 struct RingVec;
 template <>
@@ -613,6 +761,31 @@ __device__ __forceinline__ void ring_dma16(const void* gsrc, uint32_t lds_dst) {
       : "memory");
 }
 
+// N <= 4 consecutive pieces in one statement (one M0 set-up; the 13-bit instruction offset covers
+// 4 KiB)
+template <int N>
+__device__ __forceinline__ void ring_dma_pieces(const void* gsrc, uint32_t lds_dst) {
+  static_assert(N >= 1 && N <= 4, "1..4 pieces");
+  unsigned keep;
+  if constexpr (N == 1)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else if constexpr (N == 2)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else if constexpr (N == 3)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\t"
+                 "global_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
 // control words: explicit LDS instructions on absolute addresses (a `volatile` generic pointer
 // would turn into flat loads / stores and drag vmcnt(0) waits into the stream pipeline)
 __device__ __forceinline__ void ring_ctrl_store(uint32_t addr, int v) {
@@ -626,7 +799,10 @@ __device__ __forceinline__ int ring_ctrl_load(uint32_t addr) {
 
 // CB: the first parameter comes from a codebook -- `packed` is the stream with value indices in its
 // 3 low bits (mde_plan_expand_codebook), a0 the 8-entry value table; no parameter stream is read.
-template <int D, class Fn, bool HAS_GRAD, bool CB>
+// LIN: f is proportional to its first parameter (the penalties instantiated below): padding lanes
+// carry weight 0 and need no masking, so a padded iteration without duplicate rows stays on the
+// fast path.
+template <int D, class Fn, bool HAS_GRAD, bool CB, bool LIN>
 __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     int nloc, int row_lo, int n, int R, int Q, int NC, const int32_t* __restrict__ wave_iter,
     const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ packed, const float* __restrict__ a0,
@@ -658,7 +834,22 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     float4* z = reinterpret_cast<float4*>(L + GR_OFF);
     for (int i = tid; i < (MDE_RING_OFF - GR_OFF) / 16; i += BS) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* Xrow = X + (size_t)(row_lo + r0) * D;
-    for (int i = tid; i < nr * D; i += BS) XR[i] = Xrow[i];
+    if ((reinterpret_cast<uintptr_t>(Xrow) & 15) == 0) {
+      // 16-byte loads, all issued before the first LDS store
+      const ring_f4* X4 = reinterpret_cast<const ring_f4*>(Xrow);
+      ring_f4* XR4 = reinterpret_cast<ring_f4*>(L);
+      const int n4 = (nr * D) >> 2;
+      constexpr int PER = (MDE_RING_CTRL_OFF / 16 + BS - 1) / BS;
+      ring_f4 t[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) t[k] = X4[min(tid + k * BS, max(n4 - 1, 0))];
+#pragma unroll
+      for (int k = 0; k < PER; ++k)
+        if (tid + k * BS < n4) XR4[tid + k * BS] = t[k];
+      for (int i = (n4 << 2) + tid; i < nr * D; i += BS) XR[i] = Xrow[i];
+    } else {
+      for (int i = tid; i < nr * D; i += BS) XR[i] = Xrow[i];
+    }
     if (tid < D) XR[R * D + tid] = 0.0f;  // the dummy row
     if (tid < 16) prog[tid] = (tid < NCW) ? j_lo : MDE_RING_DONE;
     if (tid >= 16 && tid < 16 + NPROD) F[tid - 16] = j_lo + (tid - 16);
@@ -676,36 +867,137 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     // ---------------- producer p: chunks j_lo + p, j_lo + p + NPROD, ...
     const int p = wave - NCW;
     const char* Xb = reinterpret_cast<const char*>(X);
+    const char* Xl = Xb + lane * 16;
     const size_t nbytes = (size_t)n * D * 4;
     const size_t last16 = nbytes - 16;
-    int minprog = j_lo, infl = 0;
-    for (int j = j_lo + p; j < j_hi; j += NPROD) {
-      // slot j % S still holds chunk j - S: wait until every consumer is past it
-      while (j - S >= minprog && !(dbg & 8)) {
-        int v = ring_ctrl_load(MDE_RING_CTRL_PROG + 4u * (uint32_t)(lane < NCW ? lane : 0));
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
-        minprog = __builtin_amdgcn_readfirstlane(v);
-        if (j - S >= minprog) __builtin_amdgcn_s_sleep(2);
-      }
-      const uint32_t dst = (uint32_t)RING_OFF + (uint32_t)(j % S) * (uint32_t)CBYTES;
-      const size_t off0 = (size_t)j * CBYTES + (size_t)lane * 16;
-      if (!(dbg & 2))
+#if MDE_RING_STAGE
+    // Register-staged: three chunks per producer in flight in VGPRs (coalesced 16-byte loads),
+    // written to their ring slot once the slot is free.  Data in flight therefore occupies no
+    // LDS: the whole ring is window + slack for the consumers, which is what lets the waves
+    // drift (with LDS-DMA the in-flight chunks took half of the 12 slots and every wave ended up
+    // waiting for the slowest one chunk by chunk).
+    int minprog = j_lo;
+    ring_f4 bufA[PIECES], bufB[PIECES], bufC[PIECES];
+    const int j_last = j_hi - 1;
+    auto fetch = [&](ring_f4 (&buf)[PIECES], int j) __attribute__((always_inline)) {
+      const size_t off0 = (size_t)min(j, j_last) * CBYTES + (size_t)lane * 16;
 #pragma unroll
       for (int k = 0; k < PIECES; ++k) {
         const size_t off = off0 + (size_t)k * 1024;
-        ring_dma16(Xb + (off < last16 ? off : last16), dst + (uint32_t)k * 1024u);
+        buf[k] = *reinterpret_cast<const ring_f4*>(Xb + (off < last16 ? off : last16));
       }
-      if (++infl == MDE_RING_DEPTH) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * (MDE_RING_DEPTH - 1)) : "memory");
-        // everything of mine before this chunk has landed
-        ring_ctrl_store(MDE_RING_CTRL_F + 4u * (uint32_t)p, j - (MDE_RING_DEPTH - 1) * NPROD + NPROD);
-        --infl;
+    };
+    auto commit = [&](const ring_f4 (&buf)[PIECES], int j) __attribute__((always_inline)) {
+      if (j >= j_hi || (dbg & 128)) return;
+      // slot j % S still holds chunk j - S until every consumer is past it
+      while (j - S >= minprog && !(dbg & 8)) {
+        const int v = ring_ctrl_load(MDE_RING_CTRL_PROG + 4u * (uint32_t)(lane & 15));
+        int mn = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+        for (int w = 1; w < NCW; ++w) mn = min(mn, __builtin_amdgcn_readlane(v, w));
+        minprog = mn;
+        if (j - S >= minprog) __builtin_amdgcn_s_sleep(1);
+      }
+      char* dst = L + RING_OFF + (j % S) * CBYTES + lane * 16;
+      if (!(dbg & 2)) {
+#pragma unroll
+        for (int k = 0; k < PIECES; ++k) *reinterpret_cast<ring_f4*>(dst + k * 1024) = buf[k];
+        // when the table is not a multiple of 16 bytes its final dwords are put in place by hand
+        // (the lane whose 16 bytes straddle the end loaded a clamped address)
+        if (j == NC - 1 && (nbytes & 15)) {
+          const size_t tail0 = nbytes & ~(size_t)15;
+          const int nt = (int)((nbytes - tail0) >> 2);
+          if (lane < nt)
+            *reinterpret_cast<float*>(L + RING_OFF + (j % S) * CBYTES + (tail0 + (size_t)lane * 4 - (size_t)j * CBYTES)) =
+                *reinterpret_cast<const float*>(Xb + tail0 + (size_t)lane * 4);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ring_ctrl_store(MDE_RING_CTRL_F + 4u * (uint32_t)p, j + NPROD);
+    };
+    {
+      const int j0 = j_lo + p;
+      fetch(bufA, j0);
+      fetch(bufB, j0 + NPROD);
+      fetch(bufC, j0 + 2 * NPROD);
+      for (int j = j0; j < j_hi; j += 3 * NPROD) {
+        commit(bufA, j);
+        fetch(bufA, j + 3 * NPROD);
+        commit(bufB, j + NPROD);
+        fetch(bufB, j + 4 * NPROD);
+        commit(bufC, j + 2 * NPROD);
+        fetch(bufC, j + 5 * NPROD);
       }
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // (no counted load pending past the role's end)
+#else
+    int minprog = j_lo, infl = 0;
+    int slot = (j_lo + p) % S;
+    int j = j_lo + p;         // next chunk to issue
+    int oldest = j;           // oldest chunk in flight (valid while infl > 0)
+    // wait for the oldest chunk in flight and publish it (F[p] = my next chunk that has not landed)
+    auto retire = [&]() __attribute__((always_inline)) {
+      if (infl == 3)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * 2) : "memory");
+      else if (infl == 2)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      oldest += NPROD;
+      ring_ctrl_store(MDE_RING_CTRL_F + 4u * (uint32_t)p, oldest);
+      --infl;
+    };
+    static_assert(MDE_RING_DEPTH >= 1 && MDE_RING_DEPTH <= 3, "retire() spells out the wait counts of up to three chunks in flight");
+    while (j < j_hi && !(dbg & 128)) {
+      // slot j % S still holds chunk j - S until every consumer is past it
+      if (j - S >= minprog && !(dbg & 8)) {
+        // one LDS read (lane w = consumer w), then a scalar minimum over the 14 lanes
+        const int v = ring_ctrl_load(MDE_RING_CTRL_PROG + 4u * (uint32_t)(lane & 15));
+        int mn = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+        for (int w = 1; w < NCW; ++w) mn = min(mn, __builtin_amdgcn_readlane(v, w));
+        minprog = mn;
+        if (j - S >= minprog) {
+          // blocked: meanwhile publish what has landed (a consumer may be waiting for exactly that)
+          if (infl > 0)
+            retire();
+          else
+            __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+      }
+      const uint32_t dst = (uint32_t)RING_OFF + (uint32_t)slot * (uint32_t)CBYTES;
+      if (!(dbg & 2)) {
+        if (j != NC - 1) {
+          // 1 KiB pieces, up to four per statement: the instruction offset advances the global and
+          // the LDS address together
+          const char* src = Xl + (size_t)j * CBYTES;
+#if MDE_RING_DMA_IMM
+          ring_dma_pieces<4>(src, dst);
+          ring_dma_pieces<PIECES - 4>(src + 4096, dst + 4096u);
+#else
+#pragma unroll
+          for (int k = 0; k < PIECES; ++k) ring_dma_pieces<1>(src + k * 1024, dst + (uint32_t)k * 1024u);
+#endif
+        } else {
+          // the table's last chunk: lanes whose 16 bytes would cross its end load a clamped address
+          const size_t off0 = (size_t)j * CBYTES + (size_t)lane * 16;
+#pragma unroll
+          for (int k = 0; k < PIECES; ++k) {
+            const size_t off = off0 + (size_t)k * 1024;
+            ring_dma_pieces<1>(Xb + (off < last16 ? off : last16), dst + (uint32_t)k * 1024u);
+          }
+        }
+      }
+      if (infl == 0) oldest = j;
+      ++infl;
+      j += NPROD;
+      slot += NPROD;
+      slot = slot >= S ? slot - S : slot;
+      if (infl == MDE_RING_DEPTH) retire();
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // the table's last chunk: lanes whose 16 bytes cross the end loaded a clamped address; when
-    // the table is not a multiple of 16 bytes the final dwords are put in place by hand
+    // when the table is not a multiple of 16 bytes its final dwords are put in place by hand
     if ((nbytes & 15) && (NC - 1) >= j_lo && (NC - 1) < j_hi && ((NC - 1 - j_lo) % NPROD) == p) {
       const size_t tail0 = nbytes & ~(size_t)15;
       const int nt = (int)((nbytes - tail0) >> 2);
@@ -716,56 +1008,83 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+#endif
     ring_ctrl_store(MDE_RING_CTRL_F + 4u * (uint32_t)p, MDE_RING_DONE);
   } else {
-    // ---------------- consumer: my contiguous stream of wave iterations
+    // ---------------- consumer: my contiguous stream of wave iterations, 4 per block
     const int ib = __builtin_amdgcn_readfirstlane(wave_iter[blockIdx.x * NCW + wave]);
-    const int niter = __builtin_amdgcn_readfirstlane(wave_iter[blockIdx.x * NCW + wave + 1]) - ib;
-    if (niter > 0 && !(dbg & 64)) {
-      const uint32_t* sp = packed + (size_t)ib * 64 + lane;
-      // (the header is loaded like the packed words, as a vector load every lane issues for the
-      // same address: a scalar load would tie each iteration to an SMEM round trip through the
-      // lgkmcnt(0) its out-of-order return forces)
-      int zl;
-      asm volatile("v_mov_b32 %0, 0" : "=v"(zl));
-      const uint32_t* hp = hdr + ib + zl;
+    const int NB = (__builtin_amdgcn_readfirstlane(wave_iter[blockIdx.x * NCW + wave + 1]) - ib) >> 2;
+    if (NB > 0 && !(dbg & 64)) {
       const bool a0_arr = !a0_scalar && !CB;
-      const float* ap = a0_arr ? a0 + (size_t)ib * 64 + lane : a0;
-      const int astride = a0_arr ? 64 : 0;
-      const int last = niter - 1;
-      uint32_t pk[PF] = {}, hd[PF] = {};
-      float wv[PF] = {};
-      // All stream loads are issued from ONE place (the refill after a slot is consumed; the first
+      const ring_u4* sp = reinterpret_cast<const ring_u4*>(packed) + (size_t)(ib >> 2) * 64 + lane;
+      const ring_u4* hp = reinterpret_cast<const ring_u4*>(hdr) + (ib >> 2);
+      const ring_f4* ap = reinterpret_cast<const ring_f4*>(a0_arr ? a0 : reinterpret_cast<const float*>(packed)) +
+                          (size_t)(ib >> 2) * 64 + lane;
+      const int lastb = NB - 1;
+      // Three blocks (12 iterations) of packed words, parameters and headers in flight.  All
+      // stream loads are issued from ONE place (the refill after a block is consumed; the first
       // trip of the loop below only fills), unconditional and clamped, never predicated: on every
-      // path exactly PF - 1 younger loads are in flight when a slot is consumed, so the
-      // compiler's vmcnt counts are exact and nothing waits for a load just issued.
-      auto load_slot = [&](int k, int it) __attribute__((always_inline)) {
-        int itc = min(it, last);
-        if (dbg & 16) itc &= 31;  // (probe: an L1/L2-resident stream)
-        pk[k] = (dbg & 32) ? __builtin_nontemporal_load(sp + (size_t)itc * 64) : sp[(size_t)itc * 64];
-        hd[k] = hp[itc];
-        if (!CB) wv[k] = ap[(size_t)itc * astride];
+      // path the same loads are in flight when a block is consumed, so the compiler's vmcnt
+      // counts are exact and nothing waits for a load just issued.  The four headers of a block
+      // come with one scalar load (uniform address).
+      ring_u4 pq[3] = {}, hq[3] = {};
+      ring_f4 wq[3] = {};
+      auto load_block = [&](int u, int b) __attribute__((always_inline)) {
+        const int bc = min(b, lastb);
+        pq[u] = sp[(size_t)bc * 64];
+        hq[u] = hp[bc];
+        if (!CB) wq[u] = ap[(size_t)bc * 64];
       };
       int ready = j_lo, published = j_lo;
 
-      auto process = [&](uint32_t w, float p0, float p1, int rounds, bool padded) __attribute__((always_inline)) {
+      // One iteration ahead: while iteration k is evaluated, the LDS reads of iteration k + 1
+      // (x_v, x_u, codebook value) are already in flight into a second register set, and the
+      // accumulator read of iteration k is issued before its function evaluation -- an iteration
+      // waits for no LDS round trip of its own.
+      struct Pre {
+        float xr[D], xc[D], p0;
+      };
+      auto pre_read = [&](uint32_t w, float p0) __attribute__((always_inline)) {
+        Pre r;
         const uint32_t rowaddr = w >> 17, coladdr = w & (CB ? 0x1fff8u : 0x1ffffu);
-        if (CB) p0 = *reinterpret_cast<const float*>(L + MDE_RING_CTRL_CB + ((w & 7u) << 2));
-        float xr[D], xc[D], v[D], ss = 0.0f;
-        ring_ld<D>(L + rowaddr, xr);
-        ring_ld<D>(L + RING_OFF + coladdr, xc);
+        r.p0 = CB ? *reinterpret_cast<const float*>(L + MDE_RING_CTRL_CB + ((w & 7u) << 2)) : p0;
+        ring_ld<D>(L + rowaddr, r.xr);
+        ring_ld<D>(L + RING_OFF + coladdr, r.xc);
+        return r;
+      };
+      // common case: no duplicate rows (padding lanes carry weight 0 when LIN) -- every lane
+      // updates its own row
+      auto process_fast = [&](uint32_t w, const Pre& x, float p1) __attribute__((always_inline)) {
+        const uint32_t rowaddr = w >> 17;
+        float acc[D], v[D], ss = 0.0f;
+        if (HAS_GRAD) ring_ld<D>(L + GR_OFF + rowaddr, acc);
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-          v[c] = xr[c] - xc[c];
+          v[c] = x.xr[c] - x.xc[c];
           ss = fmaf(v[c], v[c], ss);
         }
         float f, gd;
-        fn.eval(ss, p0, p1, f, gd);
+        fn.eval(ss, x.p0, p1, f, gd);
         const float g = mde_fix_g(gd * inv_p);
-        if (padded)
-          loss += (rowaddr != dummy_row) ? f : 0.0f;
-        else
-          loss += f;
+        loss += f;
+        if (!HAS_GRAD) return;
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] = fmaf(v[c], g, acc[c]);
+        ring_st<D>(L + GR_OFF + rowaddr, acc);
+      };
+      // duplicate rows and / or padding lanes that need masking
+      auto process_slow = [&](uint32_t w, const Pre& x, float p1, int rounds) __attribute__((always_inline)) {
+        const uint32_t rowaddr = w >> 17;
+        float v[D], ss = 0.0f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          v[c] = x.xr[c] - x.xc[c];
+          ss = fmaf(v[c], v[c], ss);
+        }
+        float f, gd;
+        fn.eval(ss, x.p0, p1, f, gd);
+        const float g = mde_fix_g(gd * inv_p);
+        loss += (rowaddr != dummy_row) ? f : 0.0f;
         if (!HAS_GRAD) return;
 #pragma unroll
         for (int c = 0; c < D; ++c) v[c] *= g;
@@ -774,27 +1093,22 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         // lane per round with DPP wave_shr:1); the last lane of each run then holds the run's sum
         // and performs the single read-add-write of the row.
         const int key = (int)rowaddr;
-        bool tail = true;
-        if (rounds > 0) {
-          int kc = key;
-          float sv[D];
+        int kc = key;
+        float sv[D];
 #pragma unroll
-          for (int c = 0; c < D; ++c) sv[c] = v[c];
+        for (int c = 0; c < D; ++c) sv[c] = v[c];
 #pragma nounroll
-          for (int r = 0; r < rounds; ++r) {
-            kc = __builtin_amdgcn_update_dpp(-1, kc, 0x138, 0xf, 0xf, false);
-            const bool same = (kc == key);
+        for (int r = 0; r < rounds; ++r) {
+          kc = __builtin_amdgcn_update_dpp(-1, kc, 0x138, 0xf, 0xf, false);
+          const bool same = (kc == key);
 #pragma unroll
-            for (int c = 0; c < D; ++c) {
-              sv[c] = __int_as_float(
-                  __builtin_amdgcn_update_dpp(0, __float_as_int(sv[c]), 0x138, 0xf, 0xf, false));
-              v[c] += same ? sv[c] : 0.0f;
-            }
+          for (int c = 0; c < D; ++c) {
+            sv[c] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv[c]), 0x138, 0xf, 0xf, false));
+            v[c] += same ? sv[c] : 0.0f;
           }
-          const int knext = __builtin_amdgcn_update_dpp(-1, key, 0x130, 0xf, 0xf, false);  // wave_shl:1
-          tail = knext != key;
         }
-        if (tail) {
+        const int knext = __builtin_amdgcn_update_dpp(-1, key, 0x130, 0xf, 0xf, false);  // wave_shl:1
+        if (knext != key) {
           float acc[D];
           ring_ld<D>(L + GR_OFF + rowaddr, acc);
 #pragma unroll
@@ -802,33 +1116,62 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           ring_st<D>(L + GR_OFF + rowaddr, acc);
         }
       };
-
-      for (int base = -PF; base < niter; base += PF) {
-#pragma unroll
-        for (int k = 0; k < PF; ++k) {
-          const int it = base + k;
-          if (it >= 0 && it < niter) {
-            const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)hd[k]);
-            const int m = (int)(h & 0xffffu), need = m + (int)((h >> 16) & 15u);
-            if (m != published) {
-              // (every earlier read of chunks < m has been issued, and the LDS executes in order)
-              ring_ctrl_store(MDE_RING_CTRL_PROG + 4u * (uint32_t)wave, m);
-              published = m;
-            }
-            if (need >= ready && !(dbg & 1)) {
-              for (;;) {
-                const int fl = ring_ctrl_load(MDE_RING_CTRL_F + 4u * (uint32_t)(lane & 1));
-                ready = min(__builtin_amdgcn_readlane(fl, 0), __builtin_amdgcn_readlane(fl, 1));
-                if (need < ready) break;
-                __builtin_amdgcn_s_sleep(1);
-              }
-              asm volatile("" ::: "memory");
-            }
-            const float p1 = a1_arr ? a1[(size_t)(ib + it) * 64 + lane] : a1s;
-            if (!(dbg & 4)) process(pk[k], (a0_scalar || CB) ? a0s : wv[k], p1, (int)((h >> 20) & 63u), (h >> 26) & 1u);
-            else loss += __uint_as_float(pk[k]) * 0.0f;
+      // make the chunks of the iteration with header h resident (and tell the producers what
+      // this wave no longer needs)
+      auto sync_for = [&](uint32_t h) __attribute__((always_inline)) {
+        const int m = (int)(h & 0xffffu), need = m + (int)((h >> 16) & 15u);
+        if (m != published) {
+          // (every read of chunks < m has been issued, and the LDS executes in order)
+          ring_ctrl_store(MDE_RING_CTRL_PROG + 4u * (uint32_t)wave, m);
+          published = m;
+        }
+        if (need >= ready && !(dbg & 1)) {
+          for (;;) {
+            const int fl = ring_ctrl_load(MDE_RING_CTRL_F + 4u * (uint32_t)(lane & 1));
+            ready = min(__builtin_amdgcn_readlane(fl, 0), __builtin_amdgcn_readlane(fl, 1));
+            if (need < ready) break;
+            __builtin_amdgcn_s_sleep(1);
           }
-          load_slot(k, it + PF);
+          asm volatile("" ::: "memory");
+        }
+      };
+
+      Pre cur = {};
+      for (int base = -3; base < NB; base += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const int b = base + u;
+          if (b >= 0 && b < NB) {
+            if (b == 0) {
+              // the very first iteration has nobody to pre-read it
+              const uint32_t h0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hq[u][0]);
+              sync_for(h0);
+              cur = pre_read(pq[u][0], (a0_scalar || CB) ? a0s : wq[u][0]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)hq[u][q]);
+              // the next iteration (of this block, or the first of the next one; past the end of
+              // the stream: this one again, its chunks are resident)
+              const bool has_next = q < 3 || b + 1 < NB;
+              const uint32_t wn = q < 3 ? pq[u][q + 1] : (has_next ? pq[(u + 1) % 3][0] : pq[u][q]);
+              const uint32_t hn = (uint32_t)__builtin_amdgcn_readfirstlane(
+                  (int)(q < 3 ? hq[u][q + 1] : (has_next ? hq[(u + 1) % 3][0] : hq[u][q])));
+              const float p0n = (a0_scalar || CB) ? a0s
+                                : (q < 3 ? wq[u][q + 1] : (has_next ? wq[(u + 1) % 3][0] : wq[u][q]));
+              if (has_next) sync_for(hn);
+              const Pre nxt = pre_read(wn, p0n);
+              const float p1 = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q] : a1s;
+              if (dbg & 4)
+                loss += __uint_as_float(pq[u][q]) * 0.0f + cur.xr[0] * 0.0f;
+              else if ((h >> 20) & (LIN ? 0x3fu : 0x7fu))
+                process_slow(pq[u][q], cur, p1, (int)((h >> 20) & 63u));
+              else
+                process_fast(pq[u][q], cur, p1);
+              cur = nxt;
+            }
+          }
+          load_block(u, b + 3);
         }
       }
     }
@@ -901,7 +1244,7 @@ struct RingArgs {
   double loss_scale;
 };
 
-template <int D, class Fn>
+template <int D, class Fn, bool LIN>
 static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
   const mde_ring_layout& L = A.plan->ring;
   const bool cb = A.a0_scalar == 2;
@@ -913,9 +1256,9 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
     mde_set_error("the LDS-ring kernel needs a 16-byte aligned embedding matrix");
     return MDE_E_INVALID;
   }
-  auto kern = A.grad ? k_fused_ring<D, Fn, true, false> : k_fused_ring<D, Fn, false, false>;
+  auto kern = A.grad ? k_fused_ring<D, Fn, true, false, LIN> : k_fused_ring<D, Fn, false, false, LIN>;
   if constexpr (D == 2) {
-    if (cb) kern = A.grad ? k_fused_ring<D, Fn, true, true> : k_fused_ring<D, Fn, false, true>;
+    if (cb) kern = A.grad ? k_fused_ring<D, Fn, true, true, LIN> : k_fused_ring<D, Fn, false, true, LIN>;
   }
   // codebook form: a0 = [H packed words | 8 values]
   const uint32_t* stream = cb ? reinterpret_cast<const uint32_t*>(A.a0) : L.packed;
@@ -958,30 +1301,30 @@ int mde_ring_try(mde_plan* plan, const float* X, int d, const mde_func* f, float
   const MdeFuncArgs a = ring_func_args(f);
   const int ea = mde_exp_class(f->s0), en = mde_exp_class(f->n0);
   int rc = MDE_OK;
-#define RING(FN)                                               \
+#define RING(FN, LIN)                                          \
   do {                                                         \
     FN fn{a};                                                  \
     if (d == 2)                                                \
-      rc = launch_ring<2, FN>(A, fn, nblocks);                 \
+      rc = launch_ring<2, FN, LIN>(A, fn, nblocks);            \
     else if (d == 3)                                           \
-      rc = launch_ring<3, FN>(A, fn, nblocks);                 \
+      rc = launch_ring<3, FN, LIN>(A, fn, nblocks);            \
     else if (d == 1)                                           \
-      rc = launch_ring<1, FN>(A, fn, nblocks);                 \
+      rc = launch_ring<1, FN, LIN>(A, fn, nblocks);            \
     else                                                       \
-      rc = launch_ring<4, FN>(A, fn, nblocks);                 \
+      rc = launch_ring<4, FN, LIN>(A, fn, nblocks);            \
     return rc == MDE_OK ? 1 : rc;                              \
   } while (0)
   if (d == 2 || d == 3) {
     if (f->kind_neg == MDE_F_NONE) {
-      if (f->kind == MDE_F_LOG1P && ea == 2) RING(FnSingle<MDE_F_LOG1P COMMA 2>);
-      if (f->kind == MDE_F_QUADRATIC) RING(FnSingle<MDE_F_QUADRATIC COMMA 0>);
+      if (f->kind == MDE_F_LOG1P && ea == 2) RING(FnSingle<MDE_F_LOG1P COMMA 2>, true);
+      if (f->kind == MDE_F_QUADRATIC) RING(FnSingle<MDE_F_QUADRATIC COMMA 0>, true);
     } else if (f->kind == MDE_F_LOG1P && ea == 2) {
       if (f->kind_neg == MDE_F_LOG && en == 1)
-        RING(FnPushPull<MDE_F_LOG1P COMMA 2 COMMA MDE_F_LOG COMMA 1>);
+        RING(FnPushPull<MDE_F_LOG1P COMMA 2 COMMA MDE_F_LOG COMMA 1>, true);
       if (f->kind_neg == MDE_F_LOGRATIO && en == 3)
-        RING(FnPushPull<MDE_F_LOG1P COMMA 2 COMMA MDE_F_LOGRATIO COMMA 3>);
+        RING(FnPushPull<MDE_F_LOG1P COMMA 2 COMMA MDE_F_LOGRATIO COMMA 3>, true);
     }
   }
-  RING(FnRuntime);
+  RING(FnRuntime, false);
 #undef RING
 }

@@ -1,18 +1,4 @@
-mkdir -p gpurun_out/c8; export MDE_PANEL=1
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-for dbg in 3 0; do
-for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_SMEM"; do
-  MDE_RING_DBG=$dbg timeout 120 rocprofv3 --kernel-trace --pmc $grp -d $R/gpurun_out/c8/p_${dbg}_$(echo $grp | cut -c4-12) --output-format csv -- $R/tools/kbench 1000000 50 3 > /dev/null 2>&1
-done
-done
-cd $R
-python3 - <<'PY'
-import csv, glob, collections
-for f in sorted(glob.glob('gpurun_out/c8/*/*/*counter_collection.csv')):
-    acc = collections.defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(f)):
-        if 'k_fused_ring' in r['Kernel_Name'] and 'Lb1ELb1' in r['Kernel_Name'] or ('k_fused_ring' in r['Kernel_Name'] and 'true, true' in r['Kernel_Name']):
-            a = acc[r['Counter_Name']]; a[0] += float(r['Counter_Value']); a[1] += 1
-    print(f.split('/')[2], {k: v[0] / max(v[1], 1) for k, v in acc.items()})
-PY
+mkdir -p gpurun_out/c19; export MDE_PANEL=1 MDE_RING_STATS=1
+run() { echo "== $1 DBG=$2 n=$4" >> gpurun_out/c19/abl.txt; LD_LIBRARY_PATH=$3 MDE_RING_DBG=$2 timeout 60 ./tools/kbench $4 $5 10 2>&1 | grep -E "mde ring|codebook stream \(4|fused Log1p d=2 G|check|rc=|rror" >> gpurun_out/c19/abl.txt; }
+for v in s4d2 s5d2 s6d2 s4d1 s6d1 s8d1 s6d0; do run $v 0 tools/variants/$v 1000000 50; done
+cat gpurun_out/c19/abl.txt
