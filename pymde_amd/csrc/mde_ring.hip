@@ -59,6 +59,9 @@
 #define MDE_RING_PF 8              // stream slots prefetched per consumer wave
 #endif
 #define MDE_RING_CB_VALUES 8
+#ifndef MDE_RING_ABLATE
+#define MDE_RING_ABLATE 0
+#endif
 #ifndef MDE_RING_DMA_IMM
 #define MDE_RING_DMA_IMM 1
 #endif
@@ -74,7 +77,8 @@ __host__ __device__ constexpr int ring_max_span(int d) {
 #ifdef MDE_RING_SPAN
   return MDE_RING_SPAN;
 #endif
-  return MDE_RING_STAGE ? ring_slots(d) - MDE_RING_NPROD - 2 : ring_slots(d) - MDE_RING_NPROD * MDE_RING_DEPTH;
+  // (measured at config 4: 4..6 chunks of window leave the waves the most slack; 8 costs 4 %)
+  return MDE_RING_STAGE ? ring_slots(d) - MDE_RING_NPROD - 2 : ring_slots(d) - MDE_RING_NPROD * MDE_RING_DEPTH - 2;
 }
 
 // header word of a wave iteration: [15:0] m = lowest chunk referenced, [19:16] span (highest = m +
@@ -808,7 +812,12 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ packed, const float* __restrict__ a0,
     const float* __restrict__ a1, int a0_scalar, int a1_scalar, const float* __restrict__ X,
     float* __restrict__ grad, float* __restrict__ partial, double* __restrict__ loss_partials, Fn fn,
-    float inv_p, float grad_scale, float* __restrict__ loss_out, double loss_scale, int dbg) {
+    float inv_p, float grad_scale, float* __restrict__ loss_out, double loss_scale, int dbg_arg) {
+#if MDE_RING_ABLATE
+  const int dbg = dbg_arg;  // timing probes (tools/abl.sh): 1 consumers never wait, 2 no staging, 4 no evaluation, 8 producers never wait, 64 / 128 a role skips its loop
+#else
+  constexpr int dbg = 0;
+#endif
   constexpr int BS = MDE_RING_BS, NCW = MDE_RING_NCW, NPROD = MDE_RING_NPROD, PF = MDE_RING_PF;
   constexpr int GR_OFF = MDE_RING_GR_OFF, RING_OFF = MDE_RING_OFF;
   constexpr int C = ring_chunk_cols(D), CBYTES = ring_chunk_bytes(D), S = ring_slots(D), PIECES = CBYTES / 1024;
@@ -1159,8 +1168,14 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
                   (int)(q < 3 ? hq[u][q + 1] : (has_next ? hq[(u + 1) % 3][0] : hq[u][q])));
               const float p0n = (a0_scalar || CB) ? a0s
                                 : (q < 3 ? wq[u][q + 1] : (has_next ? wq[(u + 1) % 3][0] : wq[u][q]));
-              if (has_next) sync_for(hn);
-              const Pre nxt = pre_read(wn, p0n);
+              // chunks of the next iteration already known to be resident: read ahead now;
+              // otherwise evaluate this iteration first and wait for them afterwards
+              const bool late = has_next && ((int)(hn & 0xffffu) + (int)((hn >> 16) & 15u) >= ready) && !(dbg & 1);
+              Pre nxt;
+              if (!late) {
+                if (has_next) sync_for(hn);
+                nxt = pre_read(wn, p0n);
+              }
               const float p1 = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q] : a1s;
               if (dbg & 4)
                 loss += __uint_as_float(pq[u][q]) * 0.0f + cur.xr[0] * 0.0f;
@@ -1168,6 +1183,10 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
                 process_slow(pq[u][q], cur, p1, (int)((h >> 20) & 63u));
               else
                 process_fast(pq[u][q], cur, p1);
+              if (late) {
+                sync_for(hn);
+                nxt = pre_read(wn, p0n);
+              }
               cur = nxt;
             }
           }

@@ -1,4 +1,10 @@
-mkdir -p gpurun_out/c19; export MDE_PANEL=1 MDE_RING_STATS=1
-run() { echo "== $1 DBG=$2 n=$4" >> gpurun_out/c19/abl.txt; LD_LIBRARY_PATH=$3 MDE_RING_DBG=$2 timeout 60 ./tools/kbench $4 $5 10 2>&1 | grep -E "mde ring|codebook stream \(4|fused Log1p d=2 G|check|rc=|rror" >> gpurun_out/c19/abl.txt; }
-for v in s4d2 s5d2 s6d2 s4d1 s6d1 s8d1 s6d0; do run $v 0 tools/variants/$v 1000000 50; done
-cat gpurun_out/c19/abl.txt
+#!/bin/bash
+# abl.sh -- timing ablations of the LDS-ring kernel on the GPU box (build the probe library first:
+#   tools/build_variant.sh abl "-DMDE_RING_ABLATE=1").  MDE_RING_DBG bits: 1 consumers never wait,
+#   2 no staging, 4 no evaluation, 8 producers never wait for a slot, 64 consumers skip, 128 producers skip.
+mkdir -p gpurun_out/abl; export MDE_PANEL=1 MDE_RING_STATS=1
+for dbg in 0 1 2 3 4 64 194; do
+  echo "== MDE_RING_DBG=$dbg" >> gpurun_out/abl/abl.txt
+  LD_LIBRARY_PATH=tools/variants/abl MDE_RING_DBG=$dbg timeout 60 ./tools/kbench 1000000 50 10 2>&1 | grep -E "mde ring|codebook stream \(4|fused Log1p d=2 G|forward-only|check" >> gpurun_out/abl/abl.txt
+done
+cat gpurun_out/abl/abl.txt
