@@ -79,6 +79,8 @@ int mde_abi_version(void);
  *   MDE_F_L_FRACTIONAL      max(delta/d, d/delta) - 1
  *   MDE_F_L_SOFT_FRACTIONAL (1/g)(lse(g delta/d, g d/delta) - log 2 - g)   s0 = g (gamma)
  *   MDE_F_L_CLIPPED_QUADRATIC   min((delta-d)^2,(t+1)^2)  t
+ *   MDE_F_L_LOG1P               log(1 + (d-delta)^e)      e   (losses._Log1p; torch.pow semantics:
+ *                               NaN for d < delta unless e is an integer)
  *
  * PushAndPull [ref: penalties.py:372-400]: set `kind` to the attractive penalty and
  * `kind_neg` to the repulsive one (with its scalars in n0..n2); an edge uses `kind` when
@@ -112,7 +114,8 @@ enum {
   MDE_F_L_LOGISTIC = 39,
   MDE_F_L_FRACTIONAL = 40,
   MDE_F_L_SOFT_FRACTIONAL = 41,
-  MDE_F_L_CLIPPED_QUADRATIC = 42
+  MDE_F_L_CLIPPED_QUADRATIC = 42,
+  MDE_F_L_LOG1P = 43
 };
 
 typedef struct mde_func {

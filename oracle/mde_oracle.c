@@ -41,7 +41,7 @@ enum {
   F_DEADZONE_QUADRATIC = 13, F_DEADZONE_CUBIC = 14, F_CLIPPED_QUADRATIC = 15,
   L_QUADRATIC = 32, L_WEIGHTED_QUADRATIC = 33, L_HUBER = 34, L_CUBIC = 35, L_POWER = 36,
   L_WEIGHTED_POWER = 37, L_ABSOLUTE = 38, L_LOGISTIC = 39, L_FRACTIONAL = 40,
-  L_SOFT_FRACTIONAL = 41, L_CLIPPED_QUADRATIC = 42
+  L_SOFT_FRACTIONAL = 41, L_CLIPPED_QUADRATIC = 42, L_LOG1P = 43
 };
 
 typedef struct {
@@ -216,6 +216,13 @@ static void eval_kind(int kind, float d, float a0, float a1, float s0, float s1,
       *f = (1.f / s0) * (lse - (logf(2.f) + s0));
       const float w1 = e1 / (e1 + e2), w2 = e2 / (e1 + e2);
       *fp = (1.f / s0) * (w1 * (-s0 * a0 / (d * d)) + w2 * (s0 / a0));
+      break;
+    }
+    case L_LOG1P: { /* :232-239  log(1 + (d - delta)^e); libm powf has torch.pow's semantics
+                       (negative base: finite for an integer exponent, NaN otherwise) */
+      const float r = d - a0, pe = powf(r, s0);
+      *f = logf(1.f + pe);
+      *fp = dpowf(r, s0) / (1.f + pe);
       break;
     }
     default:

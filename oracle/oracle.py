@@ -33,7 +33,7 @@ KIND = dict(
     LOG1P=9, LOG=10, INVPOWER=11, LOGRATIO=12, DEADZONE_QUADRATIC=13, DEADZONE_CUBIC=14,
     CLIPPED_QUADRATIC=15, L_QUADRATIC=32, L_WEIGHTED_QUADRATIC=33, L_HUBER=34, L_CUBIC=35,
     L_POWER=36, L_WEIGHTED_POWER=37, L_ABSOLUTE=38, L_LOGISTIC=39, L_FRACTIONAL=40,
-    L_SOFT_FRACTIONAL=41, L_CLIPPED_QUADRATIC=42)
+    L_SOFT_FRACTIONAL=41, L_CLIPPED_QUADRATIC=42, L_LOG1P=43)
 
 
 class _OracleFunc(ctypes.Structure):

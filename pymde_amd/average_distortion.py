@@ -314,12 +314,17 @@ def _average_distortion(X, f, lhs, rhs):
     (average_distortion.py:109): lhs/rhs are the (expanded) endpoint index tensors."""
     li = lhs[:, 0] if lhs.dim() == 2 else lhs
     ri = rhs[:, 0] if rhs.dim() == 2 else rhs
-    key = (li.data_ptr(), ri.data_ptr(), li.numel(), X.shape[0], str(X.device), id(f))
-    binding = _PLAN_CACHE.get(key)
-    if binding is None:
+    key = (id(lhs), id(rhs), X.shape[0], str(X.device), id(f))
+    hit = _PLAN_CACHE.get(key)
+    # an entry is valid only for the very same tensor / function objects, unmodified since: the
+    # entry keeps them alive (no address reuse) and remembers their in-place version counters
+    if hit is not None and (hit[1] is not lhs or hit[2] is not rhs or hit[3] is not f
+                            or hit[4] != (lhs._version, rhs._version)):
+        hit = None
+    if hit is None:
         edges = torch.stack([li, ri], dim=1).to(device=X.device, dtype=torch.int64).contiguous()
         binding = Binding(EdgePlan(X.shape[0], edges), f)
         if len(_PLAN_CACHE) > 8:
             _PLAN_CACHE.clear()
-        _PLAN_CACHE[key] = binding
-    return _AverageDistortion.apply(X, binding)
+        hit = _PLAN_CACHE[key] = (binding, lhs, rhs, f, (lhs._version, rhs._version))
+    return _AverageDistortion.apply(X, hit[0])

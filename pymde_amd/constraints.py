@@ -99,10 +99,12 @@ class Anchored(Constraint):
 
     def _device_args(self, device):
         c = self._cache
-        if c is None or c[0] != str(device) or c[3] is not self.anchors or c[4] is not self.values:
+        ver = (getattr(self.anchors, "_version", None), getattr(self.values, "_version", None))
+        if (c is None or c[0] != str(device) or c[3] is not self.anchors or c[4] is not self.values
+                or c[5] != ver):  # (values edited in place are picked up through the version counter)
             a = torch.as_tensor(self.anchors).to(device=device, dtype=torch.int64).contiguous()
             v = torch.as_tensor(self.values).to(device=device, dtype=torch.float32).contiguous()
-            self._cache = c = (str(device), a, v, self.anchors, self.values)
+            self._cache = c = (str(device), a, v, self.anchors, self.values, ver)
         return c[1], c[2]
 
     def _write(self, W, device, with_values):

@@ -220,6 +220,138 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide(
   if (threadIdx.x == 0) loss_partials[blockIdx.x] = bs;
 }
 
+
+// ---------------------------------------------------------------- general-d fused kernel, 16-byte form
+// d a multiple of 4 and 16-byte aligned rows: GL lanes cooperate on one half-edge and every lane
+// moves K4 float4s of the row, so a row gather is 16 bytes per lane per instruction (a d = 128 row
+// is ONE load instruction of a half wave).  The 4-byte form above issues four times as many load
+// instructions and tops out at ~3 TB/s of row gathers at BASELINE config 5 (n = 500k, d = 128);
+// tools/rowprobe measures the chip's ceiling for random 512-byte rows from a 256 MB table at
+// 7.4 TB/s with this access shape.
+typedef float wide_f4 __attribute__((ext_vector_type(4)));
+template <int GL, int K4, bool INDIRECT, class Fn>
+__global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4(
+    int nrows, int row_lo, int d4, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ nbr,
+    const int32_t* __restrict__ eid, const float* __restrict__ a0, const float* __restrict__ a1, int a0_scalar,
+    int a1_scalar, const wide_f4* __restrict__ X4, wide_f4* __restrict__ grad4, double* __restrict__ loss_partials,
+    Fn fn, float inv_p, float grad_scale) {
+  __shared__ double smem[8];
+  constexpr int E = 64 / GL;                 // half-edges per wave step
+  constexpr int U = (K4 == 1) ? 4 : (K4 == 2 ? 2 : 1);  // independent steps in flight
+  const int lane = threadIdx.x & 63;
+  const int lig = lane & (GL - 1);
+  const int sub = lane / GL;
+  const int wave = (blockIdx.x * MDE_BLOCK + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * MDE_BLOCK) >> 6;
+  float loss = 0.0f;
+  const float a0s = a0_scalar ? a0[0] : 0.0f;
+  const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
+  const wide_f4 zero = {0.f, 0.f, 0.f, 0.f};
+
+  for (int r = wave; r < nrows; r += nwaves) {
+    const int beg = rowptr[r], end = rowptr[r + 1];
+    const int64_t v = (int64_t)row_lo + r;
+    wide_f4 xv[K4], acc[K4];
+#pragma unroll
+    for (int j = 0; j < K4; ++j) {
+      const int c = lig + j * GL;
+      xv[j] = (c < d4) ? X4[v * d4 + c] : zero;
+      acc[j] = zero;
+    }
+    // neighbour ids and parameters are fetched one step ahead: their latency overlaps the row
+    // gathers of the current step instead of preceding them
+    bool live_n[U];
+    int64_t u_n[U];
+    float p0_n[U], p1_n[U];
+    auto load_meta = [&](int h0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        const int h = h0 + q * E + sub;
+        live_n[q] = h < end;
+        const int hh = live_n[q] ? h : beg;
+        u_n[q] = nbr[hh];
+        p1_n[q] = a1s;
+        if constexpr (INDIRECT) {
+          const int k = eid[hh];
+          p0_n[q] = a0[k];
+          p1_n[q] = a1[k];
+        } else {
+          p0_n[q] = a0_scalar ? a0s : a0[hh];
+          if (a1 && !a1_scalar) p1_n[q] = a1[hh];
+        }
+      }
+    };
+    if (beg < end) load_meta(beg);
+    for (int h0 = beg; h0 < end; h0 += E * U) {
+      bool live[U];
+      int64_t u[U];
+      float p0[U], p1[U];
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        live[q] = live_n[q];
+        u[q] = u_n[q];
+        p0[q] = p0_n[q];
+        p1[q] = p1_n[q];
+      }
+      wide_f4 xu[U][K4];
+#pragma unroll
+      for (int q = 0; q < U; ++q)
+#pragma unroll
+        for (int j = 0; j < K4; ++j) {
+          const int c = lig + j * GL;
+          xu[q][j] = (c < d4) ? X4[u[q] * d4 + c] : zero;
+        }
+      if (h0 + E * U < end) load_meta(h0 + E * U);
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        wide_f4 diff[K4];
+        float ss = 0.0f;
+#pragma unroll
+        for (int j = 0; j < K4; ++j) {
+          diff[j] = xv[j] - xu[q][j];
+          ss = fmaf(diff[j].x, diff[j].x, ss);
+          ss = fmaf(diff[j].y, diff[j].y, ss);
+          ss = fmaf(diff[j].z, diff[j].z, ss);
+          ss = fmaf(diff[j].w, diff[j].w, ss);
+        }
+        ss = mde_group_sum<GL>(ss);
+        float f, gd;
+        fn.eval(ss, p0[q], p1[q], f, gd);
+        float g = mde_fix_g(gd * inv_p);
+        if (!live[q]) {
+          g = 0.0f;
+          f = 0.0f;
+        }
+        if (lig == 0) loss += f;
+#pragma unroll
+        for (int j = 0; j < K4; ++j) acc[j] += g * diff[j];
+      }
+    }
+    if (grad4) {
+      // combine the E sub-groups (lanes with equal lig): xor over the sub index bits
+#pragma unroll
+      for (int j = 0; j < K4; ++j) {
+#pragma unroll
+        for (int o = 32; o >= GL; o >>= 1) {
+          acc[j].x += __shfl_xor(acc[j].x, o, 64);
+          acc[j].y += __shfl_xor(acc[j].y, o, 64);
+          acc[j].z += __shfl_xor(acc[j].z, o, 64);
+          acc[j].w += __shfl_xor(acc[j].w, o, 64);
+        }
+      }
+      if (sub == 0) {
+#pragma unroll
+        for (int j = 0; j < K4; ++j) {
+          const int c = lig + j * GL;
+          if (c < d4) grad4[v * d4 + c] = acc[j] * grad_scale;
+        }
+      }
+    }
+  }
+  const double bs = mde_block_sum((double)loss, smem);
+  if (threadIdx.x == 0) loss_partials[blockIdx.x] = bs;
+}
+
 // loss = scale * sum(partials[0..nb)) in a fixed order (one block)
 __global__ void k_finalize_loss(const double* __restrict__ partials, int nb, double scale,
                                 float* __restrict__ loss_out) {
@@ -311,9 +443,34 @@ static int launch_wide_gk(FusedArgs& A, const Fn& fn) {
   MDE_LAUNCH_CHECK();
   return MDE_OK;
 }
+template <int GL, int K4, bool IND, class Fn>
+static int launch_wide4_gk(FusedArgs& A, const Fn& fn) {
+  const mde_plan* P = A.plan;
+  const int nrows = (int)(mde_plan_row_hi(P) - mde_plan_row_lo(P));
+  const int nb = mde_grid((int64_t)nrows * 64, MDE_BLOCK, 2048);
+  A.nblocks = nb;
+  hipLaunchKernelGGL((k_fused_wide4<GL, K4, IND, Fn>), dim3(nb), dim3(MDE_BLOCK), 0, A.st, nrows,
+                     (int)mde_plan_row_lo(P), A.d / 4, mde_plan_rowptr(P), mde_plan_nbr(P), mde_plan_eid(P),
+                     A.a0, A.a1, A.a0_scalar, A.a1_scalar, reinterpret_cast<const wide_f4*>(A.X),
+                     reinterpret_cast<wide_f4*>(A.grad), A.partials, fn, A.inv_p, A.grad_scale);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
 template <bool IND, class Fn>
 static int launch_wide(FusedArgs& A, const Fn& fn) {
   const int d = A.d;
+  if ((d & 3) == 0 && ((reinterpret_cast<uintptr_t>(A.X) | reinterpret_cast<uintptr_t>(A.grad)) & 15) == 0) {
+    const int d4 = d >> 2;
+    if (d4 <= 2) return launch_wide4_gk<2, 1, IND, Fn>(A, fn);
+    if (d4 <= 4) return launch_wide4_gk<4, 1, IND, Fn>(A, fn);
+    if (d4 <= 8) return launch_wide4_gk<8, 1, IND, Fn>(A, fn);
+    if (d4 <= 16) return launch_wide4_gk<16, 1, IND, Fn>(A, fn);
+    if (d4 <= 32) return launch_wide4_gk<32, 1, IND, Fn>(A, fn);
+    if (d4 <= 64) return launch_wide4_gk<64, 1, IND, Fn>(A, fn);
+    if (d4 <= 128) return launch_wide4_gk<64, 2, IND, Fn>(A, fn);
+    if (d4 <= 256) return launch_wide4_gk<64, 4, IND, Fn>(A, fn);
+    if (d4 <= 512) return launch_wide4_gk<64, 8, IND, Fn>(A, fn);
+  }
   if (d <= 8) return launch_wide_gk<8, 1, IND, Fn>(A, fn);
   if (d <= 16) return launch_wide_gk<16, 1, IND, Fn>(A, fn);
   if (d <= 32) return launch_wide_gk<32, 1, IND, Fn>(A, fn);

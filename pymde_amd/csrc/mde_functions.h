@@ -254,6 +254,22 @@ MDE_DEV void mde_eval(float ss, float a0, float a1, const MdeScalars& S, float& 
     const float w1 = (q1 >= q2) ? wmx : wmn, w2 = (q1 >= q2) ? wmn : wmx;
     const float fp = w1 * (-a0 * mde_rcp(ss)) + w2 * mde_rcp(a0);
     gd = fp * mde_rcp(d);
+  } else if constexpr (KIND == MDE_F_L_LOG1P) {  // losses.py:232-239  log(1 + (d - delta)^e)
+    const float d = mde_sqrt(ss);
+    const float r = d - a0;
+    const float e = S.s0;
+    // torch.pow: a negative base is fine for an integer exponent, NaN otherwise
+    const bool e_int = (e == floorf(e));
+    const bool e_odd = e_int && (fmodf(fabsf(e), 2.0f) == 1.0f);
+    const float ar = fabsf(r);
+    float pw = mde_pow<0>(ar, e), pm1 = mde_pow<0>(ar, e - 1.0f);  // |r|^e, |r|^(e-1)
+    if (r < 0.0f) {
+      pw = e_int ? (e_odd ? -pw : pw) : __builtin_nanf("");
+      pm1 = e_int ? (e_odd ? pm1 : -pm1) : __builtin_nanf("");
+    }
+    const float t = 1.0f + pw;
+    f = mde_log(t);
+    gd = e * pm1 * mde_rcp(t) * mde_rcp(d);
   } else {
     f = 0.0f;
     gd = 0.0f;
@@ -295,6 +311,7 @@ MDE_DEV void mde_eval_rt(int kind, float ss, float a0, float a1, const MdeScalar
     MDE_CASE(MDE_F_L_FRACTIONAL)
     MDE_CASE(MDE_F_L_SOFT_FRACTIONAL)
     MDE_CASE(MDE_F_L_CLIPPED_QUADRATIC)
+    MDE_CASE(MDE_F_L_LOG1P)
 #undef MDE_CASE
     default:
       f = 0.0f;
@@ -304,7 +321,7 @@ MDE_DEV void mde_eval_rt(int kind, float ss, float a0, float a1, const MdeScalar
 
 static inline bool mde_kind_valid(int kind) {
   return (kind >= MDE_F_LINEAR && kind <= MDE_F_CLIPPED_QUADRATIC) ||
-         (kind >= MDE_F_L_QUADRATIC && kind <= MDE_F_L_CLIPPED_QUADRATIC);
+         (kind >= MDE_F_L_QUADRATIC && kind <= MDE_F_L_LOG1P);
 }
 
 // ---------------------------------------------------------------- functors used by the kernels

@@ -51,16 +51,21 @@ class GradExchange(object):
     def _gather(self, buf):
         N = self.n * self.d
         lo, hi = self.bounds[self.rank] * self.d, self.bounds[self.rank + 1] * self.d
-        mine = buf[lo:hi].clone()
-        share = buf[N:N + 1].clone()
         if self._losses is None:
             self._losses = torch.empty(self.world, dtype=buf.dtype, device=buf.device)
-        h1 = dist.all_gather_into_tensor(buf[:N], mine, group=self.group, async_op=True)
-        h2 = dist.all_gather_into_tensor(self._losses, share, group=self.group, async_op=True)
+        # in place: this rank's rows already sit at their offset of the gathered buffer (the
+        # NCCL / RCCL in-place all-gather form), so no staging copy; rows owned by other ranks
+        # are overwritten and need not be zeroed first
+        h1 = dist.all_gather_into_tensor(buf[:N], buf[lo:hi], group=self.group, async_op=True)
+        h2 = dist.all_gather_into_tensor(self._losses, buf[N:N + 1], group=self.group, async_op=True)
         h1.wait()
         h2.wait()
         buf[N] = self._losses.sum()
         return buf
+
+    def needs_zero(self):
+        """Whether rows of other ranks must be zero before the exchange (all-reduce only)."""
+        return self.mode != "all_gather"
 
     def __call__(self, buf):
         if self.world <= 1 or not (dist.is_available() and dist.is_initialized()):

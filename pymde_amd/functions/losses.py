@@ -127,3 +127,13 @@ class SoftFractional(_Loss):
         if gamma <= 0.0:
             raise ValueError("gamma must be positive, received ", float(gamma))
         self.gamma = util.to_tensor(gamma, device=self.deviations.device)
+
+
+class _Log1p(_Loss):
+    """l(d, delta) = log(1 + (d - delta)^exponent)  [ref: losses.py:232-239; private upstream]"""
+    _kind = "L_LOG1P"
+    _scalar_attrs = ("exponent",)
+
+    def __init__(self, deviations, exponent):
+        super(_Log1p, self).__init__(deviations)
+        self.exponent = util.to_tensor(exponent, device=self.deviations.device)

@@ -18,13 +18,59 @@ from pymde_amd import util
 
 
 class Graph(object):
-    """An undirected weighted graph given by its unique edges."""
+    """An undirected weighted graph.
 
-    def __init__(self, edges, values, n_items):
-        self.edges = edges
-        self._values = values
-        self.n_items = int(n_items)
-        self._plan = None
+    ``Graph(adjacency_matrix)`` takes what the reference's constructor takes [ref:
+    graph.py:90-112]: a dense ``numpy`` / ``torch`` matrix or a scipy sparse matrix; ``inf``
+    entries mean "no edge", the upper triangle defines the (undirected) edges, and a non-zero
+    diagonal is an error.  Internally the graph is its unique edges ``i < j`` with one value each,
+    on the GPU (``Graph._from_unique_edges``, ``Graph.from_edges``)."""
+
+    def __init__(self, adjacency_matrix, device=None):
+        import numpy as np
+        try:
+            import scipy.sparse as sp
+        except ImportError:  # pragma: no cover
+            sp = None
+        A = adjacency_matrix
+        if sp is not None and sp.issparse(A):
+            A = A.tocoo()
+            rows, cols, vals = np.asarray(A.row), np.asarray(A.col), np.asarray(A.data, dtype=np.float64)
+            n = int(A.shape[0])
+        else:
+            if isinstance(A, torch.Tensor):
+                A = A.detach().cpu().numpy()
+            A = np.asarray(A)
+            if A.ndim != 2 or A.shape[0] != A.shape[1]:
+                raise ValueError("An adjacency matrix must be square; got shape %s" % (tuple(A.shape),))
+            n = int(A.shape[0])
+            rows, cols = np.nonzero(A)
+            vals = np.asarray(A[rows, cols], dtype=np.float64)
+        keep = (vals != 0) & ~np.isinf(vals)  # inf = unreachable = no edge (graph.py:104-106)
+        rows, cols, vals = rows[keep], cols[keep], vals[keep]
+        diag = rows == cols
+        if (vals[diag] > 0).any():
+            raise ValueError("Adjacency matrices must not contain self edges; "
+                             "the following nodes were found to have self edges: ",
+                             np.unique(rows[diag & (vals > 0)]))
+        upper = rows < cols  # the lower triangle is redundant (graph.py:27-28)
+        if device is None:
+            device = util.get_default_device()
+        device = util.require_cuda_device(device)
+        e = torch.as_tensor(np.stack([rows[upper], cols[upper]], axis=1).astype(np.int64), device=device)
+        g = Graph.from_edges(e.reshape(-1, 2), torch.as_tensor(vals[upper].astype(np.float32), device=device),
+                             n_items=n, device=device)
+        self.edges, self._values, self.n_items, self._plan = g.edges, g._values, n, None
+
+    @classmethod
+    def _from_unique_edges(cls, edges, values, n_items):
+        """Unique edges ``i < j`` (sorted) with one value each, already on the GPU."""
+        g = cls.__new__(cls)
+        g.edges = edges
+        g._values = values
+        g.n_items = int(n_items)
+        g._plan = None
+        return g
 
     @staticmethod
     def from_edges(edges, weights=None, n_items=None, device=None):
@@ -52,7 +98,7 @@ class Graph(object):
         vals = torch.zeros(uniq.shape[0], dtype=torch.float32, device=device)
         vals.index_add_(0, inverse, weights)
         e = torch.stack([uniq // n_items, uniq % n_items], dim=1).contiguous()
-        return Graph(e, vals, n_items)
+        return Graph._from_unique_edges(e, vals, n_items)
 
     @property
     def weights(self):
@@ -107,7 +153,7 @@ def shortest_paths(graph, retain_fraction=1.0, max_length=None, seed=0, verbose=
             ctypes.c_uint64(int(seed) & (2 ** 64 - 1)), capacity, _lib.ptr(edges), _lib.ptr(dist),
             ctypes.byref(count), _lib.stream_ptr(device)))
     m = count.value
-    return Graph(edges[:m], dist[:m], n)
+    return Graph._from_unique_edges(edges[:m], dist[:m], n)
 
 
 def k_nearest_neighbors(graph, k, graph_distances=False, max_distance=None, verbose=False):

@@ -154,8 +154,7 @@ def strong_wolfe(phi, t, f0, gtd0, d_norm, c1=1e-4, c2=0.9, tolerance_change=1e-
     if failed:
         while t > 1e-8:
             t *= 0.8
-            f_new, gtd_new, _ = phi(t)
-            n_evals += 1
+            f_new, gtd_new, _ = phi(t)  # (the reference does not count the back-off evaluations)
             if math.isnan(f_new):
                 continue
             if f_new < f0 + c1 * t * gtd0:
@@ -163,7 +162,6 @@ def strong_wolfe(phi, t, f0, gtd0, d_norm, c1=1e-4, c2=0.9, tolerance_change=1e-
     if math.isnan(f_new):
         t = 0.0
         f_new, gtd_new, _ = phi(t)
-        n_evals += 1
     return f_new, t, n_evals
 
 

@@ -97,8 +97,12 @@ class _Engine(object):
         # the solve runs on the stream that is current now; its handle is looked up once
         self._stream_obj = torch.cuda.current_stream(dev)
         self._stream = ctypes.c_void_p(self._stream_obj.cuda_stream)
+        if int(memory_size) > 63:
+            raise ValueError("memory_size must be at most 63 (the device-resident L-BFGS keeps its "
+                             "pair statistics in one wave); got %d" % int(memory_size))
         handle = ctypes.c_void_p()
-        _lib.check(self.lib.mde_lbfgs_create(self.N, int(memory_size), ctypes.byref(handle)))
+        with torch.cuda.device(dev):  # the history buffer must live on X's GPU, not the current one
+            _lib.check(self.lib.mde_lbfgs_create(self.N, int(memory_size), ctypes.byref(handle)))
         self.lbfgs = handle
 
     def close(self):
@@ -178,8 +182,8 @@ class _NativeProblem(object):
     def value_and_grad(self, X):
         from pymde_amd import average_distortion as ad
         e, lib = self.e, self.e.lib
-        if self.reducer is not None:
-            e.gbuf.zero_()
+        if self.reducer is not None and getattr(self.reducer, "needs_zero", lambda: True)():
+            e.gbuf.zero_()  # (an all-gather exchange overwrites the other ranks' rows instead)
         if self.binding.fused:
             _lib.check(lib.mde_average_distortion(
                 self.binding.plan.handle, _lib.ptr(X), e.d, ctypes.byref(self.fstruct), 1.0,
@@ -242,7 +246,13 @@ def _make_problem(engine, objective_fn, constraint):
     if (builtin and owner is not None and hasattr(owner, "_binding")
             and getattr(objective_fn, "__name__", "") == "average_distortion"):
         reducer = getattr(owner, "_reducer", None)
-        return _NativeProblem(engine, owner._binding(), constraint, reducer)
+        binding = owner._binding()
+        if reducer is not None and not binding.fused:
+            # the unfused path evaluates the full mean on every rank and fills only the owned
+            # gradient rows: the exchange would produce garbage (average_distortion raises too)
+            raise NotImplementedError("a sharded problem needs a built-in distortion function "
+                                      "(pymde_amd.penalties / pymde_amd.losses)")
+        return _NativeProblem(engine, binding, constraint, reducer)
     return _GenericProblem(engine, objective_fn, constraint)
 
 

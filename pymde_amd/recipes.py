@@ -121,8 +121,9 @@ def preserve_neighbors(data, embedding_dim=2, attractive_penalty=penalties.Log1p
     device = util.require_cuda_device(device)
     n = int(data.n_items) if is_graph else int(data.shape[0])
     if n_neighbors is None:
-        # the reference's default (recipes.py:300-307): max(min(15, 2 % of the items), 5)
-        n_neighbors = int(max(min(15, n * 0.02), 5))
+        # the reference's default (recipes.py:318-321): about 1 % of all pairs as edges, within [5, 15]
+        n_choose_2 = n * (n - 1) / 2
+        n_neighbors = int(max(min(15, n_choose_2 * 0.01 / n), 5))
     if n_neighbors > n:
         problem.LOGGER.warning(
             "Requested n_neighbors {0} > number of items {1}. Setting n_neighbors to {2}".format(
@@ -132,6 +133,9 @@ def preserve_neighbors(data, embedding_dim=2, attractive_penalty=penalties.Log1p
         constraint = constraints.Centered()
     elif constraint is None and repulsive_penalty is None:
         constraint = constraints.Standardized()
+    if is_graph and max_distance is None:
+        # the reference bounds neighbourhoods on graphs (recipes.py:335-339)
+        max_distance = (3 * torch.quantile(data.distances.float().cpu(), 0.75)).item()
     if verbose:
         problem.LOGGER.info(f"Computing {n_neighbors}-nearest neighbors, with max_distance={max_distance}")
     if is_graph:

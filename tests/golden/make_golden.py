@@ -18,6 +18,7 @@ Fixtures
   preprocess.npz    deduplicate_edges / sample_edges of the reference
   cycle.npz         BASELINE config 1 scaled down: preserve_distances on a cycle graph,
                     losses.Quadratic, all pairs
+  linesearch.npz    trial sequences of _strong_wolfe on scalar problems (lbfgs.py:44-253)
   api.npz           pca / align / rotate, k-NN with max_distance, graph k-NN (shortest-path and
                     direct), the graphs behind laplacian_embedding and preserve_neighbors(Graph)
 """
@@ -110,6 +111,21 @@ def function_cases(pymde, torch, rng, p):
         ("loss_fractional", los.Fractional(dev), "L_FRACTIONAL", dev, None, (), "NONE", ()),
         ("loss_soft_fractional", los.SoftFractional(dev, 5.0), "L_SOFT_FRACTIONAL", dev, None, (5.0,),
          "NONE", ()),
+        # the reference's private kinds (penalties.py:134-160,174-188; losses.py:90-98,151-163,232-239)
+        ("pen_deadzone_quadratic", pen._DeadzoneQuadratic(w_pos, 1.0), "DEADZONE_QUADRATIC", w_pos, None,
+         (1.0,), "NONE", ()),
+        ("pen_deadzone_cubic", pen._DeadzoneCubic(w_pos, 1.2), "DEADZONE_CUBIC", w_pos, None, (1.2,),
+         "NONE", ()),
+        ("pen_clipped_quadratic", pen._ClippedQuadratic(w_pos, torch.tensor(0.4)), "CLIPPED_QUADRATIC", w_pos, None,
+         (0.4,), "NONE", ()),
+        ("loss_clipped_quadratic", los._ClippedQuadratic(dev, torch.tensor(0.1)), "L_CLIPPED_QUADRATIC", dev, None,
+         (0.1,), "NONE", ()),
+        ("loss_weighted_power", los._WeightedPower(dev, 1.7, w2), "L_WEIGHTED_POWER", dev, w2, (1.7,),
+         "NONE", ()),
+        ("loss_weighted_power_default", los._WeightedPower(dev, 2.0), "L_WEIGHTED_POWER", dev,
+         1.0 / dev.pow(2), (2.0,), "NONE", ()),
+        # (an even exponent: the reference's (d - delta).pow(e) is NaN for d < delta otherwise)
+        ("loss_log1p_e2", los._Log1p(dev, 2.0), "L_LOG1P", dev, None, (2.0,), "NONE", ()),
     ]
     return cases
 
@@ -414,11 +430,76 @@ def gen_api(pymde, torch):
     print("api.npz:", {k: np.asarray(v).shape for k, v in out.items() if k.endswith("edges")})
 
 
+def linesearch_problems():
+    """Scalar problems phi(t) -> (f, f') for the strong-Wolfe trace; shared with the test."""
+    nan = float("nan")
+
+    def quartic(t):
+        return (t - 0.25) ** 2 * (t + 1) ** 2, 2 * (t - 0.25) * (t + 1) * (2 * t + 0.75)
+
+    def more_thuente(t):  # -t / (t^2 + 2): long extrapolation phase from a tiny first step
+        return -t / (t * t + 2.0), (t * t - 2.0) / (t * t + 2.0) ** 2
+
+    def steep(t):  # Armijo fails at t = 1, zoom with the 10 % safeguard
+        return 1.0 - t + 40.0 * t ** 4, -1.0 + 160.0 * t ** 3
+
+    def nan_beyond(t):  # not finite for t > 0.3: the halving prologue
+        return ((t - 0.2) ** 2, 2 * (t - 0.2)) if t <= 0.3 else (nan, nan)
+
+    def nan_gap(t):  # finite at t >= 1 and t <= 0.01 only: zoom walks into NaNs, 0.8 back-off recovers
+        if t >= 1.0:
+            return 10.0, 1.0
+        if t <= 0.01:
+            return 1.0 - t, -1.0
+        return nan, nan
+
+    def nan_below(t):  # finite at t = 0 and t >= 1 only: the back-off ends at t = 0
+        if t >= 1.0:
+            return 10.0, 1.0
+        if t == 0.0:
+            return 1.0, -1.0
+        return nan, nan
+
+    return [("quartic", quartic, 1.0), ("more_thuente_small", more_thuente, 1e-3),
+            ("more_thuente_large", more_thuente, 10.0), ("steep", steep, 1.0),
+            ("nan_beyond", nan_beyond, 1.0), ("nan_gap", nan_gap, 1.0), ("nan_below", nan_below, 1.0)]
+
+
+def gen_linesearch(pymde, torch):
+    """Trial sequences of the reference's _strong_wolfe (lbfgs.py:44-253) on scalar problems
+    (x = 0, d = 1, so the trial point IS t), in float64."""
+    from pymde import lbfgs as ref_lbfgs
+    out = {"names": np.array([p[0] for p in linesearch_problems()])}
+    for name, fn, t0 in linesearch_problems():
+        trials = []
+
+        def obj_func(x, t, d):
+            trials.append(float(t))
+            f, g = fn(float(t))
+            return f, torch.tensor([g], dtype=torch.float64)
+        f0, g0 = fn(0.0)
+        x = [torch.zeros(1, dtype=torch.float64)]
+        d = torch.ones(1, dtype=torch.float64)
+        g = torch.tensor([g0], dtype=torch.float64)
+        f_new, g_new, t, n_evals = ref_lbfgs._strong_wolfe(obj_func, x, t0, d, f0, g, g.dot(d))
+        out[name + "__t0"] = np.array(t0)
+        out[name + "__trials"] = np.array(trials, dtype=np.float64)
+        out[name + "__result"] = np.array([float(f_new), float(t), float(n_evals)], dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "linesearch.npz"), **out)
+    print("linesearch.npz:", {n: len(out[n + "__trials"]) for n in out["names"]})
+
+
 def main():
     pymde = import_reference()
     import torch
     torch.set_num_threads(1)
+    only = sys.argv[1:]
+    if only:  # e.g. `make_golden.py functions linesearch`
+        for name in only:
+            globals()["gen_" + name](pymde, torch)
+        return
     gen_functions(pymde, torch)
+    gen_linesearch(pymde, torch)
     gen_constraints(pymde, torch)
     gen_trajectories(pymde, torch)
     gen_spectral(pymde, torch)

@@ -36,6 +36,9 @@ def _make_function(fd, device=DEV):
         "LOG1P": lambda w, sc: pen.Log1p(w, sc[0]), "LOG": lambda w, sc: pen.Log(w, sc[0]),
         "INVPOWER": lambda w, sc: pen.InvPower(w, sc[0]),
         "LOGRATIO": lambda w, sc: pen.LogRatio(w, sc[0]),
+        "DEADZONE_QUADRATIC": lambda w, sc: pen._DeadzoneQuadratic(w, sc[0]),
+        "DEADZONE_CUBIC": lambda w, sc: pen._DeadzoneCubic(w, sc[0]),
+        "CLIPPED_QUADRATIC": lambda w, sc: pen._ClippedQuadratic(w, sc[0]),
     }
     kind, kind_neg = fd["kind"], fd.get("kind_neg", "NONE")
     if kind_neg != "NONE":
@@ -52,6 +55,9 @@ def _make_function(fd, device=DEV):
         "L_POWER": lambda: los.Power(a0, s[0]), "L_ABSOLUTE": lambda: los.Absolute(a0),
         "L_LOGISTIC": lambda: los.Logistic(a0), "L_FRACTIONAL": lambda: los.Fractional(a0),
         "L_SOFT_FRACTIONAL": lambda: los.SoftFractional(a0, s[0]),
+        "L_CLIPPED_QUADRATIC": lambda: los._ClippedQuadratic(a0, s[0]),
+        "L_WEIGHTED_POWER": lambda: los._WeightedPower(a0, s[0], a1),
+        "L_LOG1P": lambda: los._Log1p(a0, s[0]),
     }
     return losses[kind]()
 

@@ -13,6 +13,8 @@ import torch
 from conftest import ROOT
 from pymde_amd import _lib, lbfgs
 
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
 
 # ---------------------------------------------------------------- the C ABI
 def _declared_symbols():
@@ -141,22 +143,31 @@ def test_strong_wolfe_backs_off_non_finite_trials():
         lbfgs.strong_wolfe(always_nan, 1.0, 1.0, -1.0, d_norm=1.0)
 
 
-def test_strong_wolfe_matches_reference_trace_on_a_scalar_problem():
-    """Trace of the reference's _strong_wolfe (lbfgs.py:44-253) on phi(t) = (t-0.25)^2 (t+1)^2
-    started at t = 1, recorded by running the reference in the build container."""
-    def fn(t):
-        return (t - 0.25) ** 2 * (t + 1) ** 2, 2 * (t - 0.25) * (t + 1) * (2 * t + 0.75)
-    seen = []
+def test_strong_wolfe_reproduces_the_reference_trial_sequences():
+    """tests/golden/linesearch.npz: every trial step and the returned (f, t, n_evals) of the
+    reference's _strong_wolfe (lbfgs.py:44-253), recorded by running it in the build container on
+    scalar problems that hit the extrapolation phase, the zoom with its 10 % safeguard, the
+    NaN-halving prologue, and the 0.8 back-off (once recovering, once ending at t = 0)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = np.load(os.path.join(GOLDEN, "linesearch.npz"))
+    assert len(g["names"]) >= 6
+    for name, fn, t0 in mg.linesearch_problems():
+        want_trials, want = g[name + "__trials"], g[name + "__result"]
+        seen = []
 
-    def phi(t):
-        seen.append(t)
-        f, g = fn(t)
-        return f, g, True
-    f0, g0 = fn(0.0)
-    f_t, t, n = lbfgs.strong_wolfe(phi, 1.0, f0, g0, d_norm=1.0)
-    assert _wolfe_ok(lambda s: fn(s) + (True,), t, f0, g0)
-    assert seen[0] == 1.0 and len(seen) == n
-    assert abs(t - 0.25) < 0.2
+        def phi(t):
+            seen.append(t)
+            f, gd = fn(t)
+            return f, gd, not (math.isnan(gd) or math.isinf(gd))
+        f0, g0 = fn(0.0)
+        f_t, t, n = lbfgs.strong_wolfe(phi, float(t0), f0, g0, d_norm=1.0)
+        assert len(seen) == len(want_trials), (name, seen, want_trials)
+        np.testing.assert_allclose(seen, want_trials, rtol=1e-6, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose([f_t, t], want[:2], rtol=1e-6, atol=1e-12, err_msg=name)
+        assert n == int(want[2]), name
 
 
 # ---------------------------------------------------------------- two-loop recursion
