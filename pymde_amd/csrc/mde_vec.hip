@@ -452,6 +452,51 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_rmul_generic(int64_t n, int d, in
   }
 }
 
+// Widths that are multiples of 32 with d * d2 floats <= 64 KB (d = d2 <= 128): f32 MFMA
+// (v_mfma_f32_32x32x2_f32).  A 256-thread workgroup takes 32 rows: their d columns are staged in
+// LDS with coalesced loads (row stride d + 1: the A-operand reads then walk distinct banks), M is
+// staged once as fp32, and wave w produces the 32 x 32 output tiles j = w, w + 4, ...  Operand
+// map as in k_gram_mfma: A-operand lane l = (row l & 31, k = l >> 5), B-operand lane l =
+// (k = l >> 5, column l & 31); C/D: column l & 31, row (reg & 3) + 8 (reg >> 2) + 4 (l >> 5).
+__global__ __launch_bounds__(MDE_BLOCK) void k_rmul_mfma(int64_t n, int d, int d2, const float* __restrict__ A,
+                                                         const double* __restrict__ M, float alpha,
+                                                         const float* base, float* out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* sm = reinterpret_cast<float*>(smem_raw);  // [d][d2] fp32 copy of M
+  float* sa = sm + (size_t)d * d2;                 // [32][d + 1]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kk = lane >> 5, cc = lane & 31;
+  const int lda = d + 1;
+  for (int i = tid; i < d * d2; i += MDE_BLOCK) sm[i] = (float)M[i];
+  for (int64_t t0 = (int64_t)blockIdx.x * 32; t0 < n; t0 += (int64_t)gridDim.x * 32) {
+    __syncthreads();  // (previous tile's reads of sa are done; sm is ready on the first trip)
+    for (int i = tid; i < 32 * d; i += MDE_BLOCK) {
+      const int r = i / d, c = i - r * d;
+      sa[r * lda + c] = (t0 + r < n) ? A[(t0 + r) * d + c] : 0.0f;
+    }
+    __syncthreads();
+    for (int tj = wave; tj * 32 < d2; tj += MDE_BLOCK / 64) {
+      f32x16 acc;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+      const float* pa = sa + cc * lda + kk;
+      const float* pb = sm + (size_t)kk * d2 + tj * 32 + cc;
+#pragma unroll 4
+      for (int c = 0; c < d; c += 2)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[c], pb[(size_t)c * d2], acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * kk;
+        if (t0 + row < n) {
+          const int64_t o = (t0 + row) * d2 + tj * 32 + cc;
+          const float b = base ? base[o] : 0.0f;
+          out[o] = fmaf(alpha, acc[q], b);
+        }
+      }
+    }
+  }
+}
+
 static int rmul_impl(int64_t n, int d, int d2, const float* A, const double* M, float alpha,
                      const float* base, float* out, hipStream_t st) {
 #define RT(D_)                                                                                     \
@@ -463,6 +508,17 @@ static int rmul_impl(int64_t n, int d, int d2, const float* A, const double* M, 
   }
   RT(1) RT(2) RT(3) RT(4)
 #undef RT
+  if (g_no_mfma < 0) {
+    const char* e = getenv("MDE_NO_MFMA");
+    g_no_mfma = (e && atoi(e)) ? 1 : 0;
+  }
+  if (!g_no_mfma && d % 32 == 0 && d2 % 32 == 0 && (size_t)d * d2 * sizeof(float) <= 65536 && (A != out || d == d2)) {
+    const size_t lds = ((size_t)d * d2 + 32 * (size_t)(d + 1)) * sizeof(float);
+    hipLaunchKernelGGL(k_rmul_mfma, dim3(mde_grid(n, 32, 2048)), dim3(MDE_BLOCK), lds, st, n, d, d2, A, M, alpha,
+                       base, out);
+    MDE_LAUNCH_CHECK();
+    return MDE_OK;
+  }
   int rows_tile = 8192 / d;
   if (rows_tile < 1) rows_tile = 1;
   if (rows_tile > 64) rows_tile = 64;
@@ -633,6 +689,132 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_invsqrt(int d, const double* __re
   if (tid == 0 && status && !converged) *status = 1;
 }
 
+
+// ---------------------------------------------------------------- C^{-1/2}, d >= 32: one launch per half step
+// The single-workgroup iteration above needs three d^3 double products per step out of global
+// memory with 256 threads (22 ms at d = 128).  Here every product is spread over d^2 / 256
+// workgroups; the convergence test lives in a device flag that turns the remaining launches of
+// the fixed-length sequence into no-ops.
+//   ctl[0] = state: 0 iterating, 1 converged, 2 failed     ctl[1] = residual bits (max |I - Z Y|)
+__global__ __launch_bounds__(MDE_BLOCK) void k_ns_init(int d, const double* __restrict__ C, double* __restrict__ Y,
+                                                       double* __restrict__ Z, double* __restrict__ ctl) {
+  __shared__ double smem[8];
+  const int m = d * d;
+  double ss = 0.0;
+  for (int i = threadIdx.x; i < m; i += MDE_BLOCK) ss += C[i] * C[i];
+  const double tot = mde_block_sum(ss, smem);
+  __shared__ double sh;
+  if (threadIdx.x == 0) sh = sqrt(tot);
+  __syncthreads();
+  const double s = sh;
+  const bool ok = (s > 0.0) && (s < 1e300);
+  for (int i = threadIdx.x; i < m; i += MDE_BLOCK) {
+    const int r = i / d, c = i % d;
+    Y[i] = ok ? 0.5 * (C[i] + C[c * d + r]) / s : 0.0;  // symmetrise
+    Z[i] = (r == c) ? 1.0 : 0.0;
+  }
+  if (threadIdx.x == 0) {
+    ctl[0] = ok ? 0.0 : 2.0;
+    ctl[1] = 0.0;
+    ctl[2] = s;
+  }
+}
+// T = (3 I - Z Y) / 2 and the residual max |I - Z Y| (atomic max on the bit pattern of a non-negative double)
+__global__ __launch_bounds__(MDE_BLOCK) void k_ns_t(int d, const double* __restrict__ Y, const double* __restrict__ Z,
+                                                    double* __restrict__ T, double* __restrict__ ctl) {
+  if (ctl[0] != 0.0) return;
+  __shared__ double smem[8];
+  const int i = blockIdx.x * MDE_BLOCK + threadIdx.x;
+  double e = 0.0;
+  if (i < d * d) {
+    const int r = i / d, c = i % d;
+    double acc = 0.0;
+    for (int k = 0; k < d; ++k) acc = fma(Z[r * d + k], Y[k * d + c], acc);
+    e = ((r == c) ? 1.0 : 0.0) - acc;
+    T[i] = ((r == c) ? 1.0 : 0.0) + 0.5 * e;
+    e = (e == e) ? fabs(e) : 1e308;
+  }
+  const double mx = mde_block_max(e, smem);
+  if (threadIdx.x == 0)
+    atomicMax(reinterpret_cast<unsigned long long*>(ctl + 1), (unsigned long long)__double_as_longlong(mx));
+}
+// (Y, Z) <- (Y T, T Z) unless the residual of this step says converged / failed
+__global__ __launch_bounds__(MDE_BLOCK) void k_ns_yz(int d, const double* __restrict__ Y, const double* __restrict__ Z,
+                                                     const double* __restrict__ T, double* __restrict__ Yn,
+                                                     double* __restrict__ Zn, const double* __restrict__ ctl) {
+  if (ctl[0] != 0.0) return;
+  const double res = ctl[1];
+  if (res < 1e-13 || !(res < 1e300)) return;  // k_ns_flag records it
+  const int i = blockIdx.x * MDE_BLOCK + threadIdx.x;
+  if (i >= d * d) return;
+  const int r = i / d, c = i % d;
+  double ay = 0.0, az = 0.0;
+  for (int k = 0; k < d; ++k) {
+    ay = fma(Y[r * d + k], T[k * d + c], ay);
+    az = fma(T[r * d + k], Z[k * d + c], az);
+  }
+  Yn[i] = ay;
+  Zn[i] = az;
+}
+// after k_ns_yz: fold the residual into the state and reset it for the next step
+__global__ void k_ns_flag(double* __restrict__ ctl, int* __restrict__ which) {
+  if (ctl[0] != 0.0) return;
+  const double res = ctl[1];
+  if (res < 1e-13)
+    ctl[0] = 1.0;
+  else if (!(res < 1e300))
+    ctl[0] = 2.0;
+  else
+    *which ^= 1;  // the new (Y, Z) pair is the current one
+  ctl[1] = 0.0;
+}
+__global__ __launch_bounds__(MDE_BLOCK) void k_ns_finish(int d, const double* __restrict__ Z0, const double* __restrict__ Z1,
+                                                         const int* __restrict__ which, const double* __restrict__ ctl,
+                                                         double out_scale, double* __restrict__ M,
+                                                         int32_t* __restrict__ status) {
+  const bool ok = ctl[0] == 1.0;
+  const double* Z = *which ? Z1 : Z0;
+  const double k = ok ? out_scale / sqrt(ctl[2]) : 0.0;
+  for (int i = blockIdx.x * MDE_BLOCK + threadIdx.x; i < d * d; i += gridDim.x * MDE_BLOCK) M[i] = ok ? Z[i] * k : 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && status && !ok) *status = 1;
+}
+
+// M = out_scale * C^{-1/2}: the single-workgroup kernel for small d, the launch sequence above otherwise
+static int invsqrt_impl(int d, const double* C, double out_scale, double* M, double* scratch /* 5 d^2 + 8 */,
+                        int32_t* status_dev, hipStream_t st) {
+  if (d < 32) {
+    hipLaunchKernelGGL(k_invsqrt, dim3(1), dim3(MDE_BLOCK), 0, st, d, C, out_scale, M, scratch, status_dev);
+    MDE_LAUNCH_CHECK();
+    return MDE_OK;
+  }
+  const int64_t m = (int64_t)d * d;
+  double* Y[2] = {scratch, scratch + 3 * m};
+  double* Z[2] = {scratch + m, scratch + 4 * m};
+  double* T = scratch + 2 * m;
+  double* ctl = scratch + 5 * m;         // 3 doubles
+  int* which = reinterpret_cast<int*>(ctl + 4);
+  MDE_HIP(hipMemsetAsync(which, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_ns_init, dim3(1), dim3(MDE_BLOCK), 0, st, d, C, Y[0], Z[0], ctl);
+  MDE_LAUNCH_CHECK();
+  const int nb = (int)((m + MDE_BLOCK - 1) / MDE_BLOCK);
+  // Near-orthonormal inputs (the solver's iterates) converge in < 10 steps; the 60 launched here
+  // cover condition numbers up to ~1e12.  The (Y, Z) pair alternates between two buffers (two
+  // steps per trip); once the state word leaves 0 the remaining launches return at once, and the
+  // device word `which` says which buffer holds the result.
+  for (int it = 0; it < 30; ++it) {
+    for (int h = 0; h < 2; ++h) {
+      hipLaunchKernelGGL(k_ns_t, dim3(nb), dim3(MDE_BLOCK), 0, st, d, Y[h], Z[h], T, ctl);
+      hipLaunchKernelGGL(k_ns_yz, dim3(nb), dim3(MDE_BLOCK), 0, st, d, Y[h], Z[h], T, Y[h ^ 1], Z[h ^ 1], ctl);
+      hipLaunchKernelGGL(k_ns_flag, dim3(1), dim3(1), 0, st, ctl, which);
+    }
+  }
+  MDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_ns_finish, dim3(mde_grid(m, MDE_BLOCK, 64)), dim3(MDE_BLOCK), 0, st, d, Z[0], Z[1], which, ctl,
+                     out_scale, M, status_dev);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
 // Z <- sqrt(n) (Z - mean) C^{-1/2},  C = (Z-mean)^T (Z-mean)          [ref: util.py:129-161]
 // (= sqrt(n) U V^T of the thin SVD Z - mean = U S V^T, the reference's formula.)
 extern "C" int mde_std_retract(int64_t n, int32_t d, float* Z, int32_t demean, double* work,
@@ -651,9 +833,8 @@ extern "C" int mde_std_retract(int64_t n, int32_t d, float* Z, int32_t demean, d
   double* scratch = mats + 2 * m;  // 5 m
   rc = gram_impl(n, d, d, Z, Z, C, work_partials(work, d), st);
   if (rc != MDE_OK) return rc;
-  hipLaunchKernelGGL(k_invsqrt, dim3(1), dim3(MDE_BLOCK), 0, st, d, C, sqrt((double)n), M, scratch,
-                     status_dev);
-  MDE_LAUNCH_CHECK();
+  rc = invsqrt_impl(d, C, sqrt((double)n), M, scratch, status_dev, st);
+  if (rc != MDE_OK) return rc;
   return rmul_impl(n, d, d, Z, M, 1.0f, nullptr, Z, st);
 }
 

@@ -379,6 +379,35 @@ def test_gram_mfma_and_generic_paths(da, db):
     np.testing.assert_allclose(out.cpu().numpy(), want.cpu().numpy(), rtol=2e-5, atol=2e-3)
 
 
+@pytest.mark.parametrize("d", [32, 64, 96, 128, 160, 40])
+def test_right_multiply_mfma_and_generic_paths(d):
+    """out = base + alpha A M: widths that are multiples of 32 (M <= 64 KB as fp32) take the f32
+    MFMA tile kernel, the others the generic one; also in place, as the projections use it."""
+    from pymde_amd import _lib
+    lib = _lib.load()
+    n = 4321
+    torch.manual_seed(2)
+    A = torch.randn((n, d), device=DEV)
+    base = torch.randn((n, d), device=DEV)
+    M = torch.randn((d, d), dtype=torch.float64, device=DEV) / np.sqrt(d)
+    want = (base.double() - 0.25 * (A.double() @ M)).cpu().numpy()
+    out = torch.empty((n, d), device=DEV)
+    _lib.check(lib.mde_right_multiply_add(n, d, d, _lib.ptr(A), _lib.ptr(M), -0.25, _lib.ptr(base),
+                                          _lib.ptr(out), _lib.stream_ptr()))
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    # in place on A (asymmetric M: a transposed operand mapping would fail here)
+    A2 = A.clone()
+    _lib.check(lib.mde_right_multiply(n, d, d, _lib.ptr(A2), _lib.ptr(M), _lib.ptr(A2), _lib.stream_ptr()))
+    np.testing.assert_allclose(A2.cpu().numpy(), (A.double() @ M).cpu().numpy(), rtol=1e-4, atol=1e-4)
+    # Standardized tangent projection Z - X (Z^T X) / n at this width
+    import pymde_amd
+    c = pymde_amd.Standardized()
+    X = c.project_onto_constraint(A, inplace=False)
+    T = c.project_onto_tangent_space(X, base, inplace=False).double().cpu().numpy()
+    Xd, Zd = X.double().cpu().numpy(), base.double().cpu().numpy()
+    np.testing.assert_allclose(T, Zd - Xd @ (Zd.T @ Xd) / n, rtol=1e-3, atol=2e-4)
+
+
 # ---------------------------------------------------------------- determinism and invariants
 def test_bitwise_reproducible_and_translation_invariant():
     import pymde_amd
