@@ -71,9 +71,21 @@ def test_trajectory_matches_reference(golden_trajectories, name):
     # iteration 0 is the plain evaluation at X0: tight
     assert s.average_distortions[0] == pytest.approx(E_ref[0, 0], rel=1e-5)
     assert s.residual_norms[0] == pytest.approx(R_ref[0, 0], rel=1e-4)
-    k = 3
+    # the first 5 iterations within rtol 1e-3 of the oracle run.  "The" oracle run does
+    # not exist -- six of the seven ensembles (12 reference runs from X0 perturbed by <= 1e-5)
+    # spread by 1e-2 .. 4e-1 already at iteration 1 -- so the tier is stated against a member:
+    # one reference run is followed for the first 5 iterations (measured on MI355X: every case
+    # follows its member for all 12 recorded iterations), and the run stays inside the envelope.
+    spread = (np.nanmax(E_ref, 0) - np.nanmin(E_ref, 0)) / np.abs(np.nanmean(E_ref, 0))
+    k = 5
     idx = _match_member(s.average_distortions, E_ref, k, 1e-3)
     assert idx is not None, (s.average_distortions[:k], E_ref[:, :k])
+    follow = k
+    while follow < min(E_ref.shape[1], len(s.average_distortions)) and \
+            _match_member(s.average_distortions, E_ref[idx:idx + 1], follow + 1, 1e-3) is not None:
+        follow += 1
+    print("trajectory %s: member %d of %d followed for %d iterations (ensemble spread > 1e-3 from iteration %d)"
+          % (name, idx, E_ref.shape[0], follow, int(np.argmax(spread > 1e-3)) if (spread > 1e-3).any() else -1))
     np.testing.assert_allclose(s.residual_norms[:k], R_ref[idx, :k], rtol=2e-3, atol=1e-6)
     np.testing.assert_allclose(s.step_size_percents[:k], S_ref[idx, :k], rtol=5e-3, atol=1e-5)
     m = min(E_ref.shape[1], len(s.average_distortions))
@@ -244,7 +256,7 @@ def test_spectral_initialiser(golden_spectral):
         want = g[key + "_emb"].astype(np.float64)
         Q, _ = np.linalg.qr(want)
         resid = emb - Q @ (Q.T @ emb)
-        assert np.linalg.norm(resid) / np.linalg.norm(emb) < 2e-2, key
+        assert np.linalg.norm(resid) / np.linalg.norm(emb) < 5e-3, key  # (the reference tests rtol 1e-3 per vector)
     import pymde_amd
     n, m = 400, 2
     mde = pymde_amd.MDE(n, m, torch.tensor(g["mid_edges"], device=DEV),

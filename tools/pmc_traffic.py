@@ -19,11 +19,12 @@ sys.path.insert(0, ROOT)
 
 
 def classify(name):
-    if "k_fused_ring" in name and "true" in name:
-        # k_fused_ring<D, Fn, HAS_GRAD, CB, LIN>
-        flags = name.split(">(")[0].rsplit(">", 1)[0].split(", ")[-3:]
-        if len(flags) == 3 and flags[0].strip() == "true":
-            return "ring_codebook" if flags[1].strip() == "true" else "ring_fp32"
+    if "k_fused_ring<" in name:
+        # k_fused_ring<D, Fn, HAS_GRAD, CB, LIN>(...)
+        targs = name.split("k_fused_ring<", 1)[1].split(">(", 1)[0]
+        flags = [t.strip() for t in targs.split(",")][-3:]
+        if len(flags) == 3 and flags[0] == "true":
+            return "ring_codebook" if flags[1] == "true" else "ring_fp32"
     if "k_fused_wide4" in name:
         return "wide4"
     if "k_fused_small" in name:
