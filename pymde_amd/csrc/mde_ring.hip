@@ -349,13 +349,11 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_stats(int64_t nit, const uin
   }
 }
 
-static int g_panel_mode = -2;  // MDE_PANEL env: -1 auto, 0 never, 1 whenever the layout is feasible
+// MDE_PANEL env: unset / -1 auto, 0 never, 1 whenever the layout is feasible (read at every layout
+// decision, so a test can switch it inside one process)
 static int panel_mode() {
-  if (g_panel_mode == -2) {
-    const char* e = getenv("MDE_PANEL");
-    g_panel_mode = e ? atoi(e) : -1;
-  }
-  return g_panel_mode;
+  const char* e = getenv("MDE_PANEL");
+  return e ? atoi(e) : -1;
 }
 
 static int bits_for_u64(uint64_t maxval) {

@@ -1,4 +1,4 @@
-"""Two ranks on one GPU (gloo): a sharded solve reproduces the single-process solve bit for bit."""
+"""Two ranks on one GPU (gloo): a sharded solve reproduces the single-process solve (bit for bit on the CSR kernel)."""
 import os
 import subprocess
 import sys
