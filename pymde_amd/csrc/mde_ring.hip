@@ -46,12 +46,14 @@
 #define MDE_RING_CTRL_PROG (MDE_RING_CTRL_OFF)        // int prog[16]: oldest chunk consumer w still reads
 #define MDE_RING_CTRL_F (MDE_RING_CTRL_OFF + 64)      // int F[2]: next chunk producer p has not landed
 #define MDE_RING_CTRL_CB (MDE_RING_CTRL_OFF + 96)     // float[8]: parameter codebook
-#define MDE_RING_NCW 14            // consumer waves
+#ifndef MDE_RING_NCW
+#define MDE_RING_NCW 12            // consumer waves (8..14 measured within 7 % of each other at config 4; 11-12 best)
+#endif
 #define MDE_RING_NPROD 2           // producer waves
 #ifndef MDE_RING_STAGE
 #define MDE_RING_STAGE 0            // 1: producers stage chunks through VGPRs (in flight in registers), 0: LDS-DMA
 #endif
-#define MDE_RING_BS 1024
+#define MDE_RING_BS (64 * (MDE_RING_NCW + MDE_RING_NPROD))
 #ifndef MDE_RING_DEPTH
 #define MDE_RING_DEPTH 2           // chunks in flight per producer (<= 3)
 #endif
@@ -1166,14 +1168,8 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
                   (int)(q < 3 ? hq[u][q + 1] : (has_next ? hq[(u + 1) % 3][0] : hq[u][q])));
               const float p0n = (a0_scalar || CB) ? a0s
                                 : (q < 3 ? wq[u][q + 1] : (has_next ? wq[(u + 1) % 3][0] : wq[u][q]));
-              // chunks of the next iteration already known to be resident: read ahead now;
-              // otherwise evaluate this iteration first and wait for them afterwards
-              const bool late = has_next && ((int)(hn & 0xffffu) + (int)((hn >> 16) & 15u) >= ready) && !(dbg & 1);
-              Pre nxt;
-              if (!late) {
-                if (has_next) sync_for(hn);
-                nxt = pre_read(wn, p0n);
-              }
+              if (has_next) sync_for(hn);
+              const Pre nxt = pre_read(wn, p0n);
               const float p1 = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q] : a1s;
               if (dbg & 4)
                 loss += __uint_as_float(pq[u][q]) * 0.0f + cur.xr[0] * 0.0f;
@@ -1181,10 +1177,6 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
                 process_slow(pq[u][q], cur, p1, (int)((h >> 20) & 63u));
               else
                 process_fast(pq[u][q], cur, p1);
-              if (late) {
-                sync_for(hn);
-                nxt = pre_read(wn, p0n);
-              }
               cur = nxt;
             }
           }
