@@ -129,7 +129,7 @@ typedef struct mde_func {
   float s0, s1, s2;  /* scalars of `kind`                                                 */
   float n0, n1, n2;  /* scalars of `kind_neg`                                             */
   int32_t layout;    /* order of a0/a1 for mde_average_distortion: 0 = CSR plan order,
-                        1 = column-panel order (mde_plan_layout / mde_plan_expand_layout)    */
+                        1 = LDS-ring order (mde_plan_layout / mde_plan_expand_layout)        */
 } mde_func;
 
 /* ------------------------------------------------------------------ the edge plan
@@ -172,17 +172,20 @@ int mde_shard_bounds(int64_t n, int64_t p, const int64_t* edges, int32_t world,
 int mde_plan_expand(const mde_plan* plan, const float* in_edge, float* out_half, void* stream);
 
 /* Layout the fused kernel prefers for embedding dimension d: 0 = the CSR order above,
- * 1 = LDS column panels (small d, embedding table larger than L2; built on first request, SYNC).
+ * 1 = the LDS-ring layout of mde_ring.hip (d <= 4, embedding table larger than L2: per-wave streams
+ * of packed half-edges, chunk-major; built on first request, SYNC).
  * Per-edge parameters for layout 1 are permuted with mde_plan_expand_layout and flagged with
  * mde_func.layout = 1.  Negative return: error. */
 int mde_plan_layout(mde_plan* plan, int32_t d, void* stream);
-/* Entries of a per-half-edge parameter array in `layout` (layout 1 pads every per-wave tile
- * slice to whole 64-entry wave iterations, so it is larger than mde_plan_half_edges). */
+/* Entries of a per-half-edge parameter array in `layout` (layout 1 stores whole 64-entry wave
+ * iterations, padded where a stream ends or its chunk window closes, so it is larger than
+ * mde_plan_half_edges). */
 int64_t mde_plan_layout_half_edges(const mde_plan* plan, int32_t layout);
-/* Parameter codebook for layout 1 at d = 2: when `in_edge` [p] holds at most 8 distinct values
+/* Parameter codebook for layout 1 at d = 2: when `in_edge` [p] holds at most 7 distinct values
  * (k-NN weights 1 / 2, -1 for repulsive pairs, ...) write to out_half
  * [mde_plan_layout_half_edges(plan, 1)] the packed half-edge words with the value index in their 3
- * low bits, followed by the 8-entry value table, and set *n_values_host to the number of values;
+ * low bits, followed by the 8-entry value table (entry 0 = 0.0, the weight of padding lanes;
+ * entries 1..7 the values in ascending bit order), and set *n_values_host to the number of values;
  * the fused kernel then streams 4 instead of 8 bytes per half-edge (mde_func.a0 = out_half,
  * a0_scalar = 2).  *n_values_host = 0: not applicable, nothing written -- use
  * mde_plan_expand_layout.  Results are identical either way.  SYNC. */

@@ -73,7 +73,7 @@ class EdgePlan(object):
         return self.row_lo == 0 and self.row_hi == self.n
 
     def expand(self, per_edge, layout=0):
-        """Permute a per-edge array [p] into plan order (layout 0: CSR, 1: column panels)."""
+        """Permute a per-edge array [p] into plan order (layout 0: CSR, 1: LDS ring)."""
         lib = _lib.load()
         t = per_edge.detach().to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
         if t.numel() != self.p:
@@ -88,7 +88,7 @@ class EdgePlan(object):
         return out
 
     def expand_codebook(self, per_edge):
-        """Layout 1 only: the codebook form of a per-edge array with at most 8 distinct values
+        """Layout 1 only: the codebook form of a per-edge array with at most 7 distinct values
         (``mde_plan_expand_codebook``), or None when it does not apply."""
         lib = _lib.load()
         t = per_edge.detach().to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
