@@ -86,3 +86,91 @@ def test_errors_match_the_reference():
         pymde_amd.MDE(3, 2, torch.tensor([[0, 1, 2]]), pymde_amd.penalties.Quadratic(torch.ones(1)), device=DEV)
     with pytest.raises((ValueError, RuntimeError)):
         pymde_amd.MDE(3, 2, torch.tensor([[0, 1]]), pymde_amd.penalties.Quadratic(torch.ones(1)), device="cpu")
+
+
+def test_graph_from_an_adjacency_matrix():
+    """pymde.Graph(adjacency_matrix) [ref: preprocess/graph.py:90-112]: dense numpy / torch and
+    scipy sparse inputs, inf = no edge, the upper triangle defines the edges, a non-zero diagonal
+    is an error with the reference's message."""
+    import scipy.sparse as sp
+    import pymde_amd
+    rng = np.random.default_rng(4)
+    n = 60
+    A = np.triu(rng.uniform(0.5, 3.0, (n, n)) * (rng.random((n, n)) < 0.15), 1)
+    A = A + A.T
+    A[3, 7] = A[7, 3] = np.inf                       # unreachable: dropped
+    want = pymde_amd.Graph.from_edges(torch.tensor(np.argwhere(np.triu(np.where(np.isinf(A), 0, A), 1) > 0)),
+                                      torch.tensor(A[np.triu(np.where(np.isinf(A), 0, A), 1) > 0].astype(np.float32)),
+                                      n_items=n, device=DEV)
+    for M in (A.copy(), torch.tensor(A), sp.csr_matrix(np.where(np.isinf(A), 0, A)), sp.coo_matrix(np.where(np.isinf(A), 0, A))):
+        g = pymde_amd.Graph(M, device=DEV)
+        assert g.n_items == n and g.n_edges == want.n_edges
+        assert torch.equal(g.edges, want.edges)
+        np.testing.assert_allclose(g.distances.cpu().numpy(), want.distances.cpu().numpy(), rtol=1e-6)
+        assert (g.edges[:, 0] < g.edges[:, 1]).all()
+    # a graph built this way goes through the recipes like one built from edges
+    mde = pymde_amd.preserve_distances(pymde_amd.Graph(A, device=DEV), embedding_dim=2)
+    assert mde.n_items == n
+    B = A.copy()
+    B[5, 5] = 1.0
+    with pytest.raises(ValueError, match="Adjacency matrices must not contain self edges"):
+        pymde_amd.Graph(np.where(np.isinf(B), 0, B), device=DEV)
+
+
+def test_default_n_neighbors_is_the_references(monkeypatch):
+    """recipes.py:318-321: about 1 % of all pairs, within [5, 15] -- k = 5 at n = 1000 (the 2 %-of-n
+    rule this package used before gave 15), 15 from n = 3001 on."""
+    import pymde_amd
+    from pymde_amd import preprocess
+    seen = []
+    real = preprocess.k_nearest_neighbors
+
+    def spy(data, k, **kw):
+        seen.append(int(k))
+        return real(data, k, **kw)
+    monkeypatch.setattr(preprocess, "k_nearest_neighbors", spy)
+    for n, want in ((1000, 5), (2001, 10), (4000, 15)):
+        data = torch.randn((n, 6), device=DEV)
+        pymde_amd.preserve_neighbors(data, embedding_dim=2, init="random")
+        assert seen[-1] == want, (n, seen[-1], want)
+        assert seen[-1] == int(max(min(15, (n * (n - 1) / 2) * 0.01 / n), 5))
+
+
+def test_push_and_pull_with_arbitrary_penalties_and_solver_limits():
+    import pymde_amd
+    from pymde_amd.functions.function import Function
+
+    class Sqrt(Function):          # no closed form in the kernels: a plain torch callable
+        def __init__(self, weights):
+            super(Sqrt, self).__init__()
+            self.weights = weights
+
+        def forward(self, distances):
+            return self.weights * torch.sqrt(distances + 1.0)
+
+    rng = np.random.default_rng(5)
+    n, p = 200, 1500
+    e = np.unique(np.sort(rng.integers(0, n, (p, 2)), 1), axis=0)
+    e = e[e[:, 0] != e[:, 1]]
+    w = torch.tensor(np.where(rng.random(len(e)) < 0.3, -1.0, 1.0).astype(np.float32), device=DEV)
+    f = pymde_amd.penalties.PushAndPull(w, Sqrt, pymde_amd.penalties.Log)
+    d = torch.tensor(rng.uniform(0.2, 2.0, len(e)).astype(np.float32), device=DEV)
+    got = f(d)
+    pos = w >= 0
+    np.testing.assert_allclose(got[pos].cpu().numpy(), (w[pos] * torch.sqrt(d[pos] + 1.0)).cpu().numpy(), rtol=1e-6)
+    np.testing.assert_allclose(got[~pos].cpu().numpy(),
+                               pymde_amd.penalties.Log(w[~pos])(d[~pos]).cpu().numpy(), rtol=1e-6)
+    # the MDE takes the unfused path with it
+    mde = pymde_amd.MDE(n, 2, torch.tensor(e, device=DEV), f)
+    X = torch.randn((n, 2), device=DEV, requires_grad=True)
+    E = mde.average_distortion(X)
+    E.backward()
+    assert torch.isfinite(E) and torch.isfinite(X.grad).all()
+    # the device-resident L-BFGS holds at most 63 pairs: a clear error instead of MDE_E_INVALID
+    with pytest.raises(ValueError, match="memory_size"):
+        mde.embed(max_iter=2, memory_size=64)
+    # a sharded problem cannot evaluate an arbitrary callable (each rank would add the full mean)
+    from pymde_amd import distributed
+    sh = distributed.ShardedMDE(n, 2, torch.tensor(e, device=DEV), f, device=DEV, rank=0, world_size=2)
+    with pytest.raises(NotImplementedError):
+        sh.embed(max_iter=2)
