@@ -187,6 +187,8 @@ def fused_evaluate(binding, X, grad_out, loss_out, grad_scale=1.0):
     lib = _lib.load()
     plan = binding.plan
     f = binding.struct(X.shape[1])
+    if X.data_ptr() & 15:
+        X = X.clone()  # (a view into a larger tensor: the kernels read rows with 16-byte loads)
     with torch.cuda.device(plan.device):
         _lib.check(lib.mde_average_distortion(
             plan.handle, _lib.ptr(X), X.shape[1], ctypes.byref(f), float(grad_scale),

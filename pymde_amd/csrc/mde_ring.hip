@@ -310,6 +310,37 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int3
       same += (rt == rl);
     }
     const int run = mde_wave_max(act ? same : 0);
+    // Lane placement.  With duplicate rows the entries stay sorted by row (the kernel folds
+    // adjacent lanes).  Without (the common case) the order is free, and it is chosen for the LDS:
+    // x_v, the accumulator read and the accumulator write of a lane all go to the bank pair
+    // (row mod 32) -- rows of one residue class are dealt alternately to the two 32-lane halves
+    // (and land in different 16-lane write groups), so two rows collide only when a class holds
+    // more than two of the 64.  (Sorted by row, the 32 rows of a half hit the 32 bank pairs like
+    // random draws: 3-4 deep on the fullest one, for each of the three accesses.)
+    if (run <= 1) {
+      const int key = act ? (((rl & 31) << 16) | rl) : 0x7fffffff;
+      int r2 = 0;
+      for (int t = 0; t < 64; ++t) {
+        const int kt = __builtin_amdgcn_readlane(key, t);
+        r2 += (kt < key) || (kt == key && t < lane);
+      }
+      // ranks 0, 1, 2, 3, ... -> lanes 0, 32, 1, 33, ...; padding (the highest ranks) fills what is left
+      if (act) rank = ((r2 & 1) << 5) | (r2 >> 1);
+    }
+    // lanes not taken by an entry hold the padding: with the interleaved placement they are no
+    // longer the highest lanes, so every lane finds its own slot
+    unsigned long long taken = 0;
+    for (int t = 0; t < 64; ++t) {
+      const int rt = __builtin_amdgcn_readlane(act ? rank : -1, t);
+      if (rt >= 0) taken |= 1ull << rt;
+    }
+    int pad_lane = -1;
+    if (!act) {
+      // the (lane - cnt)-th free lane
+      unsigned long long fr = ~taken;
+      for (int k = 0; k < lane - cnt; ++k) fr &= fr - 1;
+      pad_lane = __builtin_ctzll(fr);
+    }
     // chunk window of the iteration: the oldest chunk its stream still needs (deferred entries
     // included) .. the newest chunk it references (entries are in stream order, chunk-major)
     const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(it_m[it]);
@@ -323,9 +354,9 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int3
       peid[base + (size_t)rank * 4] = eid[q];
     } else {
       // padding: the dummy row slot, a resident column (first of chunk m)
-      packed[base + (size_t)lane * 4] =
+      packed[base + (size_t)pad_lane * 4] =
           (((uint32_t)R * 4u * (uint32_t)d) << 17) | ((m % (uint32_t)S) * (uint32_t)C * 4u * (uint32_t)d);
-      peid[base + (size_t)lane * 4] = -1;
+      peid[base + (size_t)pad_lane * 4] = -1;
     }
     if (lane == 0) hdr[it] = MDE_RING_HDR(m, need - m, max(0, min(run - 1, 63)), cnt < 64);
   }
@@ -1374,6 +1405,11 @@ int mde_ring_try(mde_plan* plan, const float* X, int d, const mde_func* f, float
     if (f->kind_neg == MDE_F_NONE) {
       if (f->kind == MDE_F_LOG1P && ea == 2) RING(FnSingle<MDE_F_LOG1P COMMA 2>, true);
       if (f->kind == MDE_F_QUADRATIC) RING(FnSingle<MDE_F_QUADRATIC COMMA 0>, true);
+      // the losses preserve_distances uses (deviations are per-edge targets, not weights: padding
+      // lanes are masked, LIN = false); the run-time functor is 6x the code of these
+      if (f->kind == MDE_F_L_QUADRATIC) RING(FnSingle<MDE_F_L_QUADRATIC COMMA 0>, false);
+      if (f->kind == MDE_F_L_ABSOLUTE) RING(FnSingle<MDE_F_L_ABSOLUTE COMMA 0>, false);
+      if (f->kind == MDE_F_L_HUBER) RING(FnSingle<MDE_F_L_HUBER COMMA 0>, false);
     } else if (f->kind == MDE_F_LOG1P && ea == 2) {
       if (f->kind_neg == MDE_F_LOG && en == 1)
         RING(FnPushPull<MDE_F_LOG1P COMMA 2 COMMA MDE_F_LOG COMMA 1>, true);
