@@ -1077,10 +1077,10 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       };
       int ready = j_lo, published = j_lo;
 
-      // One iteration ahead: while iteration k is evaluated, the LDS reads of iteration k + 1
-      // (x_v, x_u, codebook value) are already in flight into a second register set, and the
-      // accumulator read of iteration k is issued before its function evaluation -- an iteration
-      // waits for no LDS round trip of its own.
+      // the LDS operands of an iteration (x_v, x_u, parameter); the accumulator read of the fast
+      // path is issued right behind them, before the function is evaluated.  (Reading iteration
+      // k + 1 ahead of evaluating k, and evaluating two iterations together, were measured: no
+      // gain -- what they hide in latency they take from the ring's slack.)
       struct Pre {
         float xr[D], xc[D], p0;
       };
@@ -1176,86 +1176,24 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         }
       };
 
-      // two iterations without duplicate rows, evaluated together: their function evaluations
-      // are independent instruction streams the scheduler interleaves (a wave then tolerates twice
-      // the LDS / transcendental latency); the accumulator updates stay in program order because
-      // the second iteration may hold a row of the first (a deferred duplicate)
-      auto process_fast2 = [&](uint32_t wA, const Pre& xA, float p1A, uint32_t wB, const Pre& xB, float p1B)
-                               __attribute__((always_inline)) {
-        const uint32_t rowA = wA >> 17, rowB = wB >> 17;
-        float accA[D], vA[D], vB[D], ssA = 0.0f, ssB = 0.0f;
-        if (HAS_GRAD) ring_ld<D>(L + GR_OFF + rowA, accA);
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-          vA[c] = xA.xr[c] - xA.xc[c];
-          vB[c] = xB.xr[c] - xB.xc[c];
-          ssA = fmaf(vA[c], vA[c], ssA);
-          ssB = fmaf(vB[c], vB[c], ssB);
-        }
-        float fA, gdA, fB, gdB;
-        fn.eval(ssA, xA.p0, p1A, fA, gdA);
-        fn.eval(ssB, xB.p0, p1B, fB, gdB);
-        const float gA = mde_fix_g(gdA * inv_p), gB = mde_fix_g(gdB * inv_p);
-        loss += fA;
-        loss += fB;
-        if (!HAS_GRAD) return;
-#pragma unroll
-        for (int c = 0; c < D; ++c) accA[c] = fmaf(vA[c], gA, accA[c]);
-        ring_st<D>(L + GR_OFF + rowA, accA);
-        float accB[D];
-        ring_ld<D>(L + GR_OFF + rowB, accB);
-#pragma unroll
-        for (int c = 0; c < D; ++c) accB[c] = fmaf(vB[c], gB, accB[c]);
-        ring_st<D>(L + GR_OFF + rowB, accB);
-      };
-
-      Pre cur = {};
+      // one iteration at a time: hand-shake for its own chunks, read, evaluate, update
       for (int base = -3; base < NB; base += 3) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           const int b = base + u;
           if (b >= 0 && b < NB) {
-            if (b == 0) {
-              // the very first iteration has nobody to pre-read it
-              const uint32_t h0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)hq[u][0]);
-              sync_for(h0);
-              cur = pre_read(pq[u][0], (a0_scalar || CB) ? a0s : wq[u][0]);
-            }
 #pragma unroll
-            for (int q = 0; q < 4; q += 2) {
-              // iterations q (read ahead already: `cur`) and q + 1 of this block, then the one after
-              // them (q + 2, or the first of the next block; past the end of the stream: q + 1 again)
-              const uint32_t hA = (uint32_t)__builtin_amdgcn_readfirstlane((int)hq[u][q]);
-              const uint32_t hB = (uint32_t)__builtin_amdgcn_readfirstlane((int)hq[u][q + 1]);
-              const bool has_next = q < 2 || b + 1 < NB;
-              const uint32_t wC = q < 2 ? pq[u][q + 2] : (has_next ? pq[(u + 1) % 3][0] : pq[u][q + 1]);
-              const uint32_t hC = (uint32_t)__builtin_amdgcn_readfirstlane(
-                  (int)(q < 2 ? hq[u][q + 2] : (has_next ? hq[(u + 1) % 3][0] : hq[u][q + 1])));
-              const float p0B = (a0_scalar || CB) ? a0s : wq[u][q + 1];
-              const float p0C = (a0_scalar || CB) ? a0s
-                                : (q < 2 ? wq[u][q + 2] : (has_next ? wq[(u + 1) % 3][0] : wq[u][q + 1]));
-              sync_for(hB);
-              const Pre preB = pre_read(pq[u][q + 1], p0B);
-              if (has_next) sync_for(hC);
-              const Pre preC = pre_read(wC, p0C);
-              const size_t a1i = ((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q;
-              const float p1A = a1_arr ? a1[a1i] : a1s, p1B = a1_arr ? a1[a1i + 1] : a1s;
-              constexpr uint32_t SLOW = LIN ? 0x3fu : 0x7fu;
-              if (dbg & 4) {
-                loss += __uint_as_float(pq[u][q]) * 0.0f + cur.xr[0] * 0.0f + preB.xr[0] * 0.0f;
-              } else if ((((hA | hB) >> 20) & SLOW) == 0) {
-                process_fast2(pq[u][q], cur, p1A, pq[u][q + 1], preB, p1B);
-              } else {
-                if ((hA >> 20) & SLOW)
-                  process_slow(pq[u][q], cur, p1A, (int)((hA >> 20) & 63u));
-                else
-                  process_fast(pq[u][q], cur, p1A);
-                if ((hB >> 20) & SLOW)
-                  process_slow(pq[u][q + 1], preB, p1B, (int)((hB >> 20) & 63u));
-                else
-                  process_fast(pq[u][q + 1], preB, p1B);
-              }
-              cur = preC;
+            for (int q = 0; q < 4; ++q) {
+              const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)hq[u][q]);
+              sync_for(h);
+              const Pre x = pre_read(pq[u][q], (a0_scalar || CB) ? a0s : wq[u][q]);
+              const float p1 = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q] : a1s;
+              if (dbg & 4)
+                loss += __uint_as_float(pq[u][q]) * 0.0f + x.xr[0] * 0.0f;
+              else if ((h >> 20) & (LIN ? 0x3fu : 0x7fu))
+                process_slow(pq[u][q], x, p1, (int)((h >> 20) & 63u));
+              else
+                process_fast(pq[u][q], x, p1);
             }
           }
           load_block(u, b + 3);
