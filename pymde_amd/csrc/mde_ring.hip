@@ -70,7 +70,10 @@
 #define MDE_RING_DONE 0x7fffffff
 
 // chunk geometry per embedding dimension: CBYTES bytes (PIECES x 1 KiB DMA pieces) per chunk
-__host__ __device__ constexpr int ring_chunk_cols(int d) { return d == 1 ? 2048 : (d == 2 ? 1024 : 512); }
+#ifndef MDE_RING_C2
+#define MDE_RING_C2 1024
+#endif
+__host__ __device__ constexpr int ring_chunk_cols(int d) { return d == 1 ? 2048 : (d == 2 ? MDE_RING_C2 : 512); }
 __host__ __device__ constexpr int ring_chunk_bytes(int d) { return ring_chunk_cols(d) * 4 * d; }
 __host__ __device__ constexpr int ring_slots(int d) { return MDE_RING_BYTES / ring_chunk_bytes(d); }
 // an iteration may reference chunks m .. m + span, span <= S - NPROD * DEPTH: the producers keep
@@ -80,12 +83,14 @@ __host__ __device__ constexpr int ring_max_span(int d) {
   return MDE_RING_SPAN;
 #endif
   // (measured at config 4: 4..6 chunks of window leave the waves the most slack; 8 costs 4 %)
-  return MDE_RING_STAGE ? ring_slots(d) - MDE_RING_NPROD - 2 : ring_slots(d) - MDE_RING_NPROD * MDE_RING_DEPTH - 2;
+  return (MDE_RING_STAGE ? ring_slots(d) - MDE_RING_NPROD - 2 : ring_slots(d) - MDE_RING_NPROD * MDE_RING_DEPTH - 2) > 31
+             ? 31
+             : (MDE_RING_STAGE ? ring_slots(d) - MDE_RING_NPROD - 2 : ring_slots(d) - MDE_RING_NPROD * MDE_RING_DEPTH - 2);
 }
 
-// header word of a wave iteration: [15:0] m = lowest chunk referenced, [19:16] span (highest = m +
-// span), [25:20] DPP fold rounds (longest run of equal rows - 1), [26] the iteration has padding
-#define MDE_RING_HDR(m, span, rounds, pad) ((uint32_t)(m) | ((uint32_t)(span) << 16) | ((uint32_t)(rounds) << 20) | ((uint32_t)(pad) << 26))
+// header word of a wave iteration: [15:0] m = lowest chunk referenced, [20:16] span (highest = m +
+// span), [26:21] DPP fold rounds (longest run of equal rows - 1), [27] the iteration has padding
+#define MDE_RING_HDR(m, span, rounds, pad) ((uint32_t)(m) | ((uint32_t)(span) << 16) | ((uint32_t)(rounds) << 21) | ((uint32_t)(pad) << 27))
 
 // ---------------------------------------------------------------- layout construction
 // bounds[rb * (NCW + 1) + w]: consumer wave w of row block rb owns local rows [bounds[w],
@@ -368,9 +373,9 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_stats(int64_t nit, const uin
   unsigned long long a = 0, b = 0, c = 0;
   for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < nit; i += (int64_t)gridDim.x * MDE_BLOCK) {
     const uint32_t h = hdr[i];
-    a += ((h >> 20) & 63u) != 0;
-    b += (h >> 26) & 1u;
-    c += (h >> 20) & 63u;
+    a += ((h >> 21) & 63u) != 0;
+    b += (h >> 27) & 1u;
+    c += (h >> 21) & 63u;
   }
   a = mde_wave_sum(a);
   b = mde_wave_sum(b);
@@ -977,7 +982,9 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     int oldest = j;           // oldest chunk in flight (valid while infl > 0)
     // wait for the oldest chunk in flight and publish it (F[p] = my next chunk that has not landed)
     auto retire = [&]() __attribute__((always_inline)) {
-      if (infl == 3)
+      if (infl == 4)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * 3) : "memory");
+      else if (infl == 3)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * 2) : "memory");
       else if (infl == 2)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
@@ -987,7 +994,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       ring_ctrl_store(MDE_RING_CTRL_F + 4u * (uint32_t)p, oldest);
       --infl;
     };
-    static_assert(MDE_RING_DEPTH >= 1 && MDE_RING_DEPTH <= 3, "retire() spells out the wait counts of up to three chunks in flight");
+    static_assert(MDE_RING_DEPTH >= 1 && MDE_RING_DEPTH <= 4, "retire() spells out the wait counts of up to four chunks in flight");
     while (j < j_hi && !(dbg & 128)) {
       // slot j % S still holds chunk j - S until every consumer is past it
       if (j - S >= minprog && !(dbg & 8)) {
@@ -1013,8 +1020,11 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           // the LDS address together
           const char* src = Xl + (size_t)j * CBYTES;
 #if MDE_RING_DMA_IMM
-          ring_dma_pieces<4>(src, dst);
-          ring_dma_pieces<PIECES - 4>(src + 4096, dst + 4096u);
+          // (groups of four pieces; PIECES is 4..16)
+          ring_dma_pieces<(PIECES < 4 ? PIECES : 4)>(src, dst);
+          if constexpr (PIECES > 4) ring_dma_pieces<(PIECES - 4 < 4 ? PIECES - 4 : 4)>(src + 4096, dst + 4096u);
+          if constexpr (PIECES > 8) ring_dma_pieces<(PIECES - 8 < 4 ? PIECES - 8 : 4)>(src + 8192, dst + 8192u);
+          if constexpr (PIECES > 12) ring_dma_pieces<(PIECES - 12 < 4 ? PIECES - 12 : 4)>(src + 12288, dst + 12288u);
 #else
 #pragma unroll
           for (int k = 0; k < PIECES; ++k) ring_dma_pieces<1>(src + k * 1024, dst + (uint32_t)k * 1024u);
@@ -1159,7 +1169,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       // make the chunks of the iteration with header h resident (and tell the producers what
       // this wave no longer needs)
       auto sync_for = [&](uint32_t h) __attribute__((always_inline)) {
-        const int m = (int)(h & 0xffffu), need = m + (int)((h >> 16) & 15u);
+        const int m = (int)(h & 0xffffu), need = m + (int)((h >> 16) & 31u);
         if (m != published) {
           // (every read of chunks < m has been issued, and the LDS executes in order)
           ring_ctrl_store(MDE_RING_CTRL_PROG + 4u * (uint32_t)wave, m);
@@ -1190,8 +1200,8 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
               const float p1 = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q] : a1s;
               if (dbg & 4)
                 loss += __uint_as_float(pq[u][q]) * 0.0f + x.xr[0] * 0.0f;
-              else if ((h >> 20) & (LIN ? 0x3fu : 0x7fu))
-                process_slow(pq[u][q], x, p1, (int)((h >> 20) & 63u));
+              else if ((h >> 21) & (LIN ? 0x3fu : 0x7fu))
+                process_slow(pq[u][q], x, p1, (int)((h >> 21) & 63u));
               else
                 process_fast(pq[u][q], x, p1);
             }
