@@ -6,12 +6,12 @@
 // bound by the L2 request rate (~100 G/s from an 8 MB table: >= 1 ms for 10^8 half-edges whatever
 // the HBM rate).  Here every random access is served by LDS:
 //
-//   * a 1024-thread workgroup owns a block of R rows: their x_v and their fp32 gradient
+//   * a workgroup of 14 waves owns a block of R rows: their x_v and their fp32 gradient
 //     accumulators stay in LDS for the whole kernel (2 x 32 KB);
 //   * the embedding table streams through a ring of S chunk slots in the remaining 96 KB, filled
 //     by LDS-DMA (global_load_lds_dwordx4: L2 -> LDS, no VGPRs, no ds_write) by two producer
 //     waves;
-//   * the other 14 waves are consumers.  Each owns a fixed range of the block's rows and walks
+//   * the other 12 waves are consumers.  Each owns a fixed range of the block's rows and walks
 //     its own contiguous stream of packed half-edges (row address << 17 | ring offset, 4 bytes,
 //     chunk-major) -- because a row has exactly one wave that ever touches its accumulator, the
 //     update is a plain LDS read-add-write, the summation order is fixed by the layout (bitwise
@@ -25,9 +25,11 @@
 //     in barrier-separated phases.
 //   * LDS fp32 atomics would remove the one-writer rule, but ds_add_f32 retires ~0.16 lanes per
 //     clock per CU on gfx950 (tools/ldsprobe: 397 clocks for two of them per wave) -- 20x slower
-//     than read-add-write.  Duplicate rows inside a wave iteration (the 64 entries are sorted by
-//     row, so they are adjacent lanes) are folded with DPP wave shifts instead; the number of
-//     fold rounds of each iteration is known at build time and rides in its header word.
+//     than read-add-write.  The layout builder therefore keeps duplicate rows out of a wave
+//     iteration (an entry whose row is taken is deferred to the next iteration: 97 % of the
+//     iterations of a uniform-random graph are duplicate-free); where they remain (hub vertices)
+//     the 64 entries are sorted by row, equal rows are adjacent lanes and are folded with DPP wave
+//     shifts -- the number of fold rounds is known at build time and rides in the header word.
 #include <hipcub/hipcub.hpp>
 
 #include "mde_common.h"
@@ -50,9 +52,6 @@
 #define MDE_RING_NCW 12            // consumer waves (8..14 measured within 7 % of each other at config 4; 11-12 best)
 #endif
 #define MDE_RING_NPROD 2           // producer waves
-#ifndef MDE_RING_STAGE
-#define MDE_RING_STAGE 0            // 1: producers stage chunks through VGPRs (in flight in registers), 0: LDS-DMA
-#endif
 #define MDE_RING_BS (64 * (MDE_RING_NCW + MDE_RING_NPROD))
 #ifndef MDE_RING_DEPTH
 #define MDE_RING_DEPTH 2           // chunks in flight per producer (<= 3)
@@ -83,9 +82,7 @@ __host__ __device__ constexpr int ring_max_span(int d) {
   return MDE_RING_SPAN;
 #endif
   // (measured at config 4: 4..6 chunks of window leave the waves the most slack; 8 costs 4 %)
-  return (MDE_RING_STAGE ? ring_slots(d) - MDE_RING_NPROD - 2 : ring_slots(d) - MDE_RING_NPROD * MDE_RING_DEPTH - 2) > 31
-             ? 31
-             : (MDE_RING_STAGE ? ring_slots(d) - MDE_RING_NPROD - 2 : ring_slots(d) - MDE_RING_NPROD * MDE_RING_DEPTH - 2);
+  return ring_slots(d) - MDE_RING_NPROD * MDE_RING_DEPTH - 2 > 31 ? 31 : ring_slots(d) - MDE_RING_NPROD * MDE_RING_DEPTH - 2;
 }
 
 // header word of a wave iteration: [15:0] m = lowest chunk referenced, [20:16] span (highest = m +
@@ -915,67 +912,6 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     const char* Xl = Xb + lane * 16;
     const size_t nbytes = (size_t)n * D * 4;
     const size_t last16 = nbytes - 16;
-#if MDE_RING_STAGE
-    // Register-staged: three chunks per producer in flight in VGPRs (coalesced 16-byte loads),
-    // written to their ring slot once the slot is free.  Data in flight therefore occupies no
-    // LDS: the whole ring is window + slack for the consumers, which is what lets the waves
-    // drift (with LDS-DMA the in-flight chunks took half of the 12 slots and every wave ended up
-    // waiting for the slowest one chunk by chunk).
-    int minprog = j_lo;
-    ring_f4 bufA[PIECES], bufB[PIECES], bufC[PIECES];
-    const int j_last = j_hi - 1;
-    auto fetch = [&](ring_f4 (&buf)[PIECES], int j) __attribute__((always_inline)) {
-      const size_t off0 = (size_t)min(j, j_last) * CBYTES + (size_t)lane * 16;
-#pragma unroll
-      for (int k = 0; k < PIECES; ++k) {
-        const size_t off = off0 + (size_t)k * 1024;
-        buf[k] = *reinterpret_cast<const ring_f4*>(Xb + (off < last16 ? off : last16));
-      }
-    };
-    auto commit = [&](const ring_f4 (&buf)[PIECES], int j) __attribute__((always_inline)) {
-      if (j >= j_hi || (dbg & 128)) return;
-      // slot j % S still holds chunk j - S until every consumer is past it
-      while (j - S >= minprog && !(dbg & 8)) {
-        const int v = ring_ctrl_load(MDE_RING_CTRL_PROG + 4u * (uint32_t)(lane & 15));
-        int mn = __builtin_amdgcn_readlane(v, 0);
-#pragma unroll
-        for (int w = 1; w < NCW; ++w) mn = min(mn, __builtin_amdgcn_readlane(v, w));
-        minprog = mn;
-        if (j - S >= minprog) __builtin_amdgcn_s_sleep(1);
-      }
-      char* dst = L + RING_OFF + (j % S) * CBYTES + lane * 16;
-      if (!(dbg & 2)) {
-#pragma unroll
-        for (int k = 0; k < PIECES; ++k) *reinterpret_cast<ring_f4*>(dst + k * 1024) = buf[k];
-        // when the table is not a multiple of 16 bytes its final dwords are put in place by hand
-        // (the lane whose 16 bytes straddle the end loaded a clamped address)
-        if (j == NC - 1 && (nbytes & 15)) {
-          const size_t tail0 = nbytes & ~(size_t)15;
-          const int nt = (int)((nbytes - tail0) >> 2);
-          if (lane < nt)
-            *reinterpret_cast<float*>(L + RING_OFF + (j % S) * CBYTES + (tail0 + (size_t)lane * 4 - (size_t)j * CBYTES)) =
-                *reinterpret_cast<const float*>(Xb + tail0 + (size_t)lane * 4);
-        }
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      ring_ctrl_store(MDE_RING_CTRL_F + 4u * (uint32_t)p, j + NPROD);
-    };
-    {
-      const int j0 = j_lo + p;
-      fetch(bufA, j0);
-      fetch(bufB, j0 + NPROD);
-      fetch(bufC, j0 + 2 * NPROD);
-      for (int j = j0; j < j_hi; j += 3 * NPROD) {
-        commit(bufA, j);
-        fetch(bufA, j + 3 * NPROD);
-        commit(bufB, j + NPROD);
-        fetch(bufB, j + 4 * NPROD);
-        commit(bufC, j + 2 * NPROD);
-        fetch(bufC, j + 5 * NPROD);
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // (no counted load pending past the role's end)
-#else
     int minprog = j_lo, infl = 0;
     int slot = (j_lo + p) % S;
     int j = j_lo + p;         // next chunk to issue
@@ -998,7 +934,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     while (j < j_hi && !(dbg & 128)) {
       // slot j % S still holds chunk j - S until every consumer is past it
       if (j - S >= minprog && !(dbg & 8)) {
-        // one LDS read (lane w = consumer w), then a scalar minimum over the 14 lanes
+        // one LDS read (lane w = consumer w), then a scalar minimum over the consumers' lanes
         const int v = ring_ctrl_load(MDE_RING_CTRL_PROG + 4u * (uint32_t)(lane & 15));
         int mn = __builtin_amdgcn_readlane(v, 0);
 #pragma unroll
@@ -1028,7 +964,6 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
 #else
 #pragma unroll
           for (int k = 0; k < PIECES; ++k) ring_dma_pieces<1>(src + k * 1024, dst + (uint32_t)k * 1024u);
-#endif
         } else {
           // the table's last chunk: lanes whose 16 bytes would cross its end load a clamped address
           const size_t off0 = (size_t)j * CBYTES + (size_t)lane * 16;
