@@ -964,6 +964,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
 #else
 #pragma unroll
           for (int k = 0; k < PIECES; ++k) ring_dma_pieces<1>(src + k * 1024, dst + (uint32_t)k * 1024u);
+#endif
         } else {
           // the table's last chunk: lanes whose 16 bytes would cross its end load a clamped address
           const size_t off0 = (size_t)j * CBYTES + (size_t)lane * 16;
@@ -993,7 +994,6 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-#endif
     ring_ctrl_store(MDE_RING_CTRL_F + 4u * (uint32_t)p, MDE_RING_DONE);
   } else {
     // ---------------- consumer: my contiguous stream of wave iterations, 4 per block
