@@ -32,6 +32,9 @@
 //     shifts -- the number of fold rounds is known at build time and rides in the header word.
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
+#include <vector>
+
 #include "mde_common.h"
 #include "mde_functions.h"
 #include "mde_plan.h"
@@ -851,6 +854,9 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
 #else
   constexpr int dbg = 0;
 #endif
+#if MDE_RING_ABLATE
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+#endif
   constexpr int BS = MDE_RING_BS, NCW = MDE_RING_NCW, NPROD = MDE_RING_NPROD, PF = MDE_RING_PF;
   constexpr int GR_OFF = MDE_RING_GR_OFF, RING_OFF = MDE_RING_OFF;
   constexpr int C = ring_chunk_cols(D), CBYTES = ring_chunk_bytes(D), S = ring_slots(D), PIECES = CBYTES / 1024;
@@ -1151,6 +1157,13 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     __builtin_amdgcn_s_waitcnt(0x0F70);
   }
   __syncthreads();
+#if MDE_RING_ABLATE
+  if (tid == 0 && (dbg & 256)) {
+    // probe: when this workgroup started and how long its main phase took (s_memtime ticks)
+    loss_partials[1024 + blockIdx.x] = (double)(__builtin_readcyclecounter() - t_begin);
+    loss_partials[2048 + blockIdx.x] = (double)t_begin;
+  }
+#endif
   if (HAS_GRAD) {
     // Q == 1: the rows are final.  Q > 1: unscaled per-group partials, summed by k_ring_combine
     float* grow = (Q == 1) ? grad + (size_t)(row_lo + r0) * D : partial + ((size_t)qg * nloc + r0) * D;
@@ -1241,6 +1254,29 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
                      A.a1_scalar, A.X, A.grad, L.partial, A.plan->partials, fn, A.inv_p, A.grad_scale,
                      A.loss_out, A.loss_scale, getenv("MDE_RING_DBG") ? atoi(getenv("MDE_RING_DBG")) : 0);
   MDE_LAUNCH_CHECK();
+#if MDE_RING_ABLATE
+  if (getenv("MDE_RING_DBG") && (atoi(getenv("MDE_RING_DBG")) & 256)) {
+    static int printed = 0;
+    if (printed++ == 3) {
+      const int nb = L.n_row_blocks * Q;
+      std::vector<double> h(3072);
+      (void)hipStreamSynchronize(A.st);
+      (void)hipMemcpy(h.data(), A.plan->partials, 3072 * sizeof(double), hipMemcpyDeviceToHost);
+      double mn = 1e300, mx = 0, sum = 0, t0 = 1e300, t1 = 0;
+      for (int i = 0; i < nb && i < 1024; ++i) {
+        mn = std::min(mn, h[1024 + i]); mx = std::max(mx, h[1024 + i]); sum += h[1024 + i];
+        t0 = std::min(t0, h[2048 + i]); t1 = std::max(t1, h[2048 + i] + h[1024 + i]);
+      }
+      fprintf(stderr, "[mde ring] workgroup main-phase ticks: min %.0f mean %.0f max %.0f; first start -> last end %.0f (100 MHz ticks?)\n",
+              mn, sum / nb, mx, t1 - t0);
+      for (int x = 0; x < 8; ++x) {
+        double s8 = 0; int c8 = 0;
+        for (int i = x; i < nb && i < 1024; i += 8) { s8 += h[1024 + i]; ++c8; }
+        fprintf(stderr, "  XCD %d: mean %.0f\n", x, s8 / c8);
+      }
+    }
+  }
+#endif
   if (Q > 1 && A.grad) {
     const int64_t nlocD = (A.plan->row_hi - A.plan->row_lo) * (int64_t)D;
     hipLaunchKernelGGL(k_ring_combine, dim3(mde_grid(nlocD, MDE_BLOCK, 2048)), dim3(MDE_BLOCK), 0, A.st,
