@@ -1203,15 +1203,36 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
   }
 }
 
-// grad[row] = scale * sum_q partial[q][row]  (fixed order)
-__global__ __launch_bounds__(MDE_BLOCK) void k_ring_combine(int64_t nlocD, int Q, const float* __restrict__ partial,
-                                                            float scale, float* __restrict__ out) {
-  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < nlocD;
-       i += (int64_t)gridDim.x * MDE_BLOCK) {
-    float s = 0.0f;
-    for (int q = 0; q < Q; ++q) s += partial[(size_t)q * nlocD + i];
-    out[i] = s * scale;
+// grad[row] = scale * sum_q partial[q][row]  (q ascending).  V = float4 / float: one element per
+// thread, the first eight group loads in flight together
+template <class V>
+__global__ __launch_bounds__(MDE_BLOCK) void k_ring_combine(int64_t m, int Q, const V* __restrict__ partial,
+                                                            float scale, V* __restrict__ out) {
+  constexpr int W = sizeof(V) / sizeof(float);
+  const int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x;
+  if (i >= m) return;
+  V a[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (q < Q) a[q] = partial[(size_t)q * m + i];
+  float s[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) s[k] = reinterpret_cast<const float*>(&a[0])[k];
+#pragma unroll
+  for (int q = 1; q < 8; ++q)
+    if (q < Q) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) s[k] += reinterpret_cast<const float*>(&a[q])[k];
+    }
+  for (int q = 8; q < Q; ++q) {
+    const V t = partial[(size_t)q * m + i];
+#pragma unroll
+    for (int k = 0; k < W; ++k) s[k] += reinterpret_cast<const float*>(&t)[k];
   }
+  V r;
+#pragma unroll
+  for (int k = 0; k < W; ++k) reinterpret_cast<float*>(&r)[k] = s[k] * scale;
+  out[i] = r;
 }
 
 struct RingArgs {
@@ -1279,8 +1300,16 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
 #endif
   if (Q > 1 && A.grad) {
     const int64_t nlocD = (A.plan->row_hi - A.plan->row_lo) * (int64_t)D;
-    hipLaunchKernelGGL(k_ring_combine, dim3(mde_grid(nlocD, MDE_BLOCK, 2048)), dim3(MDE_BLOCK), 0, A.st,
-                       nlocD, Q, L.partial, A.grad_scale, A.grad + (size_t)A.plan->row_lo * D);
+    float* out = A.grad + (size_t)A.plan->row_lo * D;
+    if (nlocD % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+      const int64_t m = nlocD / 4;
+      hipLaunchKernelGGL(k_ring_combine<float4>, dim3((unsigned)((m + MDE_BLOCK - 1) / MDE_BLOCK)), dim3(MDE_BLOCK),
+                         0, A.st, m, Q, reinterpret_cast<const float4*>(L.partial), A.grad_scale,
+                         reinterpret_cast<float4*>(out));
+    } else {
+      hipLaunchKernelGGL(k_ring_combine<float>, dim3((unsigned)((nlocD + MDE_BLOCK - 1) / MDE_BLOCK)),
+                         dim3(MDE_BLOCK), 0, A.st, nlocD, Q, L.partial, A.grad_scale, out);
+    }
     MDE_LAUNCH_CHECK();
   }
   return MDE_OK;
