@@ -14,6 +14,7 @@
 // Each edge is visited from both endpoints, so its loss term is counted with weight 1/2.
 #include "mde_common.h"
 #include "mde_functions.h"
+#include "mde_plan.h"
 #define COMMA ,
 
 double* mde_plan_partials(mde_plan* p);
@@ -113,6 +114,192 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_small(
   }
   const double bs = mde_block_sum((double)loss, smem);
   if (threadIdx.x == 0) loss_partials[blockIdx.x] = bs;
+}
+
+// ---------------------------------------------------------------- small-d, edge-balanced
+// The row-per-group kernel above waits on three dependent memory hops per row (row pointer ->
+// neighbour -> x_u) and its waves run as long as their longest row: on graphs with hubs (k-NN
+// graphs, scale-free graphs) it is latency-bound (70 us for 2.9M half-edges).  Here a wave takes a
+// TILE of MDE_FLAT_T consecutive half-edge positions instead -- every load of the tile is issued
+// before the first use, whatever the rows look like -- and sums the contributions of equal rows
+// with a segmented scan across the lanes (rows are contiguous runs of positions).  A run that lies
+// inside the tile is a finished gradient row.  A row that crosses tile boundaries leaves one
+// record per tile (the tile's first run if the row began earlier, its last run if the row goes
+// on); k_flat_fixup adds the records of such a row in tile order.  Tiles are aligned to global
+// half-edge positions (phase = positions of the rows below row_lo, mod the tile), so a row is
+// summed by the same lanes in the same order whichever rank owns it: shards stay bit-equal to
+// the single-process result.  No atomics.
+template <int D, bool INDIRECT, class Fn>
+__global__ __launch_bounds__(MDE_BLOCK) void k_fused_flat(
+    int64_t H, int phase, int64_t n_tiles, int row_lo, const int32_t* __restrict__ hrow,
+    const int32_t* __restrict__ nbr, const int32_t* __restrict__ eid, const float* __restrict__ a0,
+    const float* __restrict__ a1, int a0_scalar, int a1_scalar, const float* __restrict__ X,
+    float* __restrict__ grad, float* __restrict__ rec, double* __restrict__ loss_partials, Fn fn,
+    float inv_p, float grad_scale) {
+  __shared__ double smem[8];
+  constexpr int U = MDE_FLAT_U;
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = ((int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x) >> 6;
+  const int64_t nwaves = ((int64_t)gridDim.x * MDE_BLOCK) >> 6;
+  const float a0s = a0_scalar ? a0[0] : 0.0f;
+  const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
+  float loss = 0.0f;
+  for (int64_t t = wave0; t < n_tiles; t += nwaves) {
+    const int64_t base = t * MDE_FLAT_T - phase;  // local position of the tile's first slot
+    int row[U], un[U];
+    float p0[U], p1[U];
+    bool ok[U];
+    // ---- every index / parameter load of the tile
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t h = base + u * 64 + lane;
+      ok[u] = h >= 0 && h < H;
+      const int64_t hc = ok[u] ? h : 0;
+      row[u] = ok[u] ? hrow[hc] : -1;
+      un[u] = nbr[hc];
+      p1[u] = a1s;
+      if constexpr (INDIRECT) {
+        const int k = eid[hc];
+        p0[u] = a0[k];
+        p1[u] = a1[k];
+      } else {
+        p0[u] = a0_scalar ? a0s : a0[hc];
+        if (a1 && !a1_scalar) p1[u] = a1[hc];
+      }
+    }
+    // rows of the positions just before and just after the tile: a first run with the former
+    // began earlier, a last run with the latter goes on
+    const int prev_row = base > 0 ? hrow[base - 1] : -1;
+    const int next_row = base + MDE_FLAT_T < H ? hrow[base + MDE_FLAT_T] : -1;
+    // ---- every gather of the tile
+    VecD<D> xv[U], xu[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      xv[u] = load_row<D>(X, (int64_t)row_lo + (ok[u] ? row[u] : 0));
+      xu[u] = load_row<D>(X, un[u]);
+    }
+    float c[U][D];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float ss = 0.0f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        c[u][k] = xv[u].v[k] - xu[u].v[k];
+        ss = fmaf(c[u][k], c[u][k], ss);
+      }
+      float f, gd;
+      fn.eval(ss, p0[u], p1[u], f, gd);
+      const float g = ok[u] ? mde_fix_g(gd * inv_p) : 0.0f;
+      loss += ok[u] ? f : 0.0f;
+#pragma unroll
+      for (int k = 0; k < D; ++k) c[u][k] *= g;
+    }
+    if (!grad) continue;
+    // ---- rows: segmented inclusive scan per wave iteration, carry from one iteration to the next
+    int carry_row = -1, first_row = -1, first_ends = 0;
+    float carry[D], first_tot[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) carry[k] = first_tot[k] = 0.0f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int key = row[u];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int k2 = __shfl_up(key, off, 64);
+        const bool same = lane >= off && k2 == key;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const float v2 = __shfl_up(c[u][k], off, 64);
+          c[u][k] += same ? v2 : 0.0f;
+        }
+      }
+      float tot[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) tot[k] = c[u][k] + (key == carry_row ? carry[k] : 0.0f);
+      // row of the next position: the lane above, or lane 0 of the next iteration / tile
+      int nxt = __shfl_down(key, 1, 64);
+      const int over = (u + 1 < U) ? __builtin_amdgcn_readlane(row[(u + 1 < U) ? u + 1 : u], 0) : next_row;
+      if (lane == 63) nxt = over;
+      const bool row_ends = key >= 0 && nxt != key;  // the row's last position
+      if (row_ends) {
+        if (key != prev_row) {
+          const int64_t v = (int64_t)row_lo + key;
+          if constexpr (D == 2) {
+            reinterpret_cast<float2*>(grad)[v] = make_float2(tot[0] * grad_scale, tot[1] * grad_scale);
+          } else if constexpr (D == 4) {
+            reinterpret_cast<float4*>(grad)[v] = make_float4(tot[0] * grad_scale, tot[1] * grad_scale,
+                                                             tot[2] * grad_scale, tot[3] * grad_scale);
+          } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) grad[v * D + k] = tot[k] * grad_scale;
+          }
+        }
+      }
+      // the run that began before the tile ends here: its record (at most one lane of the tile)
+      const unsigned long long m = __ballot(row_ends && key == prev_row);
+      if (m) {
+        const int src = __builtin_ctzll(m);
+        first_row = __builtin_amdgcn_readlane(key, src);
+        first_ends = 1;
+#pragma unroll
+        for (int k = 0; k < D; ++k) first_tot[k] = __shfl(tot[k], src, 64);
+      }
+      // lane 63's row goes on: carry its running sum into the next iteration (or out of the tile)
+      const int k63 = __builtin_amdgcn_readlane(key, 63);
+      carry_row = (k63 >= 0 && over == k63) ? k63 : -1;
+#pragma unroll
+      for (int k = 0; k < D; ++k) carry[k] = __shfl(tot[k], 63, 64);
+    }
+    if (lane == 0) {
+      // records: [first | last] x (row, ends, sum[4], -, -)
+      float* r0 = rec + (size_t)t * 16;
+      int last_row = -1;
+      if (carry_row >= 0) {
+        if (carry_row == prev_row) {  // the whole tile is one row that began earlier and goes on
+          first_row = carry_row;
+          first_ends = 0;
+#pragma unroll
+          for (int k = 0; k < D; ++k) first_tot[k] = carry[k];
+        } else {
+          last_row = carry_row;
+        }
+      }
+      reinterpret_cast<int*>(r0)[0] = first_row;
+      reinterpret_cast<int*>(r0)[1] = first_ends;
+      reinterpret_cast<int*>(r0)[8] = last_row;
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        r0[2 + k] = first_tot[k];
+        r0[10 + k] = carry[k];
+      }
+    }
+  }
+  const double bs = mde_block_sum((double)loss, smem);
+  if (threadIdx.x == 0) loss_partials[blockIdx.x] = bs;
+}
+
+// rows that cross tile boundaries: the tile in which such a row ends adds its records in tile order
+template <int D>
+__global__ __launch_bounds__(MDE_BLOCK) void k_flat_fixup(int64_t n_tiles, int phase, int row_lo,
+                                                          const int32_t* __restrict__ rowptr,
+                                                          const float* __restrict__ rec,
+                                                          float* __restrict__ grad, float grad_scale) {
+  const int64_t t = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x;
+  if (t >= n_tiles) return;
+  const float* rt = rec + (size_t)t * 16;
+  const int r = reinterpret_cast<const int*>(rt)[0];
+  if (r < 0 || reinterpret_cast<const int*>(rt)[1] == 0) return;
+  const int64_t ta = ((int64_t)rowptr[r] + phase) / MDE_FLAT_T;  // the tile the row begins in
+  float s[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) s[k] = rec[(size_t)ta * 16 + 10 + k];
+  for (int64_t q = ta + 1; q <= t; ++q) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) s[k] += rec[(size_t)q * 16 + 2 + k];
+  }
+  const int64_t v = (int64_t)row_lo + r;
+#pragma unroll
+  for (int k = 0; k < D; ++k) grad[v * D + k] = s[k] * grad_scale;
 }
 
 // ---------------------------------------------------------------- general-d fused kernel
@@ -420,8 +607,43 @@ static int launch_small_g(FusedArgs& A, const Fn& fn) {
   MDE_LAUNCH_CHECK();
   return MDE_OK;
 }
+// MDE_FLAT env: unset / 1 the edge-balanced kernel on sparse graphs, 2 always, 0 never (the row-per-group kernel)
+static int flat_mode() {
+  const char* e = getenv("MDE_FLAT");  // (read per call: a test can switch it inside one process)
+  return e ? atoi(e) : 1;
+}
+
+template <int D, bool IND, class Fn>
+static int launch_flat(FusedArgs& A, const Fn& fn) {
+  mde_plan* P = const_cast<mde_plan*>(A.plan);
+  int rc = mde_plan_flat(P, A.st);
+  if (rc != MDE_OK) return rc;
+  const int64_t nloc = P->row_hi - P->row_lo;
+  const int phase = (int)(P->h_offset % MDE_FLAT_T);
+  float* gloc = A.grad ? A.grad + (size_t)P->row_lo * D : nullptr;
+  if (A.grad && P->has_empty) MDE_HIP(hipMemsetAsync(gloc, 0, (size_t)nloc * D * sizeof(float), A.st));
+  const int nb = mde_grid(P->n_tiles * 64, MDE_BLOCK, 2048);
+  A.nblocks = nb;
+  hipLaunchKernelGGL((k_fused_flat<D, IND, Fn>), dim3(nb), dim3(MDE_BLOCK), 0, A.st, P->H, phase, P->n_tiles,
+                     (int)P->row_lo, P->hrow, P->nbr, P->eid, A.a0, A.a1, A.a0_scalar, A.a1_scalar, A.X, A.grad,
+                     P->flat_rec, A.partials, fn, A.inv_p, A.grad_scale);
+  MDE_LAUNCH_CHECK();
+  if (A.grad) {
+    hipLaunchKernelGGL(k_flat_fixup<D>, dim3((unsigned)((P->n_tiles + MDE_BLOCK - 1) / MDE_BLOCK)), dim3(MDE_BLOCK),
+                       0, A.st, P->n_tiles, phase, (int)P->row_lo, P->rowptr, P->flat_rec, A.grad, A.grad_scale);
+    MDE_LAUNCH_CHECK();
+  }
+  return MDE_OK;
+}
+
 template <int D, bool IND, class Fn>
 static int launch_small(FusedArgs& A, const Fn& fn) {
+  // sparse graphs (the usual case): edge-balanced tiles.  Dense problems (hundreds of half-edges
+  // per row on average, e.g. all-pairs distance graphs) keep a row per 32 / 64 lanes: enough loads
+  // in flight per row, and no segmented scan (config 3: 0.67 vs 0.77 ms per evaluation)
+  const int fm = flat_mode();
+  if (fm != 0 && A.plan->H > 0 && (fm == 2 || A.plan->avg_degree < 256.f))
+    return launch_flat<D, IND, Fn>(A, fn);
   switch (pick_group(mde_plan_avg_degree(A.plan))) {
     case 4: return launch_small_g<D, 4, IND, Fn>(A, fn);
     case 8: return launch_small_g<D, 8, IND, Fn>(A, fn);

@@ -28,4 +28,16 @@ struct mde_plan {
   double* partials = nullptr;  // [MDE_MAX_PARTIALS] loss partial sums of the fused kernel
   float avg_degree = 0.f;
   mde_ring_layout ring;        // empty until mde_plan_layout builds it
+  // Edge-balanced ("flat") schedule of the CSR kernel, built on first use (mde_plan_flat):
+  // tiles of MDE_FLAT_T consecutive half-edge positions, aligned to GLOBAL positions (h_offset =
+  // half-edges of the rows below row_lo), so a row is summed in the same order whoever owns it.
+  int64_t h_offset = 0;
+  int32_t* hrow = nullptr;     // [H] local row of each half-edge position
+  float* flat_rec = nullptr;   // [n_tiles][2][8] boundary runs of a tile: row, ends?, sum[<= 4]
+  int64_t n_tiles = 0;
+  int has_empty = 0;           // some row has no half-edge (its gradient row is zero-filled)
 };
+
+#define MDE_FLAT_U 4                    // wave iterations per tile
+#define MDE_FLAT_T (64 * MDE_FLAT_U)    // half-edge positions per tile (one wave)
+int mde_plan_flat(mde_plan* plan, hipStream_t st);  // mde_plan.hip

@@ -55,6 +55,8 @@ extern "C" int mde_plan_destroy(mde_plan* plan) {
   if (plan->nbr) (void)hipFree(plan->nbr);
   if (plan->eid) (void)hipFree(plan->eid);
   if (plan->partials) (void)hipFree(plan->partials);
+  if (plan->hrow) (void)hipFree(plan->hrow);
+  if (plan->flat_rec) (void)hipFree(plan->flat_rec);
   mde_ring_release(plan);
   delete plan;
   return MDE_OK;
@@ -117,6 +119,73 @@ __global__ void k_fill_half_edges(int64_t H, const uint32_t* __restrict__ vals,
     nbr[q] = (int32_t)u;
     eid[q] = (int32_t)k;
   }
+}
+
+// number of edge endpoints below row_lo = half-edges of the rows another rank owns before ours
+__global__ void k_count_below(int64_t p, const int64_t* __restrict__ edges, int64_t row_lo,
+                              unsigned long long* __restrict__ out) {
+  unsigned long long c = 0;
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < p;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const longlong2 e = reinterpret_cast<const longlong2*>(edges)[k];
+    c += (e.x < row_lo) + (e.y < row_lo);
+  }
+  c = mde_wave_sum(c);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+// hrow[h] = row whose [rowptr[r], rowptr[r + 1]) holds position h (binary search; one-time)
+__global__ void k_fill_hrow(int64_t H, int32_t nloc, const int32_t* __restrict__ rowptr,
+                            int32_t* __restrict__ hrow) {
+  for (int64_t h = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; h < H;
+       h += (int64_t)gridDim.x * blockDim.x) {
+    int32_t lo = 0, hi = nloc;  // invariant: rowptr[lo] <= h < rowptr[hi]
+    while (hi - lo > 1) {
+      const int32_t mid = lo + ((hi - lo) >> 1);
+      if (rowptr[mid] <= (int32_t)h) lo = mid; else hi = mid;
+    }
+    hrow[h] = lo;
+  }
+}
+__global__ void k_any_empty_row(int32_t nloc, const int32_t* __restrict__ rowptr, int* __restrict__ flag) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nloc;
+       r += (int64_t)gridDim.x * blockDim.x)
+    if (rowptr[r] == rowptr[r + 1]) *flag = 1;
+}
+
+// Build the flat schedule of the CSR kernel (idempotent).
+int mde_plan_flat(mde_plan* plan, hipStream_t st) {
+  if (plan->hrow || plan->H <= 0) return MDE_OK;
+  const int64_t nloc = plan->row_hi - plan->row_lo;
+  const int64_t phase = plan->h_offset % MDE_FLAT_T;
+  const int64_t nt = (plan->H + phase + MDE_FLAT_T - 1) / MDE_FLAT_T;
+  int32_t* hrow = nullptr;
+  float* rec = nullptr;
+  int* flag = reinterpret_cast<int*>(plan->partials + MDE_MAX_PARTIALS + 1);  // scratch word
+  int hflag = 0;
+  hipError_t e = hipMalloc(&hrow, (size_t)plan->H * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&rec, (size_t)nt * 16 * sizeof(float));
+  if (e == hipSuccess) e = hipMemsetAsync(flag, 0, sizeof(int), st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_fill_hrow, dim3(mde_grid(plan->H, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st, plan->H,
+                       (int32_t)nloc, plan->rowptr, hrow);
+    hipLaunchKernelGGL(k_any_empty_row, dim3(mde_grid(nloc, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, (int32_t)nloc,
+                       plan->rowptr, flag);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipMemsetAsync(flag, 0, sizeof(int), st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) {
+    if (hrow) (void)hipFree(hrow);
+    if (rec) (void)hipFree(rec);
+    return mde_hip_fail(e, "mde_plan_flat", __FILE__, __LINE__);
+  }
+  plan->hrow = hrow;
+  plan->flat_rec = rec;
+  plan->n_tiles = nt;
+  plan->has_empty = hflag;
+  return MDE_OK;
 }
 
 __global__ void k_degree(int64_t p, const int64_t* __restrict__ edges, int32_t* __restrict__ deg) {
@@ -271,6 +340,17 @@ extern "C" int mde_plan_create(int64_t n, int64_t p, const int64_t* edges, int64
   }
   plan->H = Hlocal;
   plan->avg_degree = nloc > 0 ? (float)((double)Hlocal / (double)nloc) : 0.f;
+  if (row_lo > 0 && p > 0) {
+    // global position of the first local half-edge (the flat schedule aligns its tiles to it)
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(plan->partials);
+    unsigned long long below = 0;
+    PLAN_HIP(hipMemsetAsync(cnt, 0, sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_count_below, dim3(mde_grid(p, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, p, edges, row_lo, cnt);
+    PLAN_HIP(hipGetLastError());
+    PLAN_HIP(hipMemcpyAsync(&below, cnt, sizeof(below), hipMemcpyDeviceToHost, st));
+    PLAN_HIP(hipStreamSynchronize(st));
+    plan->h_offset = (int64_t)below;
+  }
   const size_t hb = (size_t)(Hlocal > 0 ? Hlocal : 1) * sizeof(int32_t);
   PLAN_HIP(hipMalloc(&plan->nbr, hb));
   PLAN_HIP(hipMalloc(&plan->eid, hb));

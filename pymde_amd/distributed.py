@@ -23,9 +23,9 @@ from pymde_amd import average_distortion as _ad
 from pymde_amd import problem
 
 
-def all_reduce_grad_loss(buf, group=None):
+def all_reduce_grad_loss(buf, group=None, force=False):
     """Sum the ``[grad | loss]`` buffers of all ranks in place (the only data-path collective)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf
 
@@ -40,11 +40,14 @@ class GradExchange(object):
     verified against the all-reduce on its first use (bitwise, gradient) and silently replaced by it
     if the backend cannot run it or the results differ."""
 
-    def __init__(self, n, d, bounds, rank, world, group=None):
+    def __init__(self, n, d, bounds, rank, world, group=None, force=False):
         self.n, self.d, self.rank, self.world, self.group = int(n), int(d), int(rank), int(world), group
         self.bounds = [int(b) for b in bounds]
         sizes = [self.bounds[r + 1] - self.bounds[r] for r in range(world)]
-        self.uniform = world > 1 and len(set(sizes)) == 1
+        # force: issue the collectives even in a world of one (a single-GPU box can then run the
+        # RCCL calls themselves -- tests/test_gpu_rccl.py)
+        self.force = bool(force)
+        self.uniform = (world > 1 or self.force) and len(set(sizes)) == 1
         self.mode = None  # decided at the first exchange
         self._losses = None
 
@@ -68,13 +71,13 @@ class GradExchange(object):
         return self.mode != "all_gather"
 
     def __call__(self, buf):
-        if self.world <= 1 or not (dist.is_available() and dist.is_initialized()):
+        if (self.world <= 1 and not self.force) or not (dist.is_available() and dist.is_initialized()):
             return buf
         if self.mode is None:
             self.mode = "all_reduce"
             if self.uniform:
                 try:
-                    ref = all_reduce_grad_loss(buf.clone(), self.group)
+                    ref = all_reduce_grad_loss(buf.clone(), self.group, self.force)
                     got = self._gather(buf.clone())
                     N = self.n * self.d
                     same = torch.equal(got[:N], ref[:N]) and bool(
@@ -87,7 +90,7 @@ class GradExchange(object):
                     self.mode = "all_reduce"
         if self.mode == "all_gather":
             return self._gather(buf)
-        return all_reduce_grad_loss(buf, self.group)
+        return all_reduce_grad_loss(buf, self.group, self.force)
 
 
 def shard_range(bounds, rank):

@@ -203,9 +203,61 @@ assert np.abs(Xt.grad.cpu().numpy() - wg).max() < 1e-4 * np.abs(wg).max()
 print('ok')
 """ % (str(__import__("conftest").ROOT),)
     import os
-    env = dict(os.environ, MDE_GROUP=group)
+    env = dict(os.environ, MDE_GROUP=group, MDE_FLAT="0")  # (the row-per-group kernel, not the edge-balanced one)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4])
+def test_edge_balanced_kernel_on_skewed_graphs(d, monkeypatch):
+    """The edge-balanced CSR kernel (tiles of 256 half-edge positions, segmented row sums, records for
+    rows that cross tiles): hubs spanning a dozen tiles, isolated items, rows of one half-edge; against
+    the oracle, against the row-per-group kernel, and bit-equal across vertex-range shards (tiles are
+    aligned to global positions)."""
+    import pymde_amd
+    from pymde_amd import distributed
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    monkeypatch.setenv("MDE_PANEL", "0")
+    rng = np.random.default_rng(40 + d)
+    n = 5000
+    hubs = np.array([7, 2500, 4999])
+    parts = [np.stack([np.full(m, h), rng.choice(np.setdiff1d(np.arange(100, n - 100), hubs), m, replace=False)], 1)
+             for h, m in zip(hubs, (3100, 700, 257))]
+    body = rng.integers(100, n - 100, (12000, 2))        # items 8..99 and 4900..4998 stay isolated
+    body = body[body[:, 0] != body[:, 1]]
+    edges = np.unique(np.sort(np.concatenate(parts + [body]), 1), axis=0)
+    edges = edges[rng.permutation(len(edges))]
+    p = len(edges)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    w = np.where(rng.random(p) < 0.3, -1.0, rng.uniform(0.5, 2.0, p)).astype(np.float32)
+    et, Xt = torch.tensor(edges, device=DEV), torch.tensor(X, device=DEV)
+    for fd in (oracle.func("LOG1P", w, None, (1.5,), "LOG", (1.0,)), oracle.func("L_HUBER", np.abs(w), None, (0.5,))):
+        f = _make_function(fd)
+        wE, wgrad = oracle.average_distortion(edges, X, fd)
+        out = {}
+        for mode in ("2", "0"):
+            monkeypatch.setenv("MDE_FLAT", mode)
+            buf = torch.full((n * d + 1,), float("nan"), device=DEV)
+            fused_evaluate(Binding(EdgePlan(n, et), f), Xt, buf[:n * d].view(n, d), buf[n * d:])
+            out[mode] = buf.clone()
+            assert float(buf[n * d]) == pytest.approx(wE, rel=LOSS_RTOL), (d, fd["kind"], mode)
+            assert_grad_close(buf[:n * d].view(n, d).cpu().numpy(), wgrad)
+        assert float(out["2"][8 * d:100 * d].abs().sum()) == 0.0  # isolated items: zero rows, not stale memory
+        # the same launch twice: bitwise; three vertex-range shards: the rows they own, bitwise
+        monkeypatch.setenv("MDE_FLAT", "2")
+        again = torch.zeros(n * d + 1, device=DEV)
+        fused_evaluate(Binding(EdgePlan(n, et), f), Xt, again[:n * d].view(n, d), again[n * d:])
+        assert torch.equal(again, out["2"])
+        bounds = distributed.shard_bounds(n, et, 3)
+        total = torch.zeros(n * d + 1, device=DEV)
+        for r in range(3):
+            lo, hi = distributed.shard_range(bounds, r)
+            part = torch.zeros(n * d + 1, device=DEV)
+            fused_evaluate(Binding(EdgePlan(n, et, lo, hi), f), Xt, part[:n * d].view(n, d), part[n * d:])
+            assert float(part[:lo * d].abs().sum()) == 0 and float(part[hi * d:n * d].abs().sum()) == 0
+            total += part
+        assert torch.equal(total[:n * d], out["2"][:n * d]), (d, fd["kind"])
+        assert float(total[n * d]) == pytest.approx(wE, rel=LOSS_RTOL)
 
 
 def test_zero_distance_edges_contribute_nothing():
