@@ -48,8 +48,9 @@ ALG_BYTES_PER_EDGE = 8 + 4      # two int32 endpoints + one fp32 parameter  (SUR
 REFERENCE_TORCH_CPU = {"value": 5.57e6, "unit": "edges/s/iter", "cores": 8,
                        "where": "build container (8 vCPU Xeon 2.6 GHz, 8.98 s per evaluation), NOT the GPU box",
                        "source": "tools/ref_cpu_time.py, round 2 (the survey session's container measured 9.3e6)"}
-KERNEL_SOURCES = ["pymde_amd/csrc/mde_ring.hip", "pymde_amd/csrc/mde_distortion.hip",
-                  "pymde_amd/csrc/mde_functions.h"]
+# the files that define the measured kernel (k_fused_ring, its layout and its functors); the CSR
+# kernels of mde_distortion.hip are not what the PMC passes measure
+KERNEL_SOURCES = ["pymde_amd/csrc/mde_ring.hip", "pymde_amd/csrc/mde_functions.h"]
 
 
 def source_sha():

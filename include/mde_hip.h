@@ -305,7 +305,10 @@ int mde_row_scale(int64_t n, int32_t d, const float* scale, float* Z, void* stre
 /* out[v] = sum of the per-edge weights (plan / CSR order) over the half-edges of row v: the diagonal
  * of the graph Laplacian [ref: quadratic.py:47-68].  Rows outside the plan's range are untouched. */
 int mde_weighted_degree(const mde_plan* plan, const float* w_plan_order, float* out, void* stream);
-/* number of doubles of scratch the constraint / gram / vector calls need for width d */
+/* number of doubles of scratch the constraint / gram / vector calls need for width d.  ZERO the
+ * buffer once after allocating it: a few of its words are the arrival counters of the kernels that
+ * finish their reduction in the last workgroup (they are back at zero after every call).  One
+ * buffer serves one stream at a time. */
 int64_t mde_work_doubles(int32_t d);
 
 /* ------------------------------------------------------------------ vector kernels
@@ -350,6 +353,23 @@ int mde_lbfgs_dev_reset(mde_lbfgs* o, void* stream);
 int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, const float* d, float t,
                        float* d_out, double* stats, double* work, void* stream);
 int mde_lbfgs_dev_info(const mde_lbfgs* o, int32_t* count_host, int32_t* accepted_host, void* stream);
+
+/* ---- replaying an iteration's launch sequence as one HIP graph ------------------------------------
+ * [ref: the loop accelerated is optim.py:100-175 + lbfgs.py:390-590; the reference has no counterpart.]
+ * Between mde_capture_begin(stream) and mde_capture_end(stream, &c) every ASYNC entry point above
+ * called on `stream` is RECORDED instead of executed (HIP stream capture; `stream` must be a created
+ * stream, not the legacy default one, and no SYNC entry point may be called in between);
+ * mde_capture_launch replays the recorded kernels, memsets and copies with one launch -- same kernels,
+ * same arguments, same order, hence the same bits as calling the entry points again.
+ * mde_capture_abort leaves capture mode and discards what was recorded (error paths).
+ * mde_copy_to_host is the device -> pinned-host read-back to use inside a captured sequence. */
+typedef struct mde_capture mde_capture;
+int mde_capture_begin(void* stream);
+int mde_capture_end(void* stream, mde_capture** out);
+int mde_capture_abort(void* stream);
+int mde_capture_launch(mde_capture* c, void* stream);
+int mde_capture_destroy(mde_capture* c);
+int mde_copy_to_host(void* dst_host, const void* src_dev, int64_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -78,6 +78,69 @@ __device__ __forceinline__ double mde_block_sum(double v, double* smem /* >= 4 d
   }
   return r;
 }
+// Grid-wide "am I the last workgroup?" (the final reduction then needs no second launch).  The L2s of
+// the eight XCDs are not coherent with each other, and a device-scope fence (__threadfence) writes a
+// whole L2 back -- measured at ~8 us per kernel here.  So the partials are exchanged with device-scope
+// RELAXED atomic stores / loads instead (write-through / L2-bypassing accesses of just those words):
+// every block writes its partials with mde_st_partial, the barrier below waits for their completion,
+// thread 0 takes a ticket, and the one block that arrives last reads all partials with mde_ld_partial.
+// Returns true in every thread of that block.  `ticket` is zero between launches.
+__device__ __forceinline__ void mde_st_partial(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double mde_ld_partial(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool mde_last_block(unsigned int* ticket) {
+  __shared__ int mde_last_flag;
+  // every thread's partial stores must have completed before thread 0 takes the ticket (a
+  // workgroup-scope barrier alone does not wait for global stores when the workgroup sits on one CU)
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int v = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    mde_last_flag = (v == gridDim.x * gridDim.y - 1u) ? 1 : 0;
+    if (mde_last_flag) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return mde_last_flag != 0;
+}
+
+// Final reduction by the last workgroup (256 threads): out[q] = sum (or max, bit q of max_mask) over
+// b of partial[q * nb + b], q < nq.  A wave takes four rows at a time and issues all their loads
+// before the first use (the partials come from memory: one latency per batch, not per row); the
+// order of the additions is fixed.  Meant for a handful of rows and nb <= 256.
+__device__ __forceinline__ void mde_final_rows(int nq, int nb, const double* partial, double* out,
+                                               unsigned long long max_mask, double scale = 1.0) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  for (int q0 = wave; q0 < nq; q0 += 4 * nw) {
+    double acc[4];
+    bool is_max[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = q0 + r * nw;
+      is_max[r] = q < 64 && ((max_mask >> q) & 1ull);
+      acc[r] = is_max[r] ? -1.0e308 : 0.0;
+    }
+    for (int k = lane; k < nb; k += 64) {
+      double v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = q0 + r * nw;
+        v[r] = (q < nq) ? mde_ld_partial(partial + (int64_t)q * nb + k) : 0.0;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = is_max[r] ? (v[r] > acc[r] ? v[r] : acc[r]) : acc[r] + v[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int q = q0 + r * nw;
+      const double t = is_max[r] ? mde_wave_max(acc[r]) : mde_wave_sum(acc[r]);
+      if (lane == 0 && q < nq) out[q] = t * scale;
+    }
+  }
+}
+
 __device__ __forceinline__ double mde_block_max(double v, double* smem) {
   v = mde_wave_max(v);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;

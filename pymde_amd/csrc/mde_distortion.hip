@@ -279,11 +279,22 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_flat(
 }
 
 // rows that cross tile boundaries: the tile in which such a row ends adds its records in tile order
+// (its extra last workgroup adds the loss partials of the fused kernel: no third launch)
 template <int D>
 __global__ __launch_bounds__(MDE_BLOCK) void k_flat_fixup(int64_t n_tiles, int phase, int row_lo,
                                                           const int32_t* __restrict__ rowptr,
                                                           const float* __restrict__ rec,
-                                                          float* __restrict__ grad, float grad_scale) {
+                                                          float* __restrict__ grad, float grad_scale,
+                                                          const double* __restrict__ loss_partials, int nparts,
+                                                          double loss_scale, float* __restrict__ loss_out) {
+  if (loss_out && blockIdx.x == gridDim.x - 1) {
+    __shared__ double smem[8];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += MDE_BLOCK) s += loss_partials[i];
+    const double tot = mde_block_sum(s, smem);
+    if (threadIdx.x == 0) *loss_out = (float)(tot * loss_scale);
+    return;
+  }
   const int64_t t = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x;
   if (t >= n_tiles) return;
   const float* rt = rec + (size_t)t * 16;
@@ -575,6 +586,11 @@ struct FusedArgs {
   float inv_p, grad_scale;
   hipStream_t st;
   int nblocks;  // out
+  // in: where the loss goes (a kernel that has a follow-up launch anyway reduces it there and sets
+  // loss_done; otherwise mde_average_distortion launches k_finalize_loss)
+  float* loss_out = nullptr;
+  double loss_scale = 0.0;
+  int loss_done = 0;
 };
 
 static int g_group_override = 0;  // MDE_GROUP env (tuning experiments)
@@ -629,9 +645,12 @@ static int launch_flat(FusedArgs& A, const Fn& fn) {
                      P->flat_rec, A.partials, fn, A.inv_p, A.grad_scale);
   MDE_LAUNCH_CHECK();
   if (A.grad) {
-    hipLaunchKernelGGL(k_flat_fixup<D>, dim3((unsigned)((P->n_tiles + MDE_BLOCK - 1) / MDE_BLOCK)), dim3(MDE_BLOCK),
-                       0, A.st, P->n_tiles, phase, (int)P->row_lo, P->rowptr, P->flat_rec, A.grad, A.grad_scale);
+    const unsigned fb = (unsigned)((P->n_tiles + MDE_BLOCK - 1) / MDE_BLOCK);
+    hipLaunchKernelGGL(k_flat_fixup<D>, dim3(fb + (A.loss_out ? 1u : 0u)), dim3(MDE_BLOCK), 0, A.st, P->n_tiles, phase,
+                       (int)P->row_lo, P->rowptr, P->flat_rec, A.grad, A.grad_scale, A.partials, nb, A.loss_scale,
+                       A.loss_out);
     MDE_LAUNCH_CHECK();
+    if (A.loss_out) A.loss_done = 1;
   }
   return MDE_OK;
 }
@@ -806,11 +825,15 @@ extern "C" int mde_average_distortion(mde_plan* plan, const float* X, int32_t d,
     }
     return rc < 0 ? rc : MDE_OK;
   }
+  A.loss_out = loss_out;
+  A.loss_scale = scale;
   rc = dispatch_fused(A, f);
   if (rc != MDE_OK) return rc;
-  hipLaunchKernelGGL(k_finalize_loss, dim3(1), dim3(MDE_BLOCK), 0, A.st, A.partials, A.nblocks, scale,
-                     loss_out);
-  MDE_LAUNCH_CHECK();
+  if (!A.loss_done) {
+    hipLaunchKernelGGL(k_finalize_loss, dim3(1), dim3(MDE_BLOCK), 0, A.st, A.partials, A.nblocks, scale,
+                       loss_out);
+    MDE_LAUNCH_CHECK();
+  }
   return MDE_OK;
 }
 

@@ -22,6 +22,12 @@ extern "C" int64_t mde_work_doubles(int32_t d) {
   return MDE_SMALL_DOUBLES + 8 * dd * dd + MDE_PARTIAL_DOUBLES;
 }
 static inline double* work_mats(double* work) { return work + MDE_SMALL_DOUBLES; }
+// arrival counters of the kernels that finish their reduction in the last workgroup: the last 32
+// doubles of the small area (zero between launches; the caller zeroes the buffer once)
+enum { TK_STATS = 0, TK_GRAM = 1, TK_CENTER = 2, TK_LB_STAGE = 3, TK_LB_COMBINE = 4, TK_RETRACT = 5 };
+static inline unsigned int* work_ticket(double* work, int which) {
+  return reinterpret_cast<unsigned int*>(work + MDE_SMALL_DOUBLES - 32) + which;
+}
 static inline double* work_partials(double* work, int d) {
   return work + MDE_SMALL_DOUBLES + 8 * (int64_t)d * d;
 }
@@ -77,12 +83,34 @@ extern "C" int mde_axpy(int64_t N, float alpha, const float* x, const float* y, 
   return MDE_OK;
 }
 
+// eight block-wide reductions with two barriers: wave results to LDS, thread q < 8 combines the waves
+// and publishes partial[q * nb + b] (rows in max_mask: maxima)
+__device__ __forceinline__ void mde_publish8(const double (&v)[8], unsigned max_mask, double* partial, int nb, int b) {
+  __shared__ double sm8[MDE_BLOCK / 64][8];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const double r = ((max_mask >> q) & 1u) ? mde_wave_max(v[q]) : mde_wave_sum(v[q]);
+    if (lane == 0) sm8[wave][q] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int q = threadIdx.x;
+    double r = sm8[0][q];
+#pragma unroll
+    for (int w = 1; w < MDE_BLOCK / 64; ++w) r = ((max_mask >> q) & 1u) ? (sm8[w][q] > r ? sm8[w][q] : r) : r + sm8[w][q];
+    mde_st_partial(partial + q * nb + b, r);
+  }
+}
+
 // ---------------------------------------------------------------- vector statistics
 // partial[q * nb + b], q: 0 g.d 1 g.g 2 sum|g| 3 max|g| 4 #nonfinite 5 d.d 6 max|d| 7 x.x
 __global__ __launch_bounds__(MDE_BLOCK) void k_vec_stats(int64_t N, const float* __restrict__ g,
                                                          const float* __restrict__ d,
                                                          const float* __restrict__ x,
-                                                         double* __restrict__ partial) {
+                                                         double* __restrict__ partial,
+                                                         double* __restrict__ stats,
+                                                         unsigned int* __restrict__ ticket) {
   __shared__ double smem[8];
   double gd = 0, gg = 0, g1 = 0, gm = 0, nf = 0, dd = 0, dm = 0, xx = 0;
   for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N;
@@ -107,32 +135,18 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_vec_stats(int64_t N, const float*
     }
   }
   const int nb = gridDim.x, b = blockIdx.x;
-  double r;
-  r = mde_block_sum(gd, smem);
-  if (threadIdx.x == 0) partial[0 * nb + b] = r;
-  r = mde_block_sum(gg, smem);
-  if (threadIdx.x == 0) partial[1 * nb + b] = r;
-  r = mde_block_sum(g1, smem);
-  if (threadIdx.x == 0) partial[2 * nb + b] = r;
-  r = mde_block_max(gm, smem);
-  if (threadIdx.x == 0) partial[3 * nb + b] = r;
-  r = mde_block_sum(nf, smem);
-  if (threadIdx.x == 0) partial[4 * nb + b] = r;
-  r = mde_block_sum(dd, smem);
-  if (threadIdx.x == 0) partial[5 * nb + b] = r;
-  r = mde_block_max(dm, smem);
-  if (threadIdx.x == 0) partial[6 * nb + b] = r;
-  r = mde_block_sum(xx, smem);
-  if (threadIdx.x == 0) partial[7 * nb + b] = r;
+  const double v[8] = {gd, gg, g1, gm, nf, dd, dm, xx};
+  mde_publish8(v, (1u << 3) | (1u << 6), partial, nb, b);
+  // the last block to arrive reduces the partials (fixed order: independent of arrival order)
+  if (!mde_last_block(ticket)) return;
+  mde_final_rows(8, nb, partial, stats, (1ull << 3) | (1ull << 6));
 }
 
 static int vec_stats_impl(int64_t N, const float* g, const float* d, const float* x, double* stats,
-                          double* partial, hipStream_t st) {
-  const int nb = mde_grid(N, MDE_BLOCK * 4, MDE_RED_BLOCKS * 4);
-  hipLaunchKernelGGL(k_vec_stats, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, d, x, partial);
-  MDE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_reduce_rows, dim3(8), dim3(MDE_BLOCK), 0, st, 8, nb, partial,
-                     (1ull << 3) | (1ull << 6), stats);
+                          double* work, hipStream_t st) {
+  const int nb = mde_grid(N, MDE_BLOCK * 4, MDE_RED_BLOCKS);
+  hipLaunchKernelGGL(k_vec_stats, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, d, x, work + MDE_SMALL_DOUBLES, stats,
+                     work_ticket(work, TK_STATS));
   MDE_LAUNCH_CHECK();
   return MDE_OK;
 }
@@ -140,14 +154,15 @@ static int vec_stats_impl(int64_t N, const float* g, const float* d, const float
 extern "C" int mde_vec_stats(int64_t N, const float* g, const float* d, const float* x,
                              double* stats, double* work, void* stream) {
   if (N <= 0 || !g || !stats || !work) return MDE_E_INVALID;
-  return vec_stats_impl(N, g, d, x, stats, work + MDE_SMALL_DOUBLES, mde_stream(stream));
+  return vec_stats_impl(N, g, d, x, stats, work, mde_stream(stream));
 }
 
 // ---------------------------------------------------------------- column sums / centring
 // threads are laid out (rows_per_pass x dp), dp = pow2 >= min(d,256); coalesced over columns
 __global__ __launch_bounds__(MDE_BLOCK) void k_colsum(int64_t n, int d, int dp,
                                                       const float* __restrict__ Z,
-                                                      double* __restrict__ partial /* [nb][d] */) {
+                                                      double* __restrict__ partial /* [nb][d] */,
+                                                      double* __restrict__ mean, unsigned int* ticket) {
   __shared__ double sm[MDE_BLOCK];
   const int tc = threadIdx.x & (dp - 1);
   const int tr = threadIdx.x / dp;
@@ -164,19 +179,18 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_colsum(int64_t n, int d, int dp,
     if (tr == 0 && c < d) {
       double t = 0.0;
       for (int k = 0; k < rpp; ++k) t += sm[k * dp + tc];
-      partial[(int64_t)blockIdx.x * d + c] = t;
+      mde_st_partial(partial + (int64_t)blockIdx.x * d + c, t);
     }
   }
-}
-// mean[c] = (sum_b partial[b][c]) / n
-// (one wave per column: lane-strided partial sums + a fixed-order wave reduction)
-__global__ __launch_bounds__(64) void k_colsum_final(int nb, int d, int64_t n, const double* __restrict__ partial,
-                                                     double* __restrict__ mean) {
-  const int c = blockIdx.x;
-  double s = 0.0;
-  for (int b = threadIdx.x; b < nb; b += 64) s += partial[(int64_t)b * d + c];
-  s = mde_wave_sum(s);
-  if (threadIdx.x == 0) mean[c] = s / (double)n;
+  // the last workgroup to arrive turns the partial sums into the column means (fixed order)
+  if (!mde_last_block(ticket)) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nb = gridDim.x;
+  for (int c = wave; c < d; c += MDE_BLOCK / 64) {
+    double s = 0.0;
+    for (int b = lane; b < nb; b += 64) s += mde_ld_partial(partial + (int64_t)b * d + c);
+    s = mde_wave_sum(s);
+    if (lane == 0) mean[c] = s / (double)n;
+  }
 }
 __global__ __launch_bounds__(MDE_BLOCK) void k_sub_mean(int64_t N, int d, float* __restrict__ Z,
                                                         const double* __restrict__ mean) {
@@ -198,9 +212,8 @@ static int center_impl(int64_t n, int d, float* Z, double* work, hipStream_t st)
   if (dp > MDE_BLOCK) dp = MDE_BLOCK;
   const int rpp = MDE_BLOCK / dp;
   int nb = mde_grid(n, rpp * 8, MDE_RED_BLOCKS);
-  hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(MDE_BLOCK), 0, st, n, d, dp, Z, partial);
-  MDE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_colsum_final, dim3(d), dim3(64), 0, st, nb, d, n, partial, mean);
+  hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(MDE_BLOCK), 0, st, n, d, dp, Z, partial, mean,
+                     work_ticket(work, TK_CENTER));
   MDE_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sub_mean, dim3(mde_grid(n * d, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, n * d, d, Z,
                      mean);
@@ -238,7 +251,8 @@ extern "C" int mde_anchor_rows(int64_t n_anchors, int32_t d, const int64_t* anch
 template <int DA, int DB>
 __global__ __launch_bounds__(MDE_BLOCK) void k_gram_tiny(int64_t n, const float* __restrict__ A,
                                                          const float* __restrict__ B,
-                                                         double* __restrict__ partial /*[m][nb]*/) {
+                                                         double* __restrict__ partial /*[m][nb]*/,
+                                                         double* __restrict__ out, unsigned int* ticket) {
   __shared__ double smem[8];
   double acc[DA * DB];
 #pragma unroll
@@ -258,8 +272,11 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_gram_tiny(int64_t n, const float*
 #pragma unroll
   for (int q = 0; q < DA * DB; ++q) {
     const double r = mde_block_sum(acc[q], smem);
-    if (threadIdx.x == 0) partial[(int64_t)q * gridDim.x + blockIdx.x] = r;
+    if (threadIdx.x == 0) mde_st_partial(partial + (int64_t)q * gridDim.x + blockIdx.x, r);
   }
+  // the last workgroup to arrive adds the partials (one wave per entry, fixed order)
+  if (!mde_last_block(ticket)) return;
+  mde_final_rows(DA * DB, gridDim.x, partial, out, 0ull);
 }
 
 // (b) any widths: 16x16 output tile per block, rows split into chunks (grid.y)
@@ -340,7 +357,7 @@ __global__ void k_gram_final(int64_t m, int nc, const double* __restrict__ parti
 
 static int g_no_mfma = -1;
 static int gram_impl(int64_t n, int da, int db, const float* A, const float* B, double* out,
-                     double* partial, hipStream_t st) {
+                     double* partial, unsigned int* ticket, hipStream_t st) {
   const int64_t m = (int64_t)da * db;
   if (g_no_mfma < 0) {
     const char* e = getenv("MDE_NO_MFMA");
@@ -349,9 +366,8 @@ static int gram_impl(int64_t n, int da, int db, const float* A, const float* B, 
 #define TINY(DA_, DB_)                                                                              \
   if (da == DA_ && db == DB_) {                                                                     \
     const int nb = mde_grid(n, MDE_BLOCK * 2, MDE_RED_BLOCKS);                                      \
-    hipLaunchKernelGGL((k_gram_tiny<DA_, DB_>), dim3(nb), dim3(MDE_BLOCK), 0, st, n, A, B, partial); \
-    MDE_LAUNCH_CHECK();                                                                             \
-    hipLaunchKernelGGL(k_gram_final_wave, dim3((unsigned)m), dim3(64), 0, st, nb, partial, out);    \
+    hipLaunchKernelGGL((k_gram_tiny<DA_, DB_>), dim3(nb), dim3(MDE_BLOCK), 0, st, n, A, B, partial,  \
+                       out, ticket);                                                                \
     MDE_LAUNCH_CHECK();                                                                             \
     return MDE_OK;                                                                                  \
   }
@@ -401,7 +417,7 @@ extern "C" int mde_gram(int64_t n, int32_t da, int32_t db, const float* A, const
                         double* work, void* stream) {
   if (n <= 0 || da <= 0 || db <= 0 || !A || !B || !out || !work) return MDE_E_INVALID;
   const int dm = da > db ? da : db;
-  return gram_impl(n, da, db, A, B, out, work_partials(work, dm), mde_stream(stream));
+  return gram_impl(n, da, db, A, B, out, work_partials(work, dm), work_ticket(work, TK_GRAM), mde_stream(stream));
 }
 
 // ---------------------------------------------------------------- Z (+)= alpha * A M
@@ -578,7 +594,7 @@ extern "C" int mde_std_tangent(int64_t n, int32_t d, const float* X, float* Z, d
   if (n <= 0 || d <= 0 || d > 2048 || !X || !Z || !work) return MDE_E_INVALID;
   hipStream_t st = mde_stream(stream);
   double* G = work_mats(work);  // d x d : G[i][j] = sum_r Z[r][i] X[r][j]
-  int rc = gram_impl(n, d, d, Z, X, G, work_partials(work, d), st);
+  int rc = gram_impl(n, d, d, Z, X, G, work_partials(work, d), work_ticket(work, TK_GRAM), st);
   if (rc != MDE_OK) return rc;
   return rmul_impl(n, d, d, X, G, (float)(-1.0 / (double)n), Z, Z, st);
 }
@@ -587,10 +603,10 @@ extern "C" int mde_std_tangent(int64_t n, int32_t d, const float* X, float* Z, d
 // One workgroup.  d = 1, 2: closed form.  d >= 3: coupled Newton-Schulz iteration in double
 //   Y0 = C/s, Z0 = I;  T = (3I - Z Y)/2;  Y <- Y T;  Z <- T Z;   Z -> (C/s)^{-1/2}
 // with s = ||C||_F.  M = out_scale * C^{-1/2}.  status != 0: C not numerically SPD.
-__global__ __launch_bounds__(MDE_BLOCK) void k_invsqrt(int d, const double* __restrict__ C,
-                                                       double out_scale, double* __restrict__ M,
-                                                       double* __restrict__ scratch /* 5 d^2 */,
-                                                       int32_t* __restrict__ status) {
+// (a device function of one 256-thread workgroup: also called by the last workgroup of the fused
+// small-d retraction kernel, right after it has written C -- hence no __restrict__ / read-only loads)
+__device__ void invsqrt_block(int d, const double* C, double out_scale, double* M,
+                              double* scratch /* 5 d^2 */, int32_t* status) {
   __shared__ double smem[8];
   __shared__ double sh_val;
   __shared__ int sh_done;
@@ -687,6 +703,86 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_invsqrt(int d, const double* __re
   const double k = out_scale / sqrt(s);
   for (int i = tid; i < m; i += MDE_BLOCK) M[i] = converged ? Z[i] * k : 0.0;
   if (tid == 0 && status && !converged) *status = 1;
+}
+__global__ __launch_bounds__(MDE_BLOCK) void k_invsqrt(int d, const double* C, double out_scale, double* M,
+                                                       double* scratch /* 5 d^2 */, int32_t* status) {
+  invsqrt_block(d, C, out_scale, M, scratch, status);
+}
+
+// ---------------------------------------------------------------- small-d retraction in two launches
+// Z <- sqrt(n) (Z - mean) C^{-1/2} for d <= 4.  One pass accumulates the column sums and the RAW
+// Gram matrix Z^T Z in double; the last workgroup to arrive forms mean, C = Z^T Z - n mean mean^T
+// (the Gram matrix of the centred rows) and out_scale C^{-1/2}; k_center_rmul_tiny then applies
+// both.  (Seven launches -- column sums, their reduction, the subtraction, Gram, its reduction,
+// the inverse square root, the multiply -- when composed from the general-d pieces.)
+template <int D>
+__global__ __launch_bounds__(MDE_BLOCK) void k_retract_stats_tiny(int64_t n, const float* __restrict__ Z,
+                                                                  int demean, double out_scale,
+                                                                  double* partial /* [D*D + D][nb] */,
+                                                                  double* mean /* D */, double* C, double* M,
+                                                                  double* scratch, int32_t* status,
+                                                                  unsigned int* ticket) {
+  __shared__ double smem[8];
+  constexpr int NQ = D * D + D;
+  double acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
+  for (int64_t r = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * MDE_BLOCK) {
+    double a[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) a[i] = Z[r * D + i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      acc[D * D + i] += a[i];
+#pragma unroll
+      for (int j = 0; j < D; ++j) acc[i * D + j] = fma(a[i], a[j], acc[i * D + j]);
+    }
+  }
+  const int nb = gridDim.x;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const double r = mde_block_sum(acc[q], smem);
+    if (threadIdx.x == 0) mde_st_partial(partial + (int64_t)q * nb + blockIdx.x, r);
+  }
+  if (!mde_last_block(ticket)) return;
+  __shared__ double tot[NQ];
+  mde_final_rows(NQ, nb, partial, tot, 0ull);
+  __syncthreads();
+  if (threadIdx.x < D * D) {
+    const int i = threadIdx.x / D, j = threadIdx.x % D;
+    const double mi = demean ? tot[D * D + i] / (double)n : 0.0;
+    const double mj = demean ? tot[D * D + j] / (double)n : 0.0;
+    C[threadIdx.x] = tot[threadIdx.x] - (double)n * mi * mj;
+    if (j == 0) mean[i] = mi;
+  }
+  __threadfence_block();
+  __syncthreads();
+  invsqrt_block(D, C, out_scale, M, scratch, status);
+}
+
+template <int D>
+__global__ __launch_bounds__(MDE_BLOCK) void k_center_rmul_tiny(int64_t n, const double* __restrict__ mean,
+                                                                const double* __restrict__ M,
+                                                                float* __restrict__ Z) {
+  double mu[D];
+  float m[D * D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) mu[i] = mean[i];
+#pragma unroll
+  for (int i = 0; i < D * D; ++i) m[i] = (float)M[i];
+  for (int64_t r = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * MDE_BLOCK) {
+    float a[D], o[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) a[c] = (float)((double)Z[r * D + c] - mu[c]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) o[j] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+#pragma unroll
+      for (int j = 0; j < D; ++j) o[j] = fmaf(a[c], m[c * D + j], o[j]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) Z[r * D + j] = o[j];
+  }
 }
 
 
@@ -822,16 +918,33 @@ extern "C" int mde_std_retract(int64_t n, int32_t d, float* Z, int32_t demean, d
   if (n <= 0 || d <= 0 || d > 2048 || !Z || !work) return MDE_E_INVALID;
   hipStream_t st = mde_stream(stream);
   int rc = MDE_OK;
-  if (demean) {
-    rc = center_impl(n, d, Z, work, st);
-    if (rc != MDE_OK) return rc;
-  }
   double* mats = work_mats(work);
   const int64_t m = (int64_t)d * d;
   double* C = mats;
   double* M = mats + m;
   double* scratch = mats + 2 * m;  // 5 m
-  rc = gram_impl(n, d, d, Z, Z, C, work_partials(work, d), st);
+  if (d <= 4) {
+    const int nb = mde_grid(n, MDE_BLOCK * 2, MDE_RED_BLOCKS);
+    const int nb2 = mde_grid(n, MDE_BLOCK, 2048);
+    double* mean = work;  // small area
+#define TINY(D_)                                                                                             \
+  if (d == D_) {                                                                                             \
+    hipLaunchKernelGGL(k_retract_stats_tiny<D_>, dim3(nb), dim3(MDE_BLOCK), 0, st, n, Z, (int)demean,        \
+                       sqrt((double)n), work_partials(work, d), mean, C, M, scratch, status_dev,             \
+                       work_ticket(work, TK_RETRACT));                                                       \
+    MDE_LAUNCH_CHECK();                                                                                      \
+    hipLaunchKernelGGL(k_center_rmul_tiny<D_>, dim3(nb2), dim3(MDE_BLOCK), 0, st, n, mean, M, Z);             \
+    MDE_LAUNCH_CHECK();                                                                                      \
+    return MDE_OK;                                                                                           \
+  }
+    TINY(1) TINY(2) TINY(3) TINY(4)
+#undef TINY
+  }
+  if (demean) {
+    rc = center_impl(n, d, Z, work, st);
+    if (rc != MDE_OK) return rc;
+  }
+  rc = gram_impl(n, d, d, Z, Z, C, work_partials(work, d), work_ticket(work, TK_GRAM), st);
   if (rc != MDE_OK) return rc;
   rc = invsqrt_impl(d, C, sqrt((double)n), M, scratch, status_dev, st);
   if (rc != MDE_OK) return rc;
@@ -1062,99 +1175,6 @@ __global__ void k_lbfgs_dev_reset(LbDev* __restrict__ dv, int history) {
   }
 }
 
-template <bool FIRST>
-__global__ __launch_bounds__(MDE_BLOCK) void k_lbfgs_stage_dev(int64_t N, const float* __restrict__ g,
-                                                               float* __restrict__ g_prev,
-                                                               const float* __restrict__ d, float t,
-                                                               float* __restrict__ buf,
-                                                               const LbDev* __restrict__ dv, int done,
-                                                               double* __restrict__ partial) {
-  __shared__ double smem[8];
-  const int count = dv->count;
-  if (!FIRST && done >= count) return;
-  int pc = count - done;
-  if (pc > MDE_LB_GROUP) pc = MDE_LB_GROUP;
-  if (pc < 0) pc = 0;
-  const int spare = dv->order[count];
-  float* s_new = buf + (int64_t)(2 * spare) * N;
-  float* y_new = buf + (int64_t)(2 * spare + 1) * N;
-  const float* ps[MDE_LB_GROUP];
-  const float* py[MDE_LB_GROUP];
-#pragma unroll
-  for (int j = 0; j < MDE_LB_GROUP; ++j) {
-    const int slot = (j < pc) ? dv->order[done + j] : spare;
-    ps[j] = buf + (int64_t)(2 * slot) * N;
-    py[j] = buf + (int64_t)(2 * slot + 1) * N;
-  }
-  double base[4] = {0, 0, 0, 0};
-  double acc[MDE_LB_GROUP][5];
-#pragma unroll
-  for (int j = 0; j < MDE_LB_GROUP; ++j)
-#pragma unroll
-    for (int q = 0; q < 5; ++q) acc[j][q] = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N;
-       i += (int64_t)gridDim.x * MDE_BLOCK) {
-    const float gv = g[i];
-    float yv, sv;
-    if constexpr (FIRST) {
-      yv = gv - g_prev[i];
-      sv = t * d[i];
-      y_new[i] = yv;
-      s_new[i] = sv;
-      g_prev[i] = gv;
-      base[0] = fma((double)yv, (double)sv, base[0]);
-      base[1] = fma((double)yv, (double)yv, base[1]);
-      base[2] = fma((double)sv, (double)gv, base[2]);
-      base[3] = fma((double)yv, (double)gv, base[3]);
-    } else {
-      yv = y_new[i];
-      sv = s_new[i];
-    }
-#pragma unroll
-    for (int j = 0; j < MDE_LB_GROUP; ++j) {
-      if (j < pc) {
-        const double sj = ps[j][i], yj = py[j][i];
-        acc[j][0] = fma(sj, (double)yv, acc[j][0]);  // s_j . y*
-        acc[j][1] = fma(yj, (double)yv, acc[j][1]);  // y_j . y*
-        acc[j][2] = fma((double)sv, yj, acc[j][2]);  // s* . y_j
-        acc[j][3] = fma(sj, (double)gv, acc[j][3]);  // s_j . g
-        acc[j][4] = fma(yj, (double)gv, acc[j][4]);  // y_j . g
-      }
-    }
-  }
-  const int nb = gridDim.x, b = blockIdx.x;
-  if constexpr (FIRST) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const double r = mde_block_sum(base[q], smem);
-      if (threadIdx.x == 0) partial[(int64_t)q * nb + b] = r;
-    }
-  }
-  const int qbase = 4 + 5 * done;
-#pragma unroll
-  for (int j = 0; j < MDE_LB_GROUP; ++j) {
-    if (j < pc) {
-#pragma unroll
-      for (int q = 0; q < 5; ++q) {
-        const double r = mde_block_sum(acc[j][q], smem);
-        if (threadIdx.x == 0) partial[(int64_t)(qbase + 5 * j + q) * nb + b] = r;
-      }
-    }
-  }
-}
-
-// dots[q] = sum_b partial[q * nb + b] for the 4 + 5 count rows that were written
-__global__ void k_lbfgs_reduce_dev(int nb, const double* __restrict__ partial, const LbDev* __restrict__ dv,
-                                   double* __restrict__ dots) {
-  __shared__ double smem[8];
-  const int q = blockIdx.x;
-  if (q >= 4 + 5 * dv->count) return;
-  double s = 0.0;
-  for (int b = threadIdx.x; b < nb; b += blockDim.x) s += partial[(int64_t)q * nb + b];
-  const double r = mde_block_sum(s, smem);
-  if (threadIdx.x == 0) dots[q] = r;
-}
-
 // One wave.  Lane j owns column j of everything; the Gram matrices sit in LDS while they are edited.
 __global__ __launch_bounds__(64) void k_lbfgs_direction(LbDev* __restrict__ dv, const double* __restrict__ dots,
                                                         int history) {
@@ -1264,36 +1284,166 @@ __global__ __launch_bounds__(64) void k_lbfgs_direction(LbDev* __restrict__ dv, 
   }
 }
 
-template <bool FIRST>
-__global__ __launch_bounds__(MDE_BLOCK) void k_lbfgs_combine_dev(int64_t N, const float* __restrict__ g,
-                                                                 const float* __restrict__ buf,
-                                                                 const LbDev* __restrict__ dv, int done,
-                                                                 float* __restrict__ out) {
+// ---- the device-driven step in four launches
+// (1) k_lb_stage_all: stage the new pair and form every dot product against the stored pairs, eight
+//     pairs per pass over the vectors; (2) k_lb_reduce adds the workgroups' partials to `dots`.
+// (3) k_lbfgs_direction (above).
+// (4) k_lb_combine_all: d_out from all pairs, its statistics against g in the same pass, reduced by
+//     the last workgroup (what mde_vec_stats(g, d_out, NULL) writes).
+#define MDE_LB_NVAL (4 + 5 * MDE_LB_GROUP)
+__global__ __launch_bounds__(MDE_BLOCK) void k_lb_stage_all(int64_t N, const float* __restrict__ g,
+                                                            float* __restrict__ g_prev,
+                                                            const float* __restrict__ d, float t,
+                                                            float* __restrict__ buf,
+                                                            const LbDev* __restrict__ dv,
+                                                            double* __restrict__ partial) {
+  __shared__ double sm[MDE_BLOCK / 64][MDE_LB_NVAL];
   const int count = dv->count;
-  if (!FIRST && done >= count) return;
-  int pc = count - done;
-  if (pc > MDE_LB_GROUP) pc = MDE_LB_GROUP;
-  if (pc < 0) pc = 0;
-  const float c_g = dv->c_g;
-  const float* ps[MDE_LB_GROUP];
-  const float* py[MDE_LB_GROUP];
-  float cs[MDE_LB_GROUP], cy[MDE_LB_GROUP];
+  const int spare = dv->order[count];
+  float* s_new = buf + (int64_t)(2 * spare) * N;
+  float* y_new = buf + (int64_t)(2 * spare + 1) * N;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int nb = gridDim.x, b = blockIdx.x;
+  for (int done = 0; done == 0 || done < count; done += MDE_LB_GROUP) {
+    const bool first = done == 0;
+    int pc = count - done;
+    if (pc > MDE_LB_GROUP) pc = MDE_LB_GROUP;
+    const float* ps[MDE_LB_GROUP];
+    const float* py[MDE_LB_GROUP];
 #pragma unroll
-  for (int j = 0; j < MDE_LB_GROUP; ++j) {
-    const int slot = (j < pc) ? dv->order[done + j] : 0;
-    ps[j] = buf + (int64_t)(2 * slot) * N;
-    py[j] = buf + (int64_t)(2 * slot + 1) * N;
-    cs[j] = (j < pc) ? dv->cs[done + j] : 0.f;
-    cy[j] = (j < pc) ? dv->cy[done + j] : 0.f;
+    for (int j = 0; j < MDE_LB_GROUP; ++j) {
+      const int slot = (j < pc) ? dv->order[done + j] : spare;
+      ps[j] = buf + (int64_t)(2 * slot) * N;
+      py[j] = buf + (int64_t)(2 * slot + 1) * N;
+    }
+    double val[MDE_LB_NVAL];  // 0..3: y*.s*, y*.y*, s*.g, y*.g; 4 + 5 j + k: pair j
+#pragma unroll
+    for (int q = 0; q < MDE_LB_NVAL; ++q) val[q] = 0.0;
+    for (int64_t i = (int64_t)b * MDE_BLOCK + threadIdx.x; i < N; i += (int64_t)nb * MDE_BLOCK) {
+      const float gv = g[i];
+      float yv, sv;
+      if (first) {
+        yv = gv - g_prev[i];
+        sv = t * d[i];
+        y_new[i] = yv;
+        s_new[i] = sv;
+        g_prev[i] = gv;
+        val[0] = fma((double)yv, (double)sv, val[0]);
+        val[1] = fma((double)yv, (double)yv, val[1]);
+        val[2] = fma((double)sv, (double)gv, val[2]);
+        val[3] = fma((double)yv, (double)gv, val[3]);
+      } else {
+        yv = y_new[i];
+        sv = s_new[i];
+      }
+      // all sixteen loads before the first use (slots beyond pc alias the spare pair: valid memory,
+      // their sums are never written) -- a branch per pair would serialise sixteen memory latencies
+      float sj[MDE_LB_GROUP], yj[MDE_LB_GROUP];
+#pragma unroll
+      for (int j = 0; j < MDE_LB_GROUP; ++j) {
+        sj[j] = ps[j][i];
+        yj[j] = py[j][i];
+      }
+#pragma unroll
+      for (int j = 0; j < MDE_LB_GROUP; ++j) {
+        const double s = sj[j], y = yj[j];
+        val[4 + 5 * j + 0] = fma(s, (double)yv, val[4 + 5 * j + 0]);  // s_j . y*
+        val[4 + 5 * j + 1] = fma(y, (double)yv, val[4 + 5 * j + 1]);  // y_j . y*
+        val[4 + 5 * j + 2] = fma((double)sv, y, val[4 + 5 * j + 2]);  // s* . y_j
+        val[4 + 5 * j + 3] = fma(s, (double)gv, val[4 + 5 * j + 3]);  // s_j . g
+        val[4 + 5 * j + 4] = fma(y, (double)gv, val[4 + 5 * j + 4]);  // y_j . g
+      }
+    }
+    // wave sums -> LDS -> one thread per value adds the four waves (two barriers per pass)
+    const int nval = 4 + 5 * pc;
+#pragma unroll
+    for (int q = 0; q < MDE_LB_NVAL; ++q) {
+      if (q < nval) {
+        const double r = mde_wave_sum(val[q]);
+        if (lane == 0) sm[wave][q] = r;
+      }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < nval && (first || threadIdx.x >= 4)) {
+      const int q = threadIdx.x;
+      double r = 0.0;
+#pragma unroll
+      for (int w = 0; w < MDE_BLOCK / 64; ++w) r += sm[w][q];
+      const int row = q < 4 ? q : 4 + 5 * done + (q - 4);
+      partial[(int64_t)row * nb + b] = r;
+    }
+    __syncthreads();
   }
+}
+
+// dots[q] = sum_b partial[q * nb + b] for the 4 + 5 count rows that were written (one workgroup per
+// row: 54 rows of up to 1024 partials are too much for one last workgroup)
+__global__ void k_lb_reduce(int nb, const double* __restrict__ partial, const LbDev* __restrict__ dv,
+                            double* __restrict__ dots) {
+  __shared__ double smem[8];
+  const int q = blockIdx.x;
+  if (q >= 4 + 5 * dv->count) return;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) s += partial[(int64_t)q * nb + b];
+  const double r = mde_block_sum(s, smem);
+  if (threadIdx.x == 0) dots[q] = r;
+}
+
+// statistics rows as in k_vec_stats (x absent): 0 g.d 1 g.g 2 sum|g| 3 max|g| 4 #nonfinite 5 d.d 6 max|d| 7 0
+__global__ __launch_bounds__(MDE_BLOCK) void k_lb_combine_all(int64_t N, const float* __restrict__ g,
+                                                              const float* __restrict__ buf,
+                                                              const LbDev* __restrict__ dv,
+                                                              float* __restrict__ out,
+                                                              double* __restrict__ partial,
+                                                              double* __restrict__ stats,
+                                                              unsigned int* __restrict__ ticket) {
+  __shared__ double smem[8];
+  __shared__ float s_cs[MDE_LB_LD + MDE_LB_GROUP], s_cy[MDE_LB_LD + MDE_LB_GROUP];
+  __shared__ int s_slot[MDE_LB_LD + MDE_LB_GROUP];
+  const int count = dv->count;
+  const float c_g = dv->c_g;
+  if (threadIdx.x < MDE_LB_LD + MDE_LB_GROUP) {
+    const bool in = (int)threadIdx.x < count;
+    s_cs[threadIdx.x] = in ? dv->cs[threadIdx.x] : 0.0f;
+    s_cy[threadIdx.x] = in ? dv->cy[threadIdx.x] : 0.0f;
+    s_slot[threadIdx.x] = in ? dv->order[threadIdx.x] : 0;
+  }
+  __syncthreads();
+  double gd = 0, gg = 0, g1 = 0, gm = 0, nf = 0, dd = 0, dm = 0;
   for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N;
        i += (int64_t)gridDim.x * MDE_BLOCK) {
-    float v = FIRST ? c_g * g[i] : out[i];
+    const float gv = g[i];
+    float v = c_g * gv;
+    for (int j0 = 0; j0 < count; j0 += MDE_LB_GROUP) {
+      // the sixteen loads of eight pairs before the first use (entries beyond count: slot 0, weight 0)
+      float sv[MDE_LB_GROUP], yv[MDE_LB_GROUP];
 #pragma unroll
-    for (int j = 0; j < MDE_LB_GROUP; ++j)
-      if (j < pc) v = fmaf(cy[j], py[j][i], fmaf(cs[j], ps[j][i], v));
+      for (int j = 0; j < MDE_LB_GROUP; ++j) {
+        const float* sp = buf + (int64_t)(2 * s_slot[j0 + j]) * N;
+        sv[j] = sp[i];
+        yv[j] = sp[N + i];
+      }
+#pragma unroll
+      for (int j = 0; j < MDE_LB_GROUP; ++j)
+        if (j0 + j < count) v = fmaf(s_cy[j0 + j], yv[j], fmaf(s_cs[j0 + j], sv[j], v));
+    }
     out[i] = v;
+    const double gvd = gv, dv2 = v;
+    gg += gvd * gvd;
+    const double ag = fabs(gvd);
+    g1 += ag;
+    gm = ag > gm ? ag : gm;
+    nf += (fabsf(gv) <= 3.402823466e+38f) ? 0.0 : 1.0;
+    gd += gvd * dv2;
+    dd += dv2 * dv2;
+    const double ad = fabs(dv2);
+    dm = ad > dm ? ad : dm;
   }
+  const int nb = gridDim.x, b = blockIdx.x;
+  const double v8[8] = {gd, gg, g1, gm, nf, dd, dm, 0.0};
+  mde_publish8(v8, (1u << 3) | (1u << 6), partial, nb, b);
+  if (!mde_last_block(ticket)) return;
+  mde_final_rows(8, nb, partial, stats, (1ull << 3) | (1ull << 6));
 }
 
 extern "C" int mde_lbfgs_dev_reset(mde_lbfgs* o, void* stream) {
@@ -1312,34 +1462,21 @@ extern "C" int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, c
   if (!o || !o->dev || !g || !g_prev || !d || !d_out || !stats || !work) return MDE_E_INVALID;
   hipStream_t st = mde_stream(stream);
   const int64_t N = o->N;
-  const int nb = mde_grid(N, MDE_BLOCK * 2, 2048);
+  const int nb = mde_grid(N, MDE_BLOCK * 2, 1024);
   double* partial = work + MDE_SMALL_DOUBLES;
   double* dots = work;  // the small area: 4 + 5 * 63 doubles at most
-  const int groups = (o->history + MDE_LB_GROUP - 1) / MDE_LB_GROUP;
-  for (int gidx = 0; gidx < groups; ++gidx) {
-    if (gidx == 0)
-      hipLaunchKernelGGL((k_lbfgs_stage_dev<true>), dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t,
-                         o->buf, o->dev, 0, partial);
-    else
-      hipLaunchKernelGGL((k_lbfgs_stage_dev<false>), dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t,
-                         o->buf, o->dev, gidx * MDE_LB_GROUP, partial);
-    MDE_LAUNCH_CHECK();
-  }
-  hipLaunchKernelGGL(k_lbfgs_reduce_dev, dim3(4 + 5 * o->history), dim3(MDE_BLOCK), 0, st, nb, partial,
-                     o->dev, dots);
+  hipLaunchKernelGGL(k_lb_stage_all, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t, o->buf, o->dev,
+                     partial);
+  MDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_lb_reduce, dim3(4 + 5 * o->history), dim3(MDE_BLOCK), 0, st, nb, partial, o->dev, dots);
   MDE_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_lbfgs_direction, dim3(1), dim3(64), 0, st, o->dev, dots, o->history);
   MDE_LAUNCH_CHECK();
-  for (int gidx = 0; gidx < groups; ++gidx) {
-    if (gidx == 0)
-      hipLaunchKernelGGL((k_lbfgs_combine_dev<true>), dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, o->buf, o->dev, 0,
-                         d_out);
-    else
-      hipLaunchKernelGGL((k_lbfgs_combine_dev<false>), dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, o->buf, o->dev,
-                         gidx * MDE_LB_GROUP, d_out);
-    MDE_LAUNCH_CHECK();
-  }
-  return vec_stats_impl(N, g, d_out, nullptr, stats, work + MDE_SMALL_DOUBLES, st);
+  const int nbc = mde_grid(N, MDE_BLOCK * 2, MDE_RED_BLOCKS);  // (its last workgroup adds nbc partials per row)
+  hipLaunchKernelGGL(k_lb_combine_all, dim3(nbc), dim3(MDE_BLOCK), 0, st, N, g, o->buf, o->dev, d_out, partial,
+                     stats, work_ticket(work, TK_LB_COMBINE));
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
 }
 
 // copies of the device bookkeeping for tests: count, accepted
@@ -1398,5 +1535,5 @@ extern "C" int mde_lbfgs_combine(mde_lbfgs* o, const float* g, float c_g, const 
     first = false;
     done += P.count;
   } while (done < o->count);
-  return vec_stats_impl(N, g, d_out, nullptr, stats, work + MDE_SMALL_DOUBLES, st);
+  return vec_stats_impl(N, g, d_out, nullptr, stats, work, st);
 }

@@ -18,6 +18,7 @@ resets the memory.
 """
 import ctypes
 import math
+import os
 import time
 
 import numpy as np
@@ -59,6 +60,8 @@ class SolveStats(object):
         p.text(self.__str__())
 
 
+GRAPH_REPLAYS = 0  # iterations replayed as one HIP graph in this process (diagnostics / tests)
+
 # indices into the statistics board (mde_vec_stats)
 _GD, _GG, _G1, _GMAX, _NONFINITE, _DD, _DMAX, _XX, _LOSS = range(9)
 _DIR = 16  # offset (doubles) of the direction statistics written by update_direction
@@ -78,22 +81,37 @@ class _Engine(object):
         self.X = X.detach().clone().contiguous()
         self.X_trial = torch.empty_like(self.X)
         # gradient buffer with one trailing float: [grad | loss] is what a multi-GPU
-        # evaluation all-reduces in a single collective
-        # (a second trailing word holds the status flag of the constraint kernels, so that one
-        # small copy brings back both)
-        self.gtail = torch.zeros(self.N + 2, dtype=torch.float32, device=dev)
+        # evaluation all-reduces in a single collective.  A second trailing word holds the status
+        # flag of the constraint kernels and the statistics board (512 doubles) follows at the next
+        # 8-byte boundary: [loss | status | pad | board] is ONE contiguous read-back.
+        pad = (self.N + 2) % 2
+        self._board_off = self.N + 2 + pad                     # in floats
+        self.gtail = torch.zeros(self._board_off + 1024, dtype=torch.float32, device=dev)
         self.gbuf = self.gtail[:self.N + 1]
         self.g = self.gbuf[:self.N].view(self.n, self.d)
         self.loss_dev = self.gbuf[self.N:]
         self.g_prev = torch.empty_like(self.X)
         self.dir = torch.empty_like(self.X)
         self.work = util.work_buffer(dev, self.d)
-        self.board = torch.zeros(512, dtype=torch.float64, device=dev)
-        self.host = torch.zeros(512, dtype=torch.float64).pin_memory()
-        self.status = self.gtail[self.N + 1:].view(torch.int32)
-        self.host_tail = torch.zeros(2, dtype=torch.float32).pin_memory()
-        self.host_loss = self.host_tail[:1]
-        self.host_status = self.host_tail[1:].view(torch.int32)
+        self.board = self.gtail[self._board_off:].view(torch.float64)
+        self.status = self.gtail[self.N + 1:self.N + 2].view(torch.int32)
+        # pinned mirror of [loss | status | pad | board]
+        head = self._board_off - self.N                        # floats before the board (2 or 3)
+        self._head_bytes = 4 * head
+        b0 = head % 2                                          # keeps the host board 8-byte aligned
+        self.host_raw = torch.zeros(b0 + head + 1024, dtype=torch.float32).pin_memory()
+        self.host = self.host_raw[b0 + head:].view(torch.float64)
+        self.host_loss = self.host_raw[b0:b0 + 1]
+        self.host_status = self.host_raw[b0 + 1:b0 + 2].view(torch.int32)
+        self._host_ptr = ctypes.c_void_p(self.host_raw.data_ptr() + 4 * b0)
+        self._tail_ptr = ctypes.c_void_p(self.gtail.data_ptr() + 4 * self.N)
+        # the solve runs on the stream that is current now; its handle is looked up once
+        self._stream_obj = torch.cuda.current_stream(dev)
+        self._stream = ctypes.c_void_p(self._stream_obj.cuda_stream)
+        # replaying the usual iteration as one HIP graph needs a created stream (the legacy default
+        # stream cannot be captured); lbfgs() provides one for native problems
+        self.graph_ok = False
+        self._captures = []
         # the solve runs on the stream that is current now; its handle is looked up once
         self._stream_obj = torch.cuda.current_stream(dev)
         self._stream = ctypes.c_void_p(self._stream_obj.cuda_stream)
@@ -106,6 +124,9 @@ class _Engine(object):
         self.lbfgs = handle
 
     def close(self):
+        for handle in self._captures:
+            self.lib.mde_capture_destroy(handle)
+        self._captures = []
         if self.lbfgs is not None:
             self.lib.mde_lbfgs_destroy(self.lbfgs)
             self.lbfgs = None
@@ -122,13 +143,48 @@ class _Engine(object):
         _lib.check(self.lib.mde_vec_stats(self.N, _lib.ptr(g), _lib.ptr(d), _lib.ptr(x),
                                           _lib.ptr(self.board), _lib.ptr(self.work), self.stream()))
 
-    def read_board(self, count):
-        """One device->host read-back of the first ``count`` doubles plus the loss."""
-        self.host[:count].copy_(self.board[:count], non_blocking=True)
-        self.host_tail.copy_(self.gtail[self.N:], non_blocking=True)
+    def enqueue_read(self, count):
+        """Enqueue the device->host copy of [loss | status | first ``count`` doubles of the board]
+        (one contiguous range; a graph node when the stream is being captured)."""
+        _lib.check(self.lib.mde_copy_to_host(self._host_ptr, self._tail_ptr, self._head_bytes + 8 * int(count),
+                                             self.stream()))
+
+    def finish_read(self, count):
         self._stream_obj.synchronize()
         vals = self.host[:count].numpy().copy()
         return vals, float(self.host_loss[0])
+
+    def read_board(self, count):
+        """One device->host read-back of the first ``count`` doubles plus the loss."""
+        self.enqueue_read(count)
+        return self.finish_read(count)
+
+    # ---- one launch for the usual iteration (mde_capture_*)
+    def capture(self, enqueue):
+        """Record what ``enqueue()`` puts on the solve's stream; returns a replayable handle, or None
+        when recording is not possible (the solver then keeps enqueueing call by call)."""
+        if not self.graph_ok:
+            return None
+        try:
+            _lib.check(self.lib.mde_capture_begin(self.stream()))
+        except _lib.MdeHipError:
+            self.graph_ok = False
+            return None
+        handle = ctypes.c_void_p()
+        try:
+            enqueue()
+            _lib.check(self.lib.mde_capture_end(self.stream(), ctypes.byref(handle)))
+        except Exception:
+            self.lib.mde_capture_abort(self.stream())
+            self.graph_ok = False
+            return None
+        self._captures.append(handle)
+        return handle
+
+    def replay(self, handle):
+        global GRAPH_REPLAYS
+        _lib.check(self.lib.mde_capture_launch(handle, self.stream()))
+        GRAPH_REPLAYS += 1
 
     # ---- L-BFGS memory
     def reset_memory(self):
@@ -237,14 +293,23 @@ class _GenericProblem(object):
         pass
 
 
+def _is_native(objective_fn, constraint, require_fused_single_gpu=False):
+    """``objective_fn`` is ``MDE.average_distortion`` of a problem with a built-in constraint."""
+    owner = getattr(objective_fn, "__self__", None)
+    builtin = isinstance(constraint, (_constraints._Standardized, _constraints._Centered,
+                                      _constraints.Anchored))
+    native = (builtin and owner is not None and hasattr(owner, "_binding")
+              and getattr(objective_fn, "__name__", "") == "average_distortion")
+    if native and require_fused_single_gpu:
+        native = getattr(owner, "_reducer", None) is None and bool(owner._binding().fused)
+    return native
+
+
 def _make_problem(engine, objective_fn, constraint):
     """Pick the native path when ``objective_fn`` is ``MDE.average_distortion`` of a problem
     with a built-in constraint; otherwise the generic (callback) path."""
     owner = getattr(objective_fn, "__self__", None)
-    builtin = isinstance(constraint, (_constraints._Standardized, _constraints._Centered,
-                                      _constraints.Anchored))
-    if (builtin and owner is not None and hasattr(owner, "_binding")
-            and getattr(objective_fn, "__name__", "") == "average_distortion"):
+    if _is_native(objective_fn, constraint):
         reducer = getattr(owner, "_reducer", None)
         binding = owner._binding()
         if reducer is not None and not binding.fused:
@@ -266,16 +331,33 @@ def lbfgs(X, objective_fn, constraint, eps, max_iter, memory_size, use_line_sear
     start_time = time.time()
     average_distortions, grad_norms, step_size_percents, times, snapshots = [], [], [], [], []
 
-    engine = _Engine(X, memory_size)
-    try:
-        with torch.cuda.device(engine.device), torch.no_grad():
-            problem = _make_problem(engine, objective_fn, constraint)
-            _solve(engine, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
-                   print_every, snapshot_every, logger, average_distortions, grad_norms,
-                   step_size_percents, times, snapshots)
-        X_final = engine.X
-    finally:
-        engine.close()
+    # PYMDE_AMD_GRAPH=1: a native problem (built-in function and constraint, single GPU) is solved on
+    # a stream of its own and its usual iteration is recorded once and replayed as one HIP graph
+    # (_solve; the legacy default stream cannot be captured).  Off by default: with ROCm 7.2 the
+    # replay of the ~25-node graph is slower than the 25 launches it replaces (config 2: 0.249 vs
+    # 0.178 ms per iteration, config 3: 0.82 vs 0.70), see DESIGN.md section 3.
+    device = util.require_cuda_device(X.device)
+    use_graph = (os.environ.get("PYMDE_AMD_GRAPH", "0") == "1" and use_line_search
+                 and _is_native(objective_fn, constraint, require_fused_single_gpu=True))
+    caller_stream = torch.cuda.current_stream(device)
+    side = torch.cuda.Stream(device) if use_graph else None
+    if side is not None:
+        side.wait_stream(caller_stream)
+    with torch.cuda.device(device), torch.cuda.stream(side if side is not None else caller_stream):
+        engine = _Engine(X, memory_size)
+        engine.graph_ok = use_graph
+        try:
+            with torch.no_grad():
+                problem = _make_problem(engine, objective_fn, constraint)
+                _solve(engine, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
+                       print_every, snapshot_every, logger, average_distortions, grad_norms,
+                       step_size_percents, times, snapshots)
+            X_final = engine.X
+        finally:
+            engine._stream_obj.synchronize()
+            engine.close()
+    if side is not None:
+        caller_stream.wait_stream(side)
     if isinstance(X, torch.Tensor) and X.shape == X_final.shape and X.device == X_final.device \
             and X.is_contiguous() and not X.requires_grad:
         X.copy_(X_final)  # the reference updates the caller's tensor in place
@@ -296,6 +378,7 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
     last_gg = 0.0       # ||g||^2 of the last evaluated gradient (X.grad)
     norm_X = None       # ||X||_F of the current iterate (None: not known yet)
     t = 0.0
+    graphs = {}         # buffer parity -> recorded launch sequence of the usual iteration
 
     def evaluate_at_current():
         """closure() at X: no move, no retraction (lbfgs.py:426)."""
@@ -333,31 +416,55 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
             gtd, d_norm2, d_max = vals[_GD], math.sqrt(vals[_DD]), vals[_DMAX]
             g1 = vals[_G1]
             t = min(1.0, 1.0 / g1) if g1 > 0 else 1.0   # initial step (lbfgs.py:521-524), lr = 1
-        else:
-            e.update_direction(t)
-            t = 1.0
-
         last_eval = {"t": None}
 
-        def phi(tt, extra=0):
+        def enqueue_trial(tt):
             e.axpy(tt, e.dir, e.X, e.X_trial)
             problem.retract(e.X_trial)
             problem.value_and_grad(e.X_trial)
             e.stats(e.g, e.dir, e.X_trial)
-            v, f = e.read_board(8 + extra)
+
+        def finish_trial(tt, extra=0):
+            v, f = e.finish_read(8 + extra)
             last_eval["t"] = tt
             last_eval["gg"] = v[_GG]
             last_eval["xx"] = v[_XX]
             return (f, v[_GD], v[_NONFINITE] == 0), v
 
+        def phi(tt, extra=0):
+            enqueue_trial(tt)
+            e.enqueue_read(8 + extra)
+            return finish_trial(tt, extra)
+
         if n_iter > 1:
             # the first trial point is enqueued before the direction statistics are known; both
             # come back in one read
-            if use_line_search:
-                first, v = phi(t, extra=_DIR)
+            t_prev, t = t, 1.0
+            if use_line_search and e.graph_ok and t_prev == 1.0 and n_iter > 3:
+                # the usual iteration (previous step accepted at t = 1, first trial at t = 1): its
+                # launch sequence -- direction update, trial point, evaluation, statistics, read-back
+                # -- is recorded once per buffer parity and replayed as one HIP graph
+                key = e.X.data_ptr()
+                cap = graphs.get(key)
+                if cap is None:
+                    def usual():
+                        e.update_direction(1.0)
+                        enqueue_trial(1.0)
+                        e.enqueue_read(8 + _DIR)
+                    cap = graphs[key] = e.capture(usual) or False
+                if cap:
+                    e.replay(cap)
+                    first, v = finish_trial(1.0, extra=_DIR)
+                else:
+                    e.update_direction(t_prev)
+                    first, v = phi(t, extra=_DIR)
             else:
-                first = None
-                v, _ = e.read_board(_DIR + 8)
+                e.update_direction(t_prev)
+                if use_line_search:
+                    first, v = phi(t, extra=_DIR)
+                else:
+                    first = None
+                    v, _ = e.read_board(_DIR + 8)
             dv = v[_DIR:_DIR + 8]
             gtd, d_norm2, d_max = dv[_GD], math.sqrt(dv[_DD]), dv[_DMAX]
         else:

@@ -116,7 +116,9 @@ def work_buffer(device, d):
     key = str(device)
     buf = _WORK.get(key)
     if buf is None or buf.numel() < need:
-        buf = torch.empty(need, dtype=torch.float64, device=device)
+        # zeroed once: the small area holds the arrival counters of the kernels that finish their
+        # reduction in the last workgroup (they return to zero after every launch)
+        buf = torch.zeros(need, dtype=torch.float64, device=device)
         _WORK[key] = buf
     return buf
 

@@ -336,3 +336,45 @@ def test_device_driven_lbfgs_step_matches_explicit_two_loop():
             assert b[0] == pytest.approx(float(np.dot(g_np.astype(np.float64), got)), rel=1e-6)   # g.d
             assert b[5] == pytest.approx(float(np.dot(got, got)), rel=1e-6)                       # d.d
         _lib.check(lib.mde_lbfgs_destroy(h))
+
+
+@pytest.mark.parametrize("cname", ["centered", "standardized", "anchored"])
+def test_graph_replay_equals_call_by_call_launches(cname, monkeypatch):
+    """The usual iteration replayed as one HIP graph (mde_capture_*) runs the same kernels with the
+    same arguments in the same order as the call-by-call path: identical iterates and statistics."""
+    import pymde_amd
+    from pymde_amd import optim
+    rng = np.random.default_rng(3)
+    n, p = 20000, 150000
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    e = np.unique(np.sort(np.stack([i, j], 1), 1), axis=0)
+    w = rng.choice(np.array([-1.0, 1.0, 2.0], dtype=np.float32), size=len(e), p=[0.3, 0.4, 0.3])
+    edges = torch.tensor(e, device="cuda")
+
+    def make():
+        if cname == "anchored":
+            anchors = torch.arange(0, 50, device="cuda")
+            values = torch.tensor(rng2.standard_normal((50, 2)).astype(np.float32), device="cuda")
+            return pymde_amd.Anchored(anchors, values)
+        return pymde_amd.Centered() if cname == "centered" else pymde_amd.Standardized()
+
+    results = {}
+    for mode in ("0", "1"):
+        rng2 = np.random.default_rng(9)
+        monkeypatch.setenv("PYMDE_AMD_GRAPH", mode)
+        c = make()
+        f = pymde_amd.penalties.PushAndPull(torch.tensor(w, device="cuda"))
+        mde = pymde_amd.MDE(n, 2, edges, f, constraint=c)
+        X0 = c.project_onto_constraint(torch.tensor(np.random.default_rng(4).standard_normal((n, 2)).astype(np.float32),
+                                                    device="cuda"))
+        before = optim.GRAPH_REPLAYS
+        X = mde.embed(X=X0.clone(), max_iter=60, eps=0.0, snapshot_every=25).clone()
+        results[mode] = (X, mde.solve_stats, optim.GRAPH_REPLAYS - before)
+    (Xe, se, ne), (Xg, sg, ng) = results["0"], results["1"]
+    assert ne == 0 and ng >= 30, (ne, ng)
+    assert torch.equal(Xe, Xg), float((Xe - Xg).abs().max())
+    assert se.average_distortions == sg.average_distortions
+    assert se.residual_norms == sg.residual_norms
+    assert se.step_size_percents == sg.step_size_percents
+    assert all(torch.equal(a, b) for a, b in zip(se.snapshots, sg.snapshots))
