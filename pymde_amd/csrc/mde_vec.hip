@@ -182,8 +182,9 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_colsum(int64_t n, int d, int dp,
       mde_st_partial(partial + (int64_t)blockIdx.x * d + c, t);
     }
   }
-  // the last workgroup to arrive turns the partial sums into the column means (fixed order)
-  if (!mde_last_block(ticket)) return;
+  // narrow matrices (ticket given): the last workgroup to arrive turns the partial sums into the
+  // column means; wide ones leave that to k_colsum_final (one wave per column, in parallel)
+  if (!ticket || !mde_last_block(ticket)) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nb = gridDim.x;
   for (int c = wave; c < d; c += MDE_BLOCK / 64) {
     double s = 0.0;
@@ -191,6 +192,16 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_colsum(int64_t n, int d, int dp,
     s = mde_wave_sum(s);
     if (lane == 0) mean[c] = s / (double)n;
   }
+}
+// mean[c] = (sum_b partial[b][c]) / n
+// (one wave per column: lane-strided partial sums + a fixed-order wave reduction)
+__global__ __launch_bounds__(64) void k_colsum_final(int nb, int d, int64_t n, const double* __restrict__ partial,
+                                                     double* __restrict__ mean) {
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int b = threadIdx.x; b < nb; b += 64) s += partial[(int64_t)b * d + c];
+  s = mde_wave_sum(s);
+  if (threadIdx.x == 0) mean[c] = s / (double)n;
 }
 __global__ __launch_bounds__(MDE_BLOCK) void k_sub_mean(int64_t N, int d, float* __restrict__ Z,
                                                         const double* __restrict__ mean) {
@@ -212,9 +223,15 @@ static int center_impl(int64_t n, int d, float* Z, double* work, hipStream_t st)
   if (dp > MDE_BLOCK) dp = MDE_BLOCK;
   const int rpp = MDE_BLOCK / dp;
   int nb = mde_grid(n, rpp * 8, MDE_RED_BLOCKS);
+  // (a last workgroup adding d columns of nb partials one after the other only pays for a few columns)
+  const bool fused_final = d <= 16;
   hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(MDE_BLOCK), 0, st, n, d, dp, Z, partial, mean,
-                     work_ticket(work, TK_CENTER));
+                     fused_final ? work_ticket(work, TK_CENTER) : (unsigned int*)nullptr);
   MDE_LAUNCH_CHECK();
+  if (!fused_final) {
+    hipLaunchKernelGGL(k_colsum_final, dim3(d), dim3(64), 0, st, nb, d, n, partial, mean);
+    MDE_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(k_sub_mean, dim3(mde_grid(n * d, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, n * d, d, Z,
                      mean);
   MDE_LAUNCH_CHECK();
