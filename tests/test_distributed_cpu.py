@@ -80,3 +80,37 @@ def test_two_rank_gloo_allreduce_matches_unsharded():
         p.join(180)
         assert p.exitcode == 0
     assert ret[0] == 1 and ret[1] == 1 and ret["mode0"] == ret["mode1"]
+
+
+def _single_worker(port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from pymde_amd import distributed
+    n, d = 50, 3
+    buf = torch.arange(n * d + 1, dtype=torch.float32) * 0.5 - 7.0
+    # a world of one exchanges nothing unless forced ...
+    ex = distributed.GradExchange(n, d, [0, n], 0, 1)
+    assert ex(buf.clone()).equal(buf) and ex.mode is None
+    # ... and forced (what the single-GPU RCCL test does) both forms are the identity
+    forced = distributed.GradExchange(n, d, [0, n], 0, 1, force=True)
+    out = forced(buf.clone())
+    assert out.equal(buf) and forced.mode == "all_gather" and not forced.needs_zero()
+    b = buf.clone()
+    assert forced(b) is b and b.equal(buf)
+    reduce_only = distributed.GradExchange(n, d, [0, n], 0, 1, force=True)
+    reduce_only.mode = "all_reduce"
+    assert reduce_only(buf.clone()).equal(buf) and reduce_only.needs_zero()
+    ret["ok"] = 1
+    dist.destroy_process_group()
+
+
+def test_forced_exchange_in_a_world_of_one_is_the_identity():
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 31500 + (os.getpid() % 2000)
+    proc = ctx.Process(target=_single_worker, args=(port, ret))
+    proc.start()
+    proc.join(180)
+    assert proc.exitcode == 0 and ret.get("ok") == 1
