@@ -122,19 +122,18 @@ MDE_DEV void mde_eval(float ss, float a0, float a1, const MdeScalars& S, float& 
     const float sub = (v > 0.0f) ? 1.0f : ((v == 0.0f) ? 0.5f : 0.0f);  // torch.max tie -> 1/2
     gd = sub * a0 * mde_rcp(d);
   } else if constexpr (KIND == MDE_F_LOG1P && ECLS == 2) {  // penalties.py:310-321, exponent 1.5
-    // d^1.5 = ss * d^-1/2 and f'/d = 1.5 w d^-1/2 / (1 + d^1.5): one rsq replaces a sqrt, a
-    // reciprocal and three multiplies.  v_mul_legacy (0 * inf = 0) keeps d = 0 exact: f = 0 and
-    // gd = inf, which the caller maps to 1 like the reference's NaN.
+    // d^1.5 = d sqrt(d) and f'/d = 1.5 w / (sqrt(d) (1 + d^1.5)): two square roots and ONE
+    // reciprocal, r = 1 / (sqrt(d) t + tiny).  The tiny term (far below one ulp of the product for
+    // every d >= 1e-44) keeps r finite at d = 0, where the reference's NaN/Inf -> 1 rule only ever
+    // multiplies x_v - x_u = 0: gd needs no fix-up here.  log1p(u) = log t + (u - (t - 1)) / t with
+    // 1 / t = sqrt(d) r.
     const float d = mde_sqrt(ss);
-    const float rs = __builtin_amdgcn_rsqf(d);
-    float pe;
-    // (s_nop: the hazard recogniser does not look inside inline asm, and rs comes straight out of
-    // the transcendental unit)
-    asm("s_nop 0\n\tv_mul_legacy_f32 %0, %1, %2" : "=v"(pe) : "v"(ss), "v"(rs));
+    const float sd = mde_sqrt(d);
+    const float pe = d * sd;
     const float t = 1.0f + pe;
-    const float rt = mde_rcp(t);
-    f = a0 * fmaf(pe - (t - 1.0f), rt, mde_log(t));
-    gd = (1.5f * a0) * rs * rt;
+    const float r = mde_rcp(fmaf(sd, t, 1.0e-30f));
+    f = a0 * fmaf((pe - (t - 1.0f)) * sd, r, mde_log(t));
+    gd = (1.5f * a0) * r;
   } else if constexpr (KIND == MDE_F_LOG1P) {  // penalties.py:310-321
     const float d = mde_sqrt(ss);
     const float e = mde_expo<ECLS>(S.s0);
@@ -332,7 +331,14 @@ struct MdeFuncArgs {
 };
 
 // universal: every kind, PushAndPull by sign of the weight (penalties.py:390: w >= 0 attractive)
+// kFiniteG: f'/d is finite for every finite parameter and distance (no NaN/Inf fix-up needed when
+// the caller knows the parameters are finite)
+// kRingFused: the LDS-ring kernel spells the evaluation out itself (mde_ring.hip: Log1p with exponent
+// 1.5, parameters pre-multiplied by kParamScale) instead of calling eval()
 struct FnRuntime {
+  static constexpr bool kFiniteG = false;
+  static constexpr bool kRingFused = false;
+  static constexpr float kParamScale = 1.0f;
   MdeFuncArgs A;
   MDE_DEV void eval(float ss, float a0, float a1, float& f, float& gd) const {
     if (A.kind_neg != MDE_F_NONE && a0 < 0.0f)
@@ -344,6 +350,9 @@ struct FnRuntime {
 // one kind, exponent class fixed at compile time
 template <int KIND, int ECLS>
 struct FnSingle {
+  static constexpr bool kFiniteG = (KIND == MDE_F_LOG1P && ECLS == 2) || KIND == MDE_F_QUADRATIC;
+  static constexpr bool kRingFused = (KIND == MDE_F_LOG1P && ECLS == 2);
+  static constexpr float kParamScale = kRingFused ? 1.5f : 1.0f;
   MdeFuncArgs A;
   MDE_DEV void eval(float ss, float a0, float a1, float& f, float& gd) const {
     mde_eval<KIND, ECLS>(ss, a0, a1, A.S, f, gd);
@@ -352,6 +361,9 @@ struct FnSingle {
 // PushAndPull with both branches fixed at compile time
 template <int KA, int EA, int KR, int ER>
 struct FnPushPull {
+  static constexpr bool kFiniteG = false;
+  static constexpr bool kRingFused = false;
+  static constexpr float kParamScale = 1.0f;
   MdeFuncArgs A;
   MDE_DEV void eval(float ss, float a0, float a1, float& f, float& gd) const {
     if (a0 >= 0.0f)
@@ -364,6 +376,10 @@ struct FnPushPull {
 MDE_DEV float mde_fix_g(float g) {
   // average_distortion.py:85-88: NaN -> 1.0, Inf -> 1.0
   return (fabsf(g) <= 3.402823466e+38f) ? g : 1.0f;
+}
+// the same rule for a g that is still to be multiplied by 1/p: `one` = p
+MDE_DEV float mde_fix_g_to(float g, float one) {
+  return (fabsf(g) <= 3.402823466e+38f) ? g : one;
 }
 
 static inline int mde_exp_class(float e) {

@@ -3,11 +3,12 @@
 #include "mde_common.h"
 
 // LDS-ring layout of the small-d kernel (mde_ring.hip; built lazily, per embedding dim).
-// A 1024-thread workgroup (row block rb, column group qg) runs MDE_RING_NCW consumer waves; the
+// A workgroup (row block rb, column group qg) runs MDE_RING_NCW consumer waves; the
 // stream of consumer wave w is the wave iterations [wave_iter[s], wave_iter[s + 1]) with
 // s = (rb * col_groups + qg) * NCW + w, 64 packed half-edges each, chunk-major.
 struct mde_ring_layout {
   int d = 0;                    // embedding dimension the sizes were chosen for
+  int rejected_d = 0;           // dimension for which the ring layout was tried and given up (too much padding)
   int rows_per_block = 0, n_row_blocks = 0;
   int col_groups = 1;           // Q: workgroups per row block, each walking 1/Q of the chunks
   int chunk_cols = 0, n_chunks = 0;
@@ -15,7 +16,7 @@ struct mde_ring_layout {
   int64_t H = 0;                // padded entry count = 64 * n_iters
   uint32_t* packed = nullptr;   // [H] LDS row address << 17 | ring byte offset
   int32_t* eid = nullptr;       // [H] original edge id (parameter expansion), -1 for padding
-  uint32_t* hdr = nullptr;      // [n_iters] chunk window, fold rounds and padding flag of an iteration
+  uint32_t* hdr = nullptr;      // [2 * n_iters] chunk window | padding flag and loss class of an iteration
   int32_t* wave_iter = nullptr; // [n_row_blocks * col_groups * NCW + 1]
   float* partial = nullptr;     // [Q * nloc * d] per-group gradient partials (Q > 1 only)
 };

@@ -6,38 +6,49 @@
 // bound by the L2 request rate (~100 G/s from an 8 MB table: >= 1 ms for 10^8 half-edges whatever
 // the HBM rate).  Here every random access is served by LDS:
 //
-//   * a workgroup of 14 waves owns a block of R rows: their x_v and their fp32 gradient
+//   * a workgroup of 12 waves owns a block of R rows: their x_v and their fp32 gradient
 //     accumulators stay in LDS for the whole kernel (2 x 32 KB);
 //   * the embedding table streams through a ring of S chunk slots in the remaining 96 KB, filled
 //     by LDS-DMA (global_load_lds_dwordx4: L2 -> LDS, no VGPRs, no ds_write) by two producer
-//     waves;
-//   * the other 12 waves are consumers.  Each owns a fixed range of the block's rows and walks
-//     its own contiguous stream of packed half-edges (row address << 17 | ring offset, 4 bytes,
-//     chunk-major) -- because a row has exactly one wave that ever touches its accumulator, the
-//     update is a plain LDS read-add-write, the summation order is fixed by the layout (bitwise
-//     reproducible), and the waves need NO workgroup barrier between prologue and epilogue;
+//     waves (raised priority: the DMA issue goes ahead of the consumers' instructions);
+//   * the other 10 waves are consumers.  Each owns a fixed range of the block's rows and walks
+//     its own contiguous stream of packed half-edges (row address << 17 | ring offset + 16, 4
+//     bytes, chunk-major) -- because a row has exactly one wave that ever touches its accumulator,
+//     the update is a plain LDS read-add-write, the summation order is fixed by the layout
+//     (bitwise reproducible), and the waves need NO workgroup barrier between prologue and epilogue;
 //   * producers and consumers synchronise through a handful of LDS words: a consumer publishes
 //     the oldest chunk it still reads (prog[w]), a producer the next chunk it has not landed yet
 //     (F[p]); a consumer polls F only when its next iteration needs a chunk it has not seen
 //     landed, a producer polls prog only when the slot it wants to refill may still be in use.
-//     The waves of a workgroup therefore drift freely within the ring's slack, and staging,
-//     stream loads, LDS traffic and VALU work of different waves overlap instead of alternating
-//     in barrier-separated phases.
 //   * LDS fp32 atomics would remove the one-writer rule, but ds_add_f32 retires ~0.16 lanes per
-//     clock per CU on gfx950 (tools/ldsprobe: 397 clocks for two of them per wave) -- 20x slower
-//     than read-add-write.  The layout builder therefore keeps duplicate rows out of a wave
-//     iteration (an entry whose row is taken is deferred to the next iteration: 97 % of the
-//     iterations of a uniform-random graph are duplicate-free); where they remain (hub vertices)
-//     the 64 entries are sorted by row, equal rows are adjacent lanes and are folded with DPP wave
-//     shifts -- the number of fold rounds is known at build time and rides in the header word.
+//     clock per CU on gfx950 (tools/ldsprobe) -- 20x slower than read-add-write.  The layout
+//     builder therefore makes the rows of a wave iteration DISTINCT (an entry whose row is taken
+//     waits for the next iteration), caps the entries per LDS bank class on the row and on the
+//     column side, and deals the entries to the lanes so that every 32-lane read pass and every
+//     16-lane write pass is as shallow as the classes allow (mde_ring_place.h: measured
+//     SQ_LDS_IDX_ACTIVE 40.6 -> 29.5 clocks per iteration, bank conflicts 21.7 -> 10.1).
+//   * every edge is evaluated from both endpoints (owner-computes gradient rows), but its LOSS term
+//     is added once: by the entry whose row is the smaller vertex.  Header word 2 says per
+//     iteration whether none / all / some of its entries do (half of the iterations skip the log).
+//   * the consumer loop is software-pipelined one iteration deep: the operands of iteration k + 1
+//     are read (after the hand-shake for its chunks) before k is evaluated, the accumulator of
+//     k + 1 right behind the write of k.
+// What bounds it (round 3, tools/r3_probe.sh, tools/dmaprobe, profiles/r03_pmc_summary.md): not
+// VALU (17 + 3 transcendental instructions per 64 half-edges), not LDS bank conflicts and not
+// HBM -- the staging.  An LDS-DMA piece takes ~34 clocks per CU with the consumers idle and
+// 55 - 65 with them running, so two producer waves need 0.19 - 0.20 ms for the 8192 pieces a
+// workgroup stages however the ring is sized; the hand-shake adds the rest.
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "mde_common.h"
 #include "mde_functions.h"
 #include "mde_plan.h"
+#include "mde_ring_place.h"
 #define COMMA ,
 
 // Static LDS map (bytes).  The region bases are compile-time constants below 2^16, so the
@@ -49,15 +60,23 @@
 #define MDE_RING_BYTES 98304
 #define MDE_RING_CTRL_OFF (32768 - 256)
 #define MDE_RING_CTRL_PROG (MDE_RING_CTRL_OFF)        // int prog[16]: oldest chunk consumer w still reads
-#define MDE_RING_CTRL_F (MDE_RING_CTRL_OFF + 64)      // int F[2]: next chunk producer p has not landed
+#define MDE_RING_CTRL_F (MDE_RING_CTRL_OFF + 64)      // int F[NPROD]: next chunk whose pieces of producer p have not landed
 #define MDE_RING_CTRL_CB (MDE_RING_CTRL_OFF + 96)     // float[8]: parameter codebook
 #ifndef MDE_RING_NCW
-#define MDE_RING_NCW 12            // consumer waves (8..14 measured within 7 % of each other at config 4; 11-12 best)
+#define MDE_RING_NCW 10            // consumer waves (config 4, round 3: 8 -> 0.243, 10 -> 0.230, 12 -> 0.238, 14 -> 0.246 ms)
 #endif
+#ifndef MDE_RING_PRODPRIO
+#define MDE_RING_PRODPRIO 3
+#endif
+#ifndef MDE_RING_COOP
+#define MDE_RING_COOP 0            // 1: the producers share every chunk (producer p moves pieces p, p + NPROD, ...); 0: they alternate whole chunks
+#endif
+#ifndef MDE_RING_NPROD
 #define MDE_RING_NPROD 2           // producer waves
+#endif
 #define MDE_RING_BS (64 * (MDE_RING_NCW + MDE_RING_NPROD))
 #ifndef MDE_RING_DEPTH
-#define MDE_RING_DEPTH 2           // chunks in flight per producer (<= 3)
+#define MDE_RING_DEPTH 2           // chunks in flight per producer (all producers together when they share chunks), <= 4
 #endif
 #ifndef MDE_RING_PF
 #define MDE_RING_PF 8              // stream slots prefetched per consumer wave
@@ -75,17 +94,21 @@
 #ifndef MDE_RING_C2
 #define MDE_RING_C2 1024
 #endif
-__host__ __device__ constexpr int ring_chunk_cols(int d) { return d == 1 ? 2048 : (d == 2 ? MDE_RING_C2 : 512); }
+// (a chunk is a multiple of NPROD KiB: every producer moves the same number of 1 KiB pieces)
+__host__ __device__ constexpr int ring_chunk_cols(int d) { return d == 1 ? 2048 : (d == 2 ? MDE_RING_C2 : (d == 3 ? 1024 : 512)); }
 __host__ __device__ constexpr int ring_chunk_bytes(int d) { return ring_chunk_cols(d) * 4 * d; }
 __host__ __device__ constexpr int ring_slots(int d) { return MDE_RING_BYTES / ring_chunk_bytes(d); }
-// an iteration may reference chunks m .. m + span, span <= S - NPROD * DEPTH: the producers keep
-// their full depth in flight while the slowest consumer sits on its window
+// an iteration may reference chunks m .. m + span: the ring also holds the chunks in flight
+// (tools/dmaprobe: the LDS-DMA fill needs ~48 KB in flight per CU to run at its 22 - 33 clocks per KiB;
+// with 32 KB it drops to 42 and everything waits for the producers) and two slots of slack
 __host__ __device__ constexpr int ring_max_span(int d) {
 #ifdef MDE_RING_SPAN
   return MDE_RING_SPAN;
 #endif
   // (measured at config 4: 4..6 chunks of window leave the waves the most slack; 8 costs 4 %)
-  return ring_slots(d) - MDE_RING_NPROD * MDE_RING_DEPTH - 2 > 31 ? 31 : ring_slots(d) - MDE_RING_NPROD * MDE_RING_DEPTH - 2;
+  constexpr int inflight = MDE_RING_COOP ? MDE_RING_DEPTH : MDE_RING_NPROD * MDE_RING_DEPTH;
+  // (config 4: windows of 4 and 5 chunks measure the same, 6 costs 2 %: the slack is worth more than the padding)
+  return ring_slots(d) - inflight - 2 > 5 ? 5 : ring_slots(d) - inflight - 2;
 }
 
 // header word of a wave iteration: [15:0] m = lowest chunk referenced, [20:16] span (highest = m +
@@ -152,65 +175,92 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_seg(int64_t H, uint32_t nseg
 }
 
 // Cut each (block, group, wave) stream into wave iterations: up to 64 entries, taken in stream
-// order, whose chunks lie within SPAN of the oldest one (the ring holds them all at once).  An
-// entry whose row already has an earlier entry in the same iteration is deferred to the next
-// one (at most `defer` times, then it goes out regardless): the kernel's common case is an
-// iteration of 64 distinct rows -- every lane does its own read-add-write, no folding -- and a
-// row's entries still reach its accumulator in stream order.  Lanes freed by deferred entries
-// are refilled from the stream (a few rounds), so iterations stay full.
-// One wave per stream; FILL = false counts the iterations, FILL = true writes, per iteration, the
-// sorted positions of its entries, their number and the oldest chunk still needed (it_m).
-#ifndef MDE_RING_DEFER
-#define MDE_RING_DEFER 2
+// order, whose chunks lie within SPAN of the oldest one (the ring holds them all at once).
+//   * The rows of an iteration are DISTINCT (always): every lane does its own LDS read-add-write
+//     of its row's accumulator, nothing is folded across lanes.  An entry whose row is taken waits
+//     for the next iteration (a row's entries still reach its accumulator in stream order); a hub
+//     row therefore costs padding, and mde_plan_layout gives up on the ring when that gets out of
+//     hand (auto mode).
+//   * Bank classes: an iteration takes at most `cap` entries per row bank class and per column
+//     bank class (the 8-byte LDS slot mod 32 at d = 2) -- with the lane placement of k_ring_pack
+//     every 32-lane pass of its LDS reads is then at most cap/2 deep (tools/sched_sim.cpp: cap 4
+//     costs ~1 % padding and takes the modelled LDS clocks per iteration from 26 to 22; the
+//     unplaced, uncapped layout of round 2 measured ~40).  An entry that lost `force` times goes
+//     out regardless of the caps (never against a taken row).
+// Lanes freed by waiting entries are refilled from the stream (a few rounds), so iterations stay
+// full.  One wave per stream; FILL = false counts the iterations, FILL = true writes, per iteration,
+// the sorted positions of its entries, their number and the oldest chunk still needed (it_m).
+#ifndef MDE_RING_FORCE
+#define MDE_RING_FORCE 3
 #endif
-#define MDE_RING_CARRY 192  // deferred entries a stream can hold (more: they go out with duplicates)
+#define MDE_RING_CARRY 256  // waiting entries a stream can hold
+__host__ __device__ constexpr int ring_cls_shift(int d) { return d == 2 ? 3 : (d == 4 ? 4 : 2); }
+__host__ __device__ constexpr int ring_cls_mask(int d) { return d == 4 ? 15 : 31; }
 template <bool FILL>
 __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* __restrict__ seg,
                                                       const int32_t* __restrict__ bounds,
                                                       const uint32_t* __restrict__ keys,
                                                       const uint32_t* __restrict__ vals,
-                                                      const int32_t* __restrict__ hrow, uint32_t JM, int SPAN,
-                                                      int R, int Q, int NC, int32_t* __restrict__ iters,
+                                                      const int32_t* __restrict__ hrow,
+                                                      const int32_t* __restrict__ nbr, uint32_t JM, int SPAN,
+                                                      int R, int Q, int NC, int d, int cap,
+                                                      int32_t* __restrict__ iters,
                                                       const int32_t* __restrict__ iter_base,
                                                       int32_t* __restrict__ it_ent, int32_t* __restrict__ it_cnt,
                                                       int32_t* __restrict__ it_m) {
   __shared__ int flag[4096];                // per row of the block: priority of the entry that holds it
-  __shared__ int cq_pos[2][MDE_RING_CARRY]; // deferred entries (sorted position), double buffered
+  __shared__ int cq_pos[2][MDE_RING_CARRY]; // waiting entries (sorted position), double buffered
   __shared__ int cq_age[2][MDE_RING_CARRY];
   __shared__ int em[64];                    // entries of the iteration being formed
+  __shared__ int rcnt[32], ccnt[32];        // entries per bank class in it
   const int i = blockIdx.x, lane = threadIdx.x;
   if (i >= nseg) return;
   for (int r = lane; r < 4096; r += 64) flag[r] = 0x7fffffff;
   __syncthreads();
   const int beg = seg[i], end = seg[i + 1];
-  const int rb = (i / MDE_RING_NCW) / Q, w = i % MDE_RING_NCW;
-  // few rows per wave (small problems): most entries of an iteration collide anyway -- no deferral
-  const int nrows = bounds[rb * (MDE_RING_NCW + 1) + w + 1] - bounds[rb * (MDE_RING_NCW + 1) + w];
-  const int defer = nrows >= 160 ? MDE_RING_DEFER : 0;
+  const int rb = (i / MDE_RING_NCW) / Q;
+  const int sh = ring_cls_shift(d), cm = ring_cls_mask(d), rowbytes = 4 * d;
   const int first = FILL ? iter_base[i] : 0;
   int out = first, next = beg, nc = 0, cur = 0;
   int last_chunk = (int)(((int64_t)((i / MDE_RING_NCW) % Q) * NC + Q - 1) / Q);
   while (nc > 0 || next < end) {
     const int m = (int)(keys[nc > 0 ? cq_pos[cur][0] : next] & JM);  // oldest candidate's chunk
     const int lim = m + SPAN;
-    int nem = 0, nnew = 0;  // emitted so far, deferred so far (into buffer cur ^ 1)
-    // offer a batch of candidates (stream order = ascending priority); prio0 keeps later batches
-    // behind earlier ones on a row's flag
+    int nem = 0, nnew = 0;  // emitted so far, waiting so far (into buffer cur ^ 1)
+    if (lane < 32) rcnt[lane] = ccnt[lane] = 0;
+    __syncthreads();
+    // offer a batch of candidates (stream order = ascending priority)
     auto offer = [&](int pos, int age, int prio) {
-      int row = 0;
+      int row = 0, rc = -1, cc = -2;
       if (pos >= 0) {
-        row = hrow[vals[pos]] - rb * R;
+        const uint32_t q = vals[pos];
+        row = hrow[q] - rb * R;
+        rc = ((row * rowbytes) >> sh) & cm;
+        cc = (int)((((uint32_t)nbr[q] * (uint32_t)rowbytes) >> sh) & (uint32_t)cm);  // (chunks start on class 0)
         atomicMin(&flag[row], prio);
       }
       __syncthreads();
-      const bool room = true;
-      const bool win = pos >= 0 && (flag[row] == prio || age >= defer);
-      (void)room;
+      const bool rowwin = pos >= 0 && flag[row] == prio;
+      // how many earlier row winners of this batch share my classes (whether or not they pass
+      // their own caps: slightly pessimistic, deterministic and parallel)
+      int rkR = 0, rkC = 0;
+      const int rcw = rowwin ? rc : -1, ccw = rowwin ? cc : -2;
+      for (int t = 0; t < 64; ++t) {
+        const int rt = __builtin_amdgcn_readlane(rcw, t), ct = __builtin_amdgcn_readlane(ccw, t);
+        rkR += (t < lane) && (rt == rc);
+        rkC += (t < lane) && (ct == cc);
+      }
+      const bool capok = rowwin && (rcnt[rc] + rkR < cap) && (ccnt[cc] + rkC < cap);
+      const bool win = rowwin && (capok || age >= MDE_RING_FORCE);
       // winners beyond the 64th wait as well (they keep their turn: age unchanged)
       const unsigned long long wm = __ballot(win);
       const int widx = nem + __popcll(wm & ((1ull << lane) - 1ull));
       const bool emit = win && widx < 64;
-      if (emit) em[widx] = pos;
+      if (emit) {
+        em[widx] = pos;
+        atomicAdd(&rcnt[rc], 1);
+        atomicAdd(&ccnt[cc], 1);
+      }
       const bool lose = pos >= 0 && !emit;
       const unsigned long long lm = __ballot(lose);
       const int lidx = nnew + __popcll(lm & ((1ull << lane) - 1ull));
@@ -218,22 +268,22 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
         cq_pos[cur ^ 1][lidx] = pos;
         cq_age[cur ^ 1][lidx] = win ? age : age + 1;
       }
-      // (overflow of the deferral queue cannot happen: a batch is only offered while
+      // (overflow of the waiting queue cannot happen: a batch is only offered while
       // nnew + 64 <= MDE_RING_CARRY)
       nem += __popcll(__ballot(emit));
       nnew += __popcll(lm);
       __syncthreads();
     };
     int prio = 0;
-    // the deferred entries first, 64 at a time
+    // the waiting entries first, 64 at a time
     for (int c0 = 0; c0 < nc; c0 += 64) {
       const int k = c0 + lane;
       offer(k < nc ? cq_pos[cur][k] : -1, k < nc ? cq_age[cur][k] : 0, prio + lane);
       prio += 64;
     }
     // then new entries while lanes are free and the window allows (a few rounds: entries that
-    // collide leave their lane to the next ones)
-    for (int round = 0; round < 4 && nem < 64 && next < end && nnew + 64 <= MDE_RING_CARRY; ++round) {
+    // have to wait leave their lane to the next ones)
+    for (int round = 0; round < 6 && nem < 64 && next < end && nnew + 64 <= MDE_RING_CARRY; ++round) {
       const int want = 64 - nem;
       const int cand = next + lane;
       const bool take = lane < want && cand < end && (int)(keys[cand] & JM) <= lim;
@@ -243,23 +293,21 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
       prio += 64;
       next += ntake;
     }
-    // the rows taken in this iteration are released
+    // the rows claimed in this iteration are released
     if (lane < nem) flag[hrow[vals[em[lane]]] - rb * R] = 0x7fffffff;
     for (int k = lane; k < nnew; k += 64) flag[hrow[vals[cq_pos[cur ^ 1][k]]] - rb * R] = 0x7fffffff;
-    if (FILL) {
-      if (lane < nem) it_ent[(size_t)out * 64 + lane] = em[lane];
-      if (lane == 0) {
-        it_cnt[out] = nem;
-        it_m[out] = m;
-      }
-    }
-    if (nem > 0) last_chunk = (int)(keys[em[nem - 1]] & JM);
-    // (em is in stream order within a batch but a deferred entry may follow... keep the maximum)
     {
+      // newest chunk the iteration references
       int mx = lane < nem ? (int)(keys[em[lane]] & JM) : 0;
       mx = mde_wave_max(mx);
       if (nem > 0) last_chunk = mx;
-      if (FILL && lane == 0 && nem > 0) it_cnt[out] = nem | (mx << 8);
+    }
+    if (FILL) {
+      if (lane < nem) it_ent[(size_t)out * 64 + lane] = em[lane];
+      if (lane == 0) {
+        it_cnt[out] = nem | (last_chunk << 8);
+        it_m[out] = m;
+      }
     }
     ++out;
     nc = nnew;
@@ -277,9 +325,20 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
   if (!FILL && lane == 0) iters[i] = out;
 }
 
-// One wave per iteration: sort its <= 64 entries by row (stable, so a row's entries keep their
-// chunk-major order), pad to 64 with dummies in the highest lanes, write packed words, edge ids
-// and the header.
+// Header of a wave iteration, four words (scalar registers in the kernel: no field extraction):
+//   [0] m    = oldest chunk this or a later iteration of the stream still reads
+//   [1] need = newest chunk this iteration reads
+//   [2] whose loss terms are added here -- every edge sits in two streams (once per endpoint) and
+//       its loss term is added by the entry whose row is the smaller vertex: 0 = no entry of the
+//       iteration, 1 = every entry, 2 = mixed (the kernel tests v < u per lane; only the
+//       iterations around the diagonal)
+//   [3] bit 0: the iteration has padding lanes
+#define MDE_RING_HW 4
+#define MDE_RING_H3_PAD 1u
+
+// One wave per iteration: deal its <= 64 entries to the lanes (ring_place: bank classes split
+// evenly over the 32-lane read passes and the 16-lane write passes), pad to 64 with dummies, write
+// packed words, edge ids and the header.
 __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int32_t* __restrict__ it_ent,
                                                          const int32_t* __restrict__ it_cnt,
                                                          const int32_t* __restrict__ it_m,
@@ -288,94 +347,92 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int3
                                                          const int32_t* __restrict__ hrow,
                                                          const int32_t* __restrict__ nbr,
                                                          const int32_t* __restrict__ eid, int R, int Q, int C, int S,
-                                                         int JB, int d, uint32_t* __restrict__ packed,
+                                                         int JB, int d, int row_lo, int place,
+                                                         uint32_t* __restrict__ packed,
                                                          int32_t* __restrict__ peid, uint32_t* __restrict__ hdr) {
-  const int lane = threadIdx.x & 63;
-  const int64_t w0 = ((int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x) >> 6;
+  __shared__ RingPlaceScratch scratch[MDE_BLOCK / 64];
+  __shared__ uint8_t s_rc[MDE_BLOCK / 64][64], s_cc[MDE_BLOCK / 64][64], s_lane[MDE_BLOCK / 64][64],
+      s_free[MDE_BLOCK / 64][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t nw = ((int64_t)gridDim.x * MDE_BLOCK) >> 6;
   const uint32_t JM = (1u << JB) - 1u;
-  for (int64_t it = w0; it < nit; it += nw) {
-    const int cw = __builtin_amdgcn_readfirstlane(it_cnt[it]);  // entries | newest chunk << 8
+  const int sh = ring_cls_shift(d), cm = ring_cls_mask(d);
+  // (the waves of a block run the same number of trips: the barriers below are block-wide)
+  for (int64_t itb = (int64_t)blockIdx.x * (MDE_BLOCK / 64); itb < nit; itb += nw) {
+    const int64_t it = itb + wv;
+    const bool valid = it < nit;
+    const int cw = valid ? __builtin_amdgcn_readfirstlane(it_cnt[it]) : 0;  // entries | newest chunk << 8
     const int cnt = cw & 0xff;
-    const bool act = lane < cnt;
-    uint32_t key = 0, q = 0;
-    int rl = 0x7fffffff;
+    const bool act = valid && lane < cnt;
+    uint32_t key = 0, q = 0, col = 0, rowaddr = 0, ring = 0;
+    int grow = 0;
     if (act) {
       const int pos = it_ent[(size_t)it * 64 + lane];
       key = keys[pos];
       q = vals[pos];
       const int rb = (int)((key >> JB) / MDE_RING_NCW) / Q;
-      rl = hrow[q] - rb * R;
+      grow = hrow[q];
+      rowaddr = (uint32_t)(grow - rb * R) * 4u * (uint32_t)d;
+      const uint32_t j = key & JM;
+      col = (uint32_t)nbr[q];
+      ring = ((j % (uint32_t)S) * (uint32_t)C + (col - j * (uint32_t)C)) * 4u * (uint32_t)d;
+      s_rc[wv][lane] = (uint8_t)((rowaddr >> sh) & (uint32_t)cm);
+      s_cc[wv][lane] = (uint8_t)((ring >> sh) & (uint32_t)cm);
     }
-    const uint32_t j = key & JM;
-    int rank = 0, same = 0;
-    for (int t = 0; t < 64; ++t) {
-      const int rt = __builtin_amdgcn_readlane(rl, t);
-      rank += (rt < rl) || (rt == rl && t < lane);
-      same += (rt == rl);
-    }
-    const int run = mde_wave_max(act ? same : 0);
-    // Lane placement.  With duplicate rows the entries stay sorted by row (the kernel folds
-    // adjacent lanes).  Without (the common case) the order is free, and it is chosen for the LDS:
-    // x_v, the accumulator read and the accumulator write of a lane all go to the bank pair
-    // (row mod 32) -- rows of one residue class are dealt alternately to the two 32-lane halves
-    // (and land in different 16-lane write groups), so two rows collide only when a class holds
-    // more than two of the 64.  (Sorted by row, the 32 rows of a half hit the 32 bank pairs like
-    // random draws: 3-4 deep on the fullest one, for each of the three accesses.)
-    if (run <= 1) {
-      const int key = act ? (((rl & 31) << 16) | rl) : 0x7fffffff;
-      int r2 = 0;
-      for (int t = 0; t < 64; ++t) {
-        const int kt = __builtin_amdgcn_readlane(key, t);
-        r2 += (kt < key) || (kt == key && t < lane);
+    __syncthreads();
+    if (lane == 0 && valid) {
+      if (place) {
+        ring_place(cnt, s_rc[wv], s_cc[wv], s_lane[wv], s_free[wv], scratch[wv]);
+      } else {
+        for (int e = 0; e < 64; ++e) {
+          s_lane[wv][e] = (uint8_t)e;
+          if (e >= cnt) s_free[wv][e - cnt] = (uint8_t)e;
+        }
       }
-      // ranks 0, 1, 2, 3, ... -> lanes 0, 32, 1, 33, ...; padding (the highest ranks) fills what is left
-      if (act) rank = ((r2 & 1) << 5) | (r2 >> 1);
     }
-    // lanes not taken by an entry hold the padding: with the interleaved placement they are no
-    // longer the highest lanes, so every lane finds its own slot
-    unsigned long long taken = 0;
-    for (int t = 0; t < 64; ++t) {
-      const int rt = __builtin_amdgcn_readlane(act ? rank : -1, t);
-      if (rt >= 0) taken |= 1ull << rt;
-    }
-    int pad_lane = -1;
-    if (!act) {
-      // the (lane - cnt)-th free lane
-      unsigned long long fr = ~taken;
-      for (int k = 0; k < lane - cnt; ++k) fr &= fr - 1;
-      pad_lane = __builtin_ctzll(fr);
-    }
-    // chunk window of the iteration: the oldest chunk its stream still needs (deferred entries
-    // included) .. the newest chunk it references (entries are in stream order, chunk-major)
-    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane(it_m[it]);
+    __syncthreads();
+    // whose loss terms: the entry whose row is the smaller vertex of the edge
+    const bool counts = act && (uint32_t)(row_lo + grow) < col;
+    const int ncount = __popcll(__ballot(counts));
+    const uint32_t lclass = ncount == 0 ? 0u : (ncount == cnt ? 1u : 2u);
+    // chunk window of the iteration: the oldest chunk its stream still needs (waiting entries
+    // included) .. the newest chunk it references
+    const uint32_t m = valid ? (uint32_t)__builtin_amdgcn_readfirstlane(it_m[it]) : 0u;
     const uint32_t need = max((uint32_t)(cw >> 8), m);
     // element (iteration it, lane l) of a stream lives at ((it / 4) * 64 + l) * 4 + it % 4
     const size_t base = ((size_t)(it >> 2) * 64) * 4 + (size_t)(it & 3);
     if (act) {
-      const uint32_t col = (uint32_t)nbr[q];
-      const uint32_t ring = ((j % (uint32_t)S) * (uint32_t)C + (col - j * (uint32_t)C)) * 4u * (uint32_t)d;
-      packed[base + (size_t)rank * 4] = (((uint32_t)rl * 4u * (uint32_t)d) << 17) | ring;
-      peid[base + (size_t)rank * 4] = eid[q];
-    } else {
-      // padding: the dummy row slot, a resident column (first of chunk m)
-      packed[base + (size_t)pad_lane * 4] =
-          (((uint32_t)R * 4u * (uint32_t)d) << 17) | ((m % (uint32_t)S) * (uint32_t)C * 4u * (uint32_t)d);
-      peid[base + (size_t)pad_lane * 4] = -1;
+      const int l = s_lane[wv][lane];
+      // (the column field is the ring byte offset + 16: the kernel reads at ring base - 16 + field,
+      // which fits the 16-bit offset of the LDS instruction)
+      packed[base + (size_t)l * 4] = (rowaddr << 17) | (ring + 16u);
+      peid[base + (size_t)l * 4] = eid[q];
+    } else if (valid) {
+      // padding: a dummy row slot of the lane's own bank class, a resident column (first of chunk m)
+      const int l = s_free[wv][lane - cnt];
+      packed[base + (size_t)l * 4] = (((uint32_t)(R + (l & 31)) * 4u * (uint32_t)d) << 17) |
+                                     ((m % (uint32_t)S) * (uint32_t)C * 4u * (uint32_t)d + 16u);
+      peid[base + (size_t)l * 4] = -1;
     }
-    if (lane == 0) hdr[it] = MDE_RING_HDR(m, need - m, max(0, min(run - 1, 63)), cnt < 64);
+    if (lane == 0 && valid) {
+      hdr[MDE_RING_HW * it] = m;
+      hdr[MDE_RING_HW * it + 1] = need;
+      hdr[MDE_RING_HW * it + 2] = lclass;
+      hdr[MDE_RING_HW * it + 3] = cnt < 64 ? MDE_RING_H3_PAD : 0u;
+    }
+    __syncthreads();
   }
 }
 
-// stats[0] = iterations with fold rounds, stats[1] = iterations with padding, stats[2] = sum of rounds
+// stats[0] = iterations with padding, stats[1] = iterations that add loss terms for every entry,
+// stats[2] = iterations with the per-lane loss test
 __global__ __launch_bounds__(MDE_BLOCK) void k_ring_stats(int64_t nit, const uint32_t* __restrict__ hdr,
                                                           unsigned long long* __restrict__ stats) {
   unsigned long long a = 0, b = 0, c = 0;
   for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < nit; i += (int64_t)gridDim.x * MDE_BLOCK) {
-    const uint32_t h = hdr[i];
-    a += ((h >> 21) & 63u) != 0;
-    b += (h >> 27) & 1u;
-    c += (h >> 21) & 63u;
+    a += hdr[MDE_RING_HW * i + 3] & MDE_RING_H3_PAD;
+    b += hdr[MDE_RING_HW * i + 2] == 1u;
+    c += hdr[MDE_RING_HW * i + 2] == 2u;
   }
   a = mde_wave_sum(a);
   b = mde_wave_sum(b);
@@ -417,7 +474,7 @@ static bool choose_sizes(const mde_plan* plan, int d, RingSizes* z) {
   int64_t pr = (plan->n + 255) / 256;
   if (pr > nloc) pr = nloc;
   pr = ((pr + 63) / 64) * 64;
-  const int64_t pr_max = ((MDE_RING_CTRL_OFF - 4 * d) / (4 * d)) / 64 * 64;
+  const int64_t pr_max = (MDE_RING_CTRL_OFF / (4 * d) - 32) / 64 * 64;  // 32 dummy row slots for padding lanes
   if (pr > pr_max) pr = pr_max;
   const int C = ring_chunk_cols(d);
   const int64_t nc = (plan->n + C - 1) / C;
@@ -517,8 +574,13 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
                      z.JB, keys2, seg);
   RB(hipGetLastError());
   RB(hipMemsetAsync(iters, 0, ((size_t)nseg + 1) * sizeof(int32_t), st));
-  hipLaunchKernelGGL(k_ring_schedule<false>, dim3(nseg), dim3(64), 0, st, nseg, seg, bounds, keys2, vals2, hrow, JM,
-                     ring_max_span(d), z.R, z.Q, z.NC, iters, nullptr, nullptr, nullptr, nullptr);
+  // bank-class cap of the scheduler and the lane placement (environment: design ablations only)
+  const int cap_default = d == 4 ? 8 : 4;
+  const int cap = getenv("MDE_RING_CAP") ? std::max(1, atoi(getenv("MDE_RING_CAP"))) : cap_default;
+  const int place = getenv("MDE_RING_PLACE") ? atoi(getenv("MDE_RING_PLACE")) : 1;
+  const int span = getenv("MDE_RING_SPAN") ? std::min(ring_max_span(d), std::max(1, atoi(getenv("MDE_RING_SPAN")))) : ring_max_span(d);
+  hipLaunchKernelGGL(k_ring_schedule<false>, dim3(nseg), dim3(64), 0, st, nseg, seg, bounds, keys2, vals2, hrow, plan->nbr,
+                     JM, span, z.R, z.Q, z.NC, d, cap, iters, nullptr, nullptr, nullptr, nullptr);
   RB(hipGetLastError());
   RB(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, iters, iter_base, nseg + 1, st));
   int32_t total_iters = 0;
@@ -529,19 +591,24 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     release(true);
     return 0;  // too large for 32-bit positions: the caller keeps the CSR layout
   }
+  if (panel_mode() != 1 && (double)Hp > 1.35 * (double)H) {
+    // distinct rows per iteration cost too much padding on this graph (hub rows): CSR kernel
+    release(true);
+    return 0;
+  }
   RB(hipMalloc(&it_ent, (size_t)total_iters * 64 * sizeof(int32_t)));
   RB(hipMalloc(&it_cnt, (size_t)total_iters * sizeof(int32_t)));
   RB(hipMalloc(&it_m, (size_t)total_iters * sizeof(int32_t)));
   RB(hipMalloc(&packed, (size_t)Hp * sizeof(uint32_t)));
   RB(hipMalloc(&peid, (size_t)Hp * sizeof(int32_t)));
-  RB(hipMalloc(&hdr, (size_t)total_iters * sizeof(uint32_t)));
+  RB(hipMalloc(&hdr, (size_t)total_iters * MDE_RING_HW * sizeof(uint32_t)));
   if (z.Q > 1) RB(hipMalloc(&partial, sizeof(float) * (size_t)z.Q * (size_t)nloc * (size_t)d));
-  hipLaunchKernelGGL(k_ring_schedule<true>, dim3(nseg), dim3(64), 0, st, nseg, seg, bounds, keys2, vals2, hrow, JM,
-                     ring_max_span(d), z.R, z.Q, z.NC, nullptr, iter_base, it_ent, it_cnt, it_m);
+  hipLaunchKernelGGL(k_ring_schedule<true>, dim3(nseg), dim3(64), 0, st, nseg, seg, bounds, keys2, vals2, hrow, plan->nbr,
+                     JM, span, z.R, z.Q, z.NC, d, cap, nullptr, iter_base, it_ent, it_cnt, it_m);
   RB(hipGetLastError());
   hipLaunchKernelGGL(k_ring_pack, dim3(mde_grid((int64_t)total_iters * 64, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st,
                      (int64_t)total_iters, it_ent, it_cnt, it_m, keys2, vals2, hrow, plan->nbr, plan->eid, z.R, z.Q, z.C,
-                     z.S, z.JB, d, packed, peid, hdr);
+                     z.S, z.JB, d, (int)plan->row_lo, place, packed, peid, hdr);
   RB(hipGetLastError());
   RB(hipStreamSynchronize(st));
   if (getenv("MDE_RING_STATS")) {
@@ -551,10 +618,11 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     hipLaunchKernelGGL(k_ring_stats, dim3(256), dim3(MDE_BLOCK), 0, st, (int64_t)total_iters, hdr, dstat);
     RB(hipMemcpyAsync(hstat, dstat, sizeof(hstat), hipMemcpyDeviceToHost, st));
     RB(hipStreamSynchronize(st));
-    fprintf(stderr, "[mde ring] d=%d R=%d NRB=%d Q=%d chunks=%d x %d cols, %d iterations for %lld half-edges (%.1f%% padding), "
-            "%.1f%% with fold rounds (mean %.2f), %.1f%% with padding lanes\n", d, z.R, z.NRB, z.Q, z.NC, z.C, total_iters,
-            (long long)H, 100.0 * ((double)Hp - (double)H) / (double)H, 100.0 * hstat[0] / total_iters,
-            hstat[0] ? (double)hstat[2] / hstat[0] : 0.0, 100.0 * hstat[1] / total_iters);
+    fprintf(stderr, "[mde ring] d=%d R=%d NRB=%d Q=%d chunks=%d x %d cols, window %d, cap %d, placement %d: %d iterations for %lld half-edges "
+            "(%.1f%% padding), %.1f%% with padding lanes; loss terms: %.1f%% of the iterations add all, %.2f%% test per lane\n",
+            d, z.R, z.NRB, z.Q, z.NC, z.C, span, cap, place, total_iters, (long long)H,
+            100.0 * ((double)Hp - (double)H) / (double)H, 100.0 * hstat[0] / total_iters, 100.0 * hstat[1] / total_iters,
+            100.0 * hstat[2] / total_iters);
   }
 #undef RB
   release(false);
@@ -583,7 +651,10 @@ extern "C" int mde_plan_layout(mde_plan* plan, int32_t d, void* stream) {
   if (plan->ring.packed && plan->ring.d == d) return 1;
   RingSizes z;
   if (!choose_sizes(plan, d, &z)) return 0;
-  return build_ring(plan, d, mde_stream(stream));
+  if (plan->ring.rejected_d == d && panel_mode() != 1) return 0;
+  const int rc = build_ring(plan, d, mde_stream(stream));
+  if (rc == 0) plan->ring.rejected_d = d;
+  return rc;
 }
 
 __global__ __launch_bounds__(MDE_BLOCK) void k_expand_ring(int64_t H, const int32_t* __restrict__ eid,
@@ -709,6 +780,12 @@ extern "C" int mde_plan_expand_codebook(const mde_plan* plan, const float* in_ed
   for (int s = 1; s < MDE_RING_CB_VALUES; ++s)
     if (host_tb[s] != MDE_CB_EMPTY) vals[1 + nv++] = host_tb[s];
   if (nv == 0) return MDE_OK;
+  // (finite values only: the kernel skips the NaN/Inf fix-up of f'/d for codebook streams)
+  for (int s = 1; s <= nv; ++s) {
+    float fv;
+    memcpy(&fv, &vals[s], sizeof(float));
+    if (!std::isfinite(fv)) return MDE_OK;
+  }
   for (int a = 2; a <= nv; ++a)
     for (int b = a; b > 1 && vals[b - 1] > vals[b]; --b) {
       const unsigned int t = vals[b];
@@ -837,27 +914,34 @@ __device__ __forceinline__ int ring_ctrl_load(uint32_t addr) {
   return v;
 }
 
+#if MDE_RING_ABLATE
+// timing probes (MDE_RING_DBG & 512): per workgroup, shader clocks summed over its waves
+//   [0] consumer loop, [1] of it inside the chunk poll, [2] poll trips, [3] producer loop,
+//   [4] of it blocked on a slot, [5] of it waiting for DMA pieces to land, [6] slot polls
+__device__ unsigned long long g_ring_probe[8][1024];
+#define RING_CLK() __builtin_readcyclecounter()
+#endif
 // CB: the first parameter comes from a codebook -- `packed` is the stream with value indices in its
 // 3 low bits (mde_plan_expand_codebook), a0 the 8-entry value table; no parameter stream is read.
-// LIN: f is proportional to its first parameter (the penalties instantiated below): padding lanes
-// carry weight 0 and need no masking, so a padded iteration without duplicate rows stays on the
-// fast path.
+// LIN: f(0) = 0 whatever the lane's parameter is once that parameter is 0 (the functors
+// instantiated below): padding lanes carry parameter 0, sit on a dummy row and need no masking.
+// The loss term of an edge is added on ONE of its two entries (the one whose row is the smaller
+// vertex; header word 1 says, per iteration, none / all / test per lane), so half of the
+// iterations skip the loss arithmetic altogether; the gradient is owner-computes as before.
 template <int D, class Fn, bool HAS_GRAD, bool CB, bool LIN>
 __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     int nloc, int row_lo, int n, int R, int Q, int NC, const int32_t* __restrict__ wave_iter,
     const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ packed, const float* __restrict__ a0,
     const float* __restrict__ a1, int a0_scalar, int a1_scalar, const float* __restrict__ X,
     float* __restrict__ grad, float* __restrict__ partial, double* __restrict__ loss_partials, Fn fn,
-    float inv_p, float grad_scale, float* __restrict__ loss_out, double loss_scale, int dbg_arg) {
+    float fix_value, float grad_scale, float* __restrict__ loss_out, double loss_scale, int dbg_arg) {
 #if MDE_RING_ABLATE
   const int dbg = dbg_arg;  // timing probes (tools/abl.sh): 1 consumers never wait, 2 no staging, 4 no evaluation, 8 producers never wait, 64 / 128 a role skips its loop
+  const unsigned long long t_begin = __builtin_readcyclecounter();
 #else
   constexpr int dbg = 0;
 #endif
-#if MDE_RING_ABLATE
-  const unsigned long long t_begin = __builtin_readcyclecounter();
-#endif
-  constexpr int BS = MDE_RING_BS, NCW = MDE_RING_NCW, NPROD = MDE_RING_NPROD, PF = MDE_RING_PF;
+  constexpr int BS = MDE_RING_BS, NCW = MDE_RING_NCW, NPROD = MDE_RING_NPROD;
   constexpr int GR_OFF = MDE_RING_GR_OFF, RING_OFF = MDE_RING_OFF;
   constexpr int C = ring_chunk_cols(D), CBYTES = ring_chunk_bytes(D), S = ring_slots(D), PIECES = CBYTES / 1024;
   // statically sized: the LDS addresses unpacked from the stream are absolute
@@ -873,7 +957,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
   const int j_lo = (int)(((int64_t)qg * NC + Q - 1) / Q), j_hi = (int)(((int64_t)(qg + 1) * NC + Q - 1) / Q);
   const int r0 = rb * R;
   const int nr = min(R, nloc - r0);
-  const uint32_t dummy_row = (uint32_t)R * 4u * (uint32_t)D;
+  const uint32_t dummy_row = (uint32_t)R * 4u * (uint32_t)D;  // the padding lanes' row slots start here
   const float a0s = (a0_scalar && !CB) ? a0[0] : 1.0f;
   const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
   const bool a1_arr = a1 && !a1_scalar;
@@ -898,48 +982,70 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     } else {
       for (int i = tid; i < nr * D; i += BS) XR[i] = Xrow[i];
     }
-    if (tid < D) XR[R * D + tid] = 0.0f;  // the dummy row
+    if (tid < 32 * D) XR[R * D + tid] = 0.0f;  // the dummy rows
     if (tid < 16) prog[tid] = (tid < NCW) ? j_lo : MDE_RING_DONE;
-    if (tid >= 16 && tid < 16 + NPROD) F[tid - 16] = j_lo + (tid - 16);
+    if (tid >= 16 && tid < 16 + NPROD) F[tid - 16] = MDE_RING_COOP ? j_lo : j_lo + (tid - 16);
     if (CB && tid >= 32 && tid < 32 + MDE_RING_CB_VALUES)
-      reinterpret_cast<float*>(L + MDE_RING_CTRL_CB)[tid - 32] = a0[tid - 32];
+      reinterpret_cast<float*>(L + MDE_RING_CTRL_CB)[tid - 32] = a0[tid - 32] * Fn::kParamScale;
   }
   __syncthreads();
   // No compiler-counted load may be pending past this point: the producers' LDS-DMA pieces are
   // invisible to hipcc's vmcnt bookkeeping, and a wait it inserts for one of ITS loads (or for
   // re-using such a load's destination register) would drain the pieces in flight with it.
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-  float loss = 0.0f;
+  float loss = 0.0f, loss2 = 0.0f;  // (the fused Log1p path keeps the log2 terms and the corrections apart)
 
   if (wave >= NCW) {
-    // ---------------- producer p: chunks j_lo + p, j_lo + p + NPROD, ...
+    __builtin_amdgcn_s_setprio(MDE_RING_PRODPRIO);  // the DMA issue ahead of the consumers' instructions (-2.5 %)
+#if MDE_RING_COOP
+    // ---------------- producer p: pieces p, p + NPROD, ... of EVERY chunk.  (Two producers that
+    // alternate whole chunks spend ~650 clocks per chunk on the eight DMA instructions alone once
+    // the consumers are running -- tools/r3_probe.sh: staging then takes 0.21 ms and everything
+    // waits for it.  Striping the pieces over four waves quarters the issue work per wave, lands a
+    // chunk four times sooner and keeps only DEPTH chunks of the ring in flight.)
     const int p = wave - NCW;
+    constexpr int PPW = PIECES / NPROD;  // pieces per producer and chunk
+    static_assert(PIECES % NPROD == 0 && PPW >= 1 && PPW <= 4, "a producer moves 1..4 pieces of every chunk");
     const char* Xb = reinterpret_cast<const char*>(X);
-    const char* Xl = Xb + lane * 16;
+    const char* Xl = Xb + lane * 16 + (size_t)p * PPW * 1024;
     const size_t nbytes = (size_t)n * D * 4;
     const size_t last16 = nbytes - 16;
     int minprog = j_lo, infl = 0;
-    int slot = (j_lo + p) % S;
-    int j = j_lo + p;         // next chunk to issue
+    int slot = j_lo % S;
+    int j = j_lo;             // next chunk to issue
     int oldest = j;           // oldest chunk in flight (valid while infl > 0)
-    // wait for the oldest chunk in flight and publish it (F[p] = my next chunk that has not landed)
+#if MDE_RING_ABLATE
+    unsigned long long pr_t0 = RING_CLK(), pr_blocked = 0, pr_retire = 0, pr_polls = 0;
+#endif
+    // wait for my pieces of the oldest chunk in flight and publish it (F[p] = first chunk whose
+    // pieces of mine have not landed)
     auto retire = [&]() __attribute__((always_inline)) {
+#if MDE_RING_ABLATE
+      const unsigned long long tr0 = RING_CLK();
+#endif
       if (infl == 4)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * 3) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * 3) : "memory");
       else if (infl == 3)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * 2) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * 2) : "memory");
       else if (infl == 2)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      oldest += NPROD;
+      ++oldest;
       ring_ctrl_store(MDE_RING_CTRL_F + 4u * (uint32_t)p, oldest);
       --infl;
+#if MDE_RING_ABLATE
+      pr_retire += RING_CLK() - tr0;
+#endif
     };
     static_assert(MDE_RING_DEPTH >= 1 && MDE_RING_DEPTH <= 4, "retire() spells out the wait counts of up to four chunks in flight");
     while (j < j_hi && !(dbg & 128)) {
       // slot j % S still holds chunk j - S until every consumer is past it
       if (j - S >= minprog && !(dbg & 8)) {
+#if MDE_RING_ABLATE
+        const unsigned long long tb0 = RING_CLK();
+        ++pr_polls;
+#endif
         // one LDS read (lane w = consumer w), then a scalar minimum over the consumers' lanes
         const int v = ring_ctrl_load(MDE_RING_CTRL_PROG + 4u * (uint32_t)(lane & 15));
         int mn = __builtin_amdgcn_readlane(v, 0);
@@ -952,8 +1058,116 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
             retire();
           else
             __builtin_amdgcn_s_sleep(1);
+#if MDE_RING_ABLATE
+          pr_blocked += RING_CLK() - tb0;
+#endif
           continue;
         }
+#if MDE_RING_ABLATE
+        pr_blocked += RING_CLK() - tb0;
+#endif
+      }
+      const uint32_t dst = (uint32_t)RING_OFF + (uint32_t)slot * (uint32_t)CBYTES + (uint32_t)p * (uint32_t)(PPW * 1024);
+      if (!(dbg & 2)) {
+        if (j != NC - 1) {
+          // my PPW consecutive 1 KiB pieces in one statement: the instruction offset advances the
+          // global and the LDS address together
+          ring_dma_pieces<PPW>(Xl + (size_t)j * CBYTES, dst);
+        } else {
+          // the table's last chunk: lanes whose 16 bytes would cross its end load a clamped address
+          const size_t off0 = (size_t)j * CBYTES + (size_t)p * PPW * 1024 + (size_t)lane * 16;
+#pragma unroll
+          for (int k = 0; k < PPW; ++k) {
+            const size_t off = off0 + (size_t)k * 1024;
+            ring_dma_pieces<1>(Xb + (off < last16 ? off : last16), dst + (uint32_t)k * 1024u);
+          }
+        }
+      }
+      if (infl == 0) oldest = j;
+      ++infl;
+      ++j;
+      ++slot;
+      slot = slot >= S ? slot - S : slot;
+      if (infl == MDE_RING_DEPTH) retire();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // when the table is not a multiple of 16 bytes its final dwords are put in place by hand, by
+    // the producer whose piece they sit in, before that producer reports the last chunk
+    if ((nbytes & 15) && (NC - 1) >= j_lo && (NC - 1) < j_hi) {
+      const size_t tail0 = nbytes & ~(size_t)15;
+      const int tail_piece = (int)((tail0 - (size_t)(NC - 1) * CBYTES) >> 10);
+      if (tail_piece / PPW == p) {
+        const int nt = (int)((nbytes - tail0) >> 2);
+        if (lane < nt) {
+          const size_t off = tail0 + (size_t)lane * 4 - (size_t)(NC - 1) * CBYTES;
+          *reinterpret_cast<float*>(L + RING_OFF + ((NC - 1) % S) * CBYTES + off) =
+              *reinterpret_cast<const float*>(Xb + tail0 + (size_t)lane * 4);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+    }
+#else
+    // ---------------- producer p: chunks j_lo + p, j_lo + p + NPROD, ...
+    const int p = wave - NCW;
+    const char* Xb = reinterpret_cast<const char*>(X);
+    const char* Xl = Xb + lane * 16;
+    const size_t nbytes = (size_t)n * D * 4;
+    const size_t last16 = nbytes - 16;
+    int minprog = j_lo, infl = 0;
+    int slot = (j_lo + p) % S;
+    int j = j_lo + p;         // next chunk to issue
+    int oldest = j;           // oldest chunk in flight (valid while infl > 0)
+    // wait for the oldest chunk in flight and publish it (F[p] = my next chunk that has not landed)
+#if MDE_RING_ABLATE
+    unsigned long long pr_t0 = RING_CLK(), pr_blocked = 0, pr_retire = 0, pr_polls = 0;
+#endif
+    auto retire = [&]() __attribute__((always_inline)) {
+#if MDE_RING_ABLATE
+      const unsigned long long tr0 = RING_CLK();
+#endif
+      if (infl == 4)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * 3) : "memory");
+      else if (infl == 3)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * 2) : "memory");
+      else if (infl == 2)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      oldest += NPROD;
+      ring_ctrl_store(MDE_RING_CTRL_F + 4u * (uint32_t)p, oldest);
+      --infl;
+#if MDE_RING_ABLATE
+      pr_retire += RING_CLK() - tr0;
+#endif
+    };
+    static_assert(MDE_RING_DEPTH >= 1 && MDE_RING_DEPTH <= 4, "retire() spells out the wait counts of up to four chunks in flight");
+    while (j < j_hi && !(dbg & 128)) {
+      // slot j % S still holds chunk j - S until every consumer is past it
+      if (j - S >= minprog && !(dbg & 8)) {
+#if MDE_RING_ABLATE
+        const unsigned long long tb0 = RING_CLK();
+        ++pr_polls;
+#endif
+        // one LDS read (lane w = consumer w), then a scalar minimum over the consumers' lanes
+        const int v = ring_ctrl_load(MDE_RING_CTRL_PROG + 4u * (uint32_t)(lane & 15));
+        int mn = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+        for (int w = 1; w < NCW; ++w) mn = min(mn, __builtin_amdgcn_readlane(v, w));
+        minprog = mn;
+        if (j - S >= minprog) {
+          // blocked: meanwhile publish what has landed (a consumer may be waiting for exactly that)
+          if (infl > 0)
+            retire();
+          else
+            __builtin_amdgcn_s_sleep(1);
+#if MDE_RING_ABLATE
+          pr_blocked += RING_CLK() - tb0;
+#endif
+          continue;
+        }
+#if MDE_RING_ABLATE
+        pr_blocked += RING_CLK() - tb0;
+#endif
       }
       const uint32_t dst = (uint32_t)RING_OFF + (uint32_t)slot * (uint32_t)CBYTES;
       if (!(dbg & 2)) {
@@ -1000,7 +1214,16 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+#endif
     ring_ctrl_store(MDE_RING_CTRL_F + 4u * (uint32_t)p, MDE_RING_DONE);
+#if MDE_RING_ABLATE
+    if ((dbg & 512) && lane == 0 && blockIdx.x < 1024) {
+      atomicAdd(&g_ring_probe[3][blockIdx.x], RING_CLK() - pr_t0);
+      atomicAdd(&g_ring_probe[4][blockIdx.x], pr_blocked);
+      atomicAdd(&g_ring_probe[5][blockIdx.x], pr_retire);
+      atomicAdd(&g_ring_probe[6][blockIdx.x], pr_polls);
+    }
+#endif
   } else {
     // ---------------- consumer: my contiguous stream of wave iterations, 4 per block
     const int ib = __builtin_amdgcn_readfirstlane(wave_iter[blockIdx.x * NCW + wave]);
@@ -1008,63 +1231,54 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     if (NB > 0 && !(dbg & 64)) {
       const bool a0_arr = !a0_scalar && !CB;
       const ring_u4* sp = reinterpret_cast<const ring_u4*>(packed) + (size_t)(ib >> 2) * 64 + lane;
-      const ring_u4* hp = reinterpret_cast<const ring_u4*>(hdr) + (ib >> 2);
+      const ring_u4* hp = reinterpret_cast<const ring_u4*>(hdr) + (size_t)ib;  // one 4-word header per iteration
       const ring_f4* ap = reinterpret_cast<const ring_f4*>(a0_arr ? a0 : reinterpret_cast<const float*>(packed)) +
                           (size_t)(ib >> 2) * 64 + lane;
       const int lastb = NB - 1;
       // Three blocks (12 iterations) of packed words, parameters and headers in flight.  All
-      // stream loads are issued from ONE place (the refill after a block is consumed; the first
-      // trip of the loop below only fills), unconditional and clamped, never predicated: on every
-      // path the same loads are in flight when a block is consumed, so the compiler's vmcnt
-      // counts are exact and nothing waits for a load just issued.  The four headers of a block
-      // come with one scalar load (uniform address).
-      ring_u4 pq[3] = {}, hq[3] = {};
+      // stream loads are issued from ONE place (the refill after a block is consumed),
+      // unconditional and clamped, never predicated: on every path the same loads are in flight
+      // when a block is consumed, so the compiler's vmcnt counts are exact and nothing waits for a
+      // load just issued.  The headers of a block come with two scalar loads (uniform address).
+      ring_u4 pq[3] = {}, hq[3][4] = {};
       ring_f4 wq[3] = {};
       auto load_block = [&](int u, int b) __attribute__((always_inline)) {
         const int bc = min(b, lastb);
-        pq[u] = sp[(size_t)bc * 64];
-        hq[u] = hp[bc];
+        pq[u] = sp[(size_t)((dbg & 1024) ? (bc & 7) : bc) * 64];  // (probe: packed words from L2, real headers)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) hq[u][k] = hp[(size_t)bc * 4 + k];
         if (!CB) wq[u] = ap[(size_t)bc * 64];
       };
-      int ready = j_lo, published = j_lo;
+      int ready = j_lo;
+#if MDE_RING_ABLATE
+      unsigned long long cs_t0 = RING_CLK(), cs_poll = 0, cs_trips = 0;
+#endif
 
-      // the LDS operands of an iteration (x_v, x_u, parameter); the accumulator read of the fast
-      // path is issued right behind them, before the function is evaluated.  (Reading iteration
-      // k + 1 ahead of evaluating k, and evaluating two iterations together, were measured: no
-      // gain -- what they hide in latency they take from the ring's slack.)
+      // the LDS operands of an entry: x_v, x_u, the parameter
       struct Pre {
         float xr[D], xc[D], p0;
       };
-      auto pre_read = [&](uint32_t w, float p0) __attribute__((always_inline)) {
+      auto issue_x = [&](uint32_t w, float p0) __attribute__((always_inline)) {
         Pre r;
-        const uint32_t rowaddr = w >> 17, coladdr = w & (CB ? 0x1fff8u : 0x1ffffu);
-        r.p0 = CB ? *reinterpret_cast<const float*>(L + MDE_RING_CTRL_CB + ((w & 7u) << 2)) : p0;
+        const uint32_t rowaddr = w >> 17, colf = w & (CB ? 0x1fff8u : 0x1ffffu);
+        r.p0 = CB ? *reinterpret_cast<const float*>(L + MDE_RING_CTRL_CB + ((w & 7u) << 2)) : p0 * Fn::kParamScale;
         ring_ld<D>(L + rowaddr, r.xr);
-        ring_ld<D>(L + RING_OFF + coladdr, r.xc);
+        ring_ld<D>(L + (RING_OFF - 16) + colf, r.xc);  // (the field carries + 16: the base fits the instruction offset)
         return r;
       };
-      // common case: no duplicate rows (padding lanes carry weight 0 when LIN) -- every lane
-      // updates its own row
-      auto process_fast = [&](uint32_t w, const Pre& x, float p1) __attribute__((always_inline)) {
-        const uint32_t rowaddr = w >> 17;
-        float acc[D], v[D], ss = 0.0f;
-        if (HAS_GRAD) ring_ld<D>(L + GR_OFF + rowaddr, acc);
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-          v[c] = x.xr[c] - x.xc[c];
-          ss = fmaf(v[c], v[c], ss);
-        }
-        float f, gd;
-        fn.eval(ss, x.p0, p1, f, gd);
-        const float g = mde_fix_g(gd * inv_p);
-        loss += f;
-        if (!HAS_GRAD) return;
-#pragma unroll
-        for (int c = 0; c < D; ++c) acc[c] = fmaf(v[c], g, acc[c]);
-        ring_st<D>(L + GR_OFF + rowaddr, acc);
+      // this entry adds the loss term iff its row is the smaller vertex (iterations around the diagonal)
+      auto counts_here = [&](uint32_t w, uint32_t hm) __attribute__((always_inline)) {
+        const uint32_t off = (w & 0x1ffffu) - 16u;
+        const uint32_t slot = off / (uint32_t)CBYTES, cidx = (off - slot * (uint32_t)CBYTES) / (4u * (uint32_t)D);
+        const uint32_t ms = hm % (uint32_t)S;
+        const uint32_t j = hm + (slot >= ms ? slot - ms : slot + (uint32_t)S - ms);
+        const uint32_t u = j * (uint32_t)C + cidx;
+        const uint32_t vv = (uint32_t)(row_lo + r0) + (w >> 17) / (4u * (uint32_t)D);
+        return vv < u;
       };
-      // duplicate rows and / or padding lanes that need masking
-      auto process_slow = [&](uint32_t w, const Pre& x, float p1, int rounds) __attribute__((always_inline)) {
+      // evaluate the entry and add its gradient term to the row's accumulator (read earlier)
+      auto finish = [&](uint32_t w, const Pre& x, float (&acc)[D], float p1, uint32_t hm, uint32_t lcls)
+          __attribute__((always_inline)) {
         const uint32_t rowaddr = w >> 17;
         float v[D], ss = 0.0f;
 #pragma unroll
@@ -1072,85 +1286,120 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           v[c] = x.xr[c] - x.xc[c];
           ss = fmaf(v[c], v[c], ss);
         }
-        float f, gd;
-        fn.eval(ss, x.p0, p1, f, gd);
-        const float g = mde_fix_g(gd * inv_p);
-        loss += (rowaddr != dummy_row) ? f : 0.0f;
-        if (!HAS_GRAD) return;
-#pragma unroll
-        for (int c = 0; c < D; ++c) v[c] *= g;
-        // The 64 entries are sorted by row: equal rows are adjacent lanes.  Round r adds the
-        // ORIGINAL contribution of lane i - r when it has the same row (keys / values shifted one
-        // lane per round with DPP wave_shr:1); the last lane of each run then holds the run's sum
-        // and performs the single read-add-write of the row.
-        const int key = (int)rowaddr;
-        int kc = key;
-        float sv[D];
-#pragma unroll
-        for (int c = 0; c < D; ++c) sv[c] = v[c];
-#pragma nounroll
-        for (int r = 0; r < rounds; ++r) {
-          kc = __builtin_amdgcn_update_dpp(-1, kc, 0x138, 0xf, 0xf, false);
-          const bool same = (kc == key);
-#pragma unroll
-          for (int c = 0; c < D; ++c) {
-            sv[c] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sv[c]), 0x138, 0xf, 0xf, false));
-            v[c] += same ? sv[c] : 0.0f;
+        float gd;
+        if constexpr (Fn::kRingFused) {
+          // Log1p, exponent 1.5 (mde_functions.h, MDE_F_LOG1P): x.p0 = 1.5 w.  Two square roots and
+          // one reciprocal; r stays finite at d = 0, where v = 0 anyway.
+          const float d = mde_sqrt(ss), sd = mde_sqrt(d);
+          const float t = fmaf(d, sd, 1.0f);
+          const float r = mde_rcp(fmaf(sd, t, 1.0e-30f));
+          gd = x.p0 * r;
+          if (lcls != 0u) {
+            // w log1p(u) = w ln2 log2(t) + (w / t) (u - (t - 1)), 1 / t = sqrt(d) r: the two sums are
+            // kept apart and combined (with 1 / 1.5) once per wave
+            const float c = d * sd - (t - 1.0f);
+            float wl = x.p0, gc = gd;
+            if (lcls == 2u) {
+              const bool here = counts_here(w, hm);
+              wl = here ? wl : 0.0f;
+              gc = here ? gc : 0.0f;
+            }
+            loss = fmaf(wl, mde_log2(t), loss);
+            loss2 = fmaf(gc, sd * c, loss2);
           }
+        } else if (lcls == 0u) {
+          float f;  // (unused: the loss arithmetic is dead code on this path)
+          fn.eval(ss, x.p0, p1, f, gd);
+        } else {
+          float f;
+          fn.eval(ss, x.p0, p1, f, gd);
+          if (!LIN) f = (rowaddr < dummy_row) ? f : 0.0f;
+          if (lcls == 2u) f = counts_here(w, hm) ? f : 0.0f;
+          loss += f;
         }
-        const int knext = __builtin_amdgcn_update_dpp(-1, key, 0x130, 0xf, 0xf, false);  // wave_shl:1
-        if (knext != key) {
-          float acc[D];
-          ring_ld<D>(L + GR_OFF + rowaddr, acc);
+        if (!HAS_GRAD) return;
+        // (codebook values are finite -- mde_plan_expand_codebook refuses others)
+        const float g = (Fn::kFiniteG && CB) ? gd : mde_fix_g_to(gd, fix_value);
 #pragma unroll
-          for (int c = 0; c < D; ++c) acc[c] += v[c];
-          ring_st<D>(L + GR_OFF + rowaddr, acc);
-        }
+        for (int c = 0; c < D; ++c) acc[c] = fmaf(v[c], g, acc[c]);
+        ring_st<D>(L + GR_OFF + rowaddr, acc);
       };
-      // make the chunks of the iteration with header h resident (and tell the producers what
-      // this wave no longer needs)
-      auto sync_for = [&](uint32_t h) __attribute__((always_inline)) {
-        const int m = (int)(h & 0xffffu), need = m + (int)((h >> 16) & 31u);
-        if (m != published) {
-          // (every read of chunks < m has been issued, and the LDS executes in order)
-          ring_ctrl_store(MDE_RING_CTRL_PROG + 4u * (uint32_t)wave, m);
-          published = m;
-        }
+      const uint32_t prog_addr = MDE_RING_CTRL_PROG + 4u * (uint32_t)wave;
+      auto sync_for = [&](uint32_t hm, uint32_t hneed) __attribute__((always_inline)) {
+        const int m = (int)hm, need = (int)hneed;
+        // (every read of chunks < m has been issued, and the LDS executes in order; m never
+        // decreases along a stream, so it is simply stored every time)
+        ring_ctrl_store(prog_addr, m);
         if (need >= ready && !(dbg & 1)) {
+#if MDE_RING_ABLATE
+          const unsigned long long tp0 = RING_CLK();
+#endif
           for (;;) {
-            const int fl = ring_ctrl_load(MDE_RING_CTRL_F + 4u * (uint32_t)(lane & 1));
-            ready = min(__builtin_amdgcn_readlane(fl, 0), __builtin_amdgcn_readlane(fl, 1));
+            const int fl = ring_ctrl_load(MDE_RING_CTRL_F + 4u * (uint32_t)min(lane, NPROD - 1));
+            ready = __builtin_amdgcn_readlane(fl, 0);
+#pragma unroll
+            for (int pp = 1; pp < NPROD; ++pp) ready = min(ready, __builtin_amdgcn_readlane(fl, pp));
+#if MDE_RING_ABLATE
+            ++cs_trips;
+#endif
             if (need < ready) break;
             __builtin_amdgcn_s_sleep(1);
           }
+#if MDE_RING_ABLATE
+          cs_poll += RING_CLK() - tp0;
+#endif
           asm volatile("" ::: "memory");
         }
       };
+      auto hword = [&](int u, int q, int k) __attribute__((always_inline)) {  // header word k of iteration q of block u
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)hq[u][q][k]);
+      };
 
-      // one iteration at a time: hand-shake for its own chunks, read, evaluate, update
-      for (int base = -3; base < NB; base += 3) {
+      // Software pipeline, one iteration deep: while iteration k is evaluated the operands of k + 1
+      // (x_v, x_u, parameter -- after the hand-shake for ITS chunks) are already on their way; the
+      // accumulator of k + 1 is read right behind the write of k (the LDS executes a wave's
+      // accesses in order, so a row shared by consecutive iterations sees the update).
+      load_block(0, 0);
+      load_block(1, 1);
+      load_block(2, 2);
+      sync_for(hword(0, 0, 0), hword(0, 0, 1));
+      Pre x = issue_x(pq[0][0], (a0_scalar || CB) ? a0s : wq[0][0]);
+      float acc[D];
+      if (HAS_GRAD) ring_ld<D>(L + GR_OFF + (pq[0][0] >> 17), acc);
+      for (int base = 0; base < NB; base += 3) {
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           const int b = base + u;
-          if (b >= 0 && b < NB) {
+          if (b < NB) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const uint32_t h = (uint32_t)__builtin_amdgcn_readfirstlane((int)hq[u][q]);
-              sync_for(h);
-              const Pre x = pre_read(pq[u][q], (a0_scalar || CB) ? a0s : wq[u][q]);
+              const int un = q < 3 ? u : (u + 1) % 3, qn = q < 3 ? q + 1 : 0;
+              // (past the end of the stream "next" is a copy of the last block: resident chunks,
+              // harmless reads, nothing published)
+              const uint32_t wn = pq[un][qn];
+              sync_for(hword(un, qn, 0), hword(un, qn, 1));
+              const Pre xn = issue_x(wn, (a0_scalar || CB) ? a0s : wq[un][qn]);
               const float p1 = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q] : a1s;
-              if (dbg & 4)
-                loss += __uint_as_float(pq[u][q]) * 0.0f + x.xr[0] * 0.0f;
-              else if ((h >> 21) & (LIN ? 0x3fu : 0x7fu))
-                process_slow(pq[u][q], x, p1, (int)((h >> 21) & 63u));
+              if (!(dbg & 4))
+                finish(pq[u][q], x, acc, p1, hword(u, q, 0), hword(u, q, 2));
               else
-                process_fast(pq[u][q], x, p1);
+                loss += __uint_as_float(pq[u][q]) * 0.0f + x.xr[0] * 0.0f;
+              if (HAS_GRAD) ring_ld<D>(L + GR_OFF + (wn >> 17), acc);
+              x = xn;
             }
           }
           load_block(u, b + 3);
         }
       }
+#if MDE_RING_ABLATE
+      if ((dbg & 512) && lane == 0 && blockIdx.x < 1024) {
+        atomicAdd(&g_ring_probe[0][blockIdx.x], RING_CLK() - cs_t0);
+        atomicAdd(&g_ring_probe[1][blockIdx.x], cs_poll);
+        atomicAdd(&g_ring_probe[2][blockIdx.x], cs_trips);
+      }
+#endif
     }
+    if constexpr (Fn::kRingFused) loss = fmaf(loss, 0.6931471805599453f, loss2) * (1.0f / Fn::kParamScale);
     ring_ctrl_store(MDE_RING_CTRL_PROG + 4u * (uint32_t)wave, MDE_RING_DONE);
     // (the two roles are laid out one after the other: leave no counted load pending here, or
     // hipcc carries the stream prefetches into the producer code as waits -- see above)
@@ -1260,6 +1509,10 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
     mde_set_error("the LDS-ring kernel needs a 16-byte aligned embedding matrix");
     return MDE_E_INVALID;
   }
+  if constexpr (LIN) {
+    // one scalar parameter for every edge: padding lanes would carry it too -- mask them instead
+    if (A.a0_scalar == 1) return launch_ring<D, Fn, false>(A, fn, nblocks);
+  }
   auto kern = A.grad ? k_fused_ring<D, Fn, true, false, LIN> : k_fused_ring<D, Fn, false, false, LIN>;
   if constexpr (D == 2) {
     if (cb) kern = A.grad ? k_fused_ring<D, Fn, true, true, LIN> : k_fused_ring<D, Fn, false, true, LIN>;
@@ -1269,14 +1522,42 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
   const float* a0 = cb ? A.a0 + L.H : A.a0;
   const int Q = L.col_groups;
   *nblocks = L.n_row_blocks * Q;
+  // the accumulators hold sum f'/d (x_v - x_u); 1/p is applied with the output scale (the
+  // NaN/Inf -> 1 rule of the reference then reads "-> p")
+  const float out_scale = A.grad_scale * A.inv_p;
+  const float fix_value = A.inv_p > 0.0f ? 1.0f / A.inv_p : 1.0f;
+#if MDE_RING_ABLATE
+  const int dbg = getenv("MDE_RING_DBG") ? atoi(getenv("MDE_RING_DBG")) : 0;
+#else
+  const int dbg = 0;
+#endif
+  // (every edge adds its loss term once here, not once per endpoint: twice the caller's scale)
   hipLaunchKernelGGL(kern, dim3(L.n_row_blocks * Q), dim3(MDE_RING_BS), 0, A.st,
                      (int)(A.plan->row_hi - A.plan->row_lo), (int)A.plan->row_lo, (int)A.plan->n,
                      L.rows_per_block, Q, L.n_chunks, L.wave_iter, L.hdr, stream, a0, A.a1, A.a0_scalar,
-                     A.a1_scalar, A.X, A.grad, L.partial, A.plan->partials, fn, A.inv_p, A.grad_scale,
-                     A.loss_out, A.loss_scale, getenv("MDE_RING_DBG") ? atoi(getenv("MDE_RING_DBG")) : 0);
+                     A.a1_scalar, A.X, A.grad, L.partial, A.plan->partials, fn, fix_value, out_scale,
+                     A.loss_out, 2.0 * A.loss_scale, dbg);
   MDE_LAUNCH_CHECK();
 #if MDE_RING_ABLATE
-  if (getenv("MDE_RING_DBG") && (atoi(getenv("MDE_RING_DBG")) & 256)) {
+  if (dbg & 512) {
+    static int launches = 0;
+    if (++launches == 8) {
+      std::vector<unsigned long long> h(8 * 1024);
+      (void)hipStreamSynchronize(A.st);
+      (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_ring_probe), sizeof(unsigned long long) * 8 * 1024);
+      const int nb = std::min(1024, L.n_row_blocks * Q);
+      double s[8] = {0};
+      for (int k = 0; k < 8; ++k)
+        for (int i = 0; i < nb; ++i) s[k] += (double)h[k * 1024 + i];
+      const double L8 = 8.0 * nb;  // launches x workgroups
+      fprintf(stderr, "[mde ring probe] per consumer wave and launch: loop %.0f clk, in chunk polls %.0f clk (%.1f%%), %.0f poll trips | "
+              "per producer wave: loop %.0f clk, blocked on a slot %.0f (%.1f%%), waiting for pieces %.0f (%.1f%%), %.0f slot polls\n",
+              s[0] / L8 / MDE_RING_NCW, s[1] / L8 / MDE_RING_NCW, 100.0 * s[1] / s[0], s[2] / L8 / MDE_RING_NCW,
+              s[3] / L8 / MDE_RING_NPROD, s[4] / L8 / MDE_RING_NPROD, 100.0 * s[4] / s[3], s[5] / L8 / MDE_RING_NPROD,
+              100.0 * s[5] / s[3], s[6] / L8 / MDE_RING_NPROD);
+    }
+  }
+  if (dbg & 256) {
     static int printed = 0;
     if (printed++ == 3) {
       const int nb = L.n_row_blocks * Q;
@@ -1288,13 +1569,8 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
         mn = std::min(mn, h[1024 + i]); mx = std::max(mx, h[1024 + i]); sum += h[1024 + i];
         t0 = std::min(t0, h[2048 + i]); t1 = std::max(t1, h[2048 + i] + h[1024 + i]);
       }
-      fprintf(stderr, "[mde ring] workgroup main-phase ticks: min %.0f mean %.0f max %.0f; first start -> last end %.0f (100 MHz ticks?)\n",
+      fprintf(stderr, "[mde ring] workgroup main-phase ticks: min %.0f mean %.0f max %.0f; first start -> last end %.0f\n",
               mn, sum / nb, mx, t1 - t0);
-      for (int x = 0; x < 8; ++x) {
-        double s8 = 0; int c8 = 0;
-        for (int i = x; i < nb && i < 1024; i += 8) { s8 += h[1024 + i]; ++c8; }
-        fprintf(stderr, "  XCD %d: mean %.0f\n", x, s8 / c8);
-      }
     }
   }
 #endif
@@ -1304,11 +1580,11 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
     if (nlocD % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
       const int64_t m = nlocD / 4;
       hipLaunchKernelGGL(k_ring_combine<float4>, dim3((unsigned)((m + MDE_BLOCK - 1) / MDE_BLOCK)), dim3(MDE_BLOCK),
-                         0, A.st, m, Q, reinterpret_cast<const float4*>(L.partial), A.grad_scale,
+                         0, A.st, m, Q, reinterpret_cast<const float4*>(L.partial), out_scale,
                          reinterpret_cast<float4*>(out));
     } else {
       hipLaunchKernelGGL(k_ring_combine<float>, dim3((unsigned)((nlocD + MDE_BLOCK - 1) / MDE_BLOCK)),
-                         dim3(MDE_BLOCK), 0, A.st, nlocD, Q, L.partial, A.grad_scale, out);
+                         dim3(MDE_BLOCK), 0, A.st, nlocD, Q, L.partial, out_scale, out);
     }
     MDE_LAUNCH_CHECK();
   }
