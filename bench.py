@@ -1,7 +1,8 @@
 """Benchmark of the north-star hot path: one average_distortion forward+backward per step.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1 without a launcher: bench.py starts its own N ranks, one per GPU over RCCL, and rank 0 prints the
+     line; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it just joins)
 
 Default workload = BASELINE.json configs[3] ("Synthetic scale"): n = 1M items,
 |E| = 50M uniform-random edges (out-degree 50), d = 2, penalties.Log1p(exponent 1.5), weights in
@@ -14,12 +15,17 @@ Prints ONE JSON line: metric/value = edges/s/iter, plus
                   per-launch HIP-event times on the launching stream), against the 8 TB/s HBM peak;
                   `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of THIS kernel
                   source (profiles/r02_pmc_traffic.json, ignored when the source has changed since)
-  cpu_baseline -- the OpenMP CPU oracle (a port of the reference's algorithm) timed on this
-                  host's cores on the same workload (N = 1 only)
+  cpu_baseline -- the reference's op sequence (average_distortion.py:68-105: index gathers,
+                  pow/sum/sqrt, the penalty under autograd, two scatter_add_) restated in torch and
+                  timed on ALL of this host's cores (kind "torch-aten-sequence"); the OpenMP CPU
+                  oracle (a port of the algorithm) beside it as `port`  (N = 1 only)
+The timed region is repeated (--blocks, default 10); `ms_per_step` / `value` are the MEDIAN block.
 
 Other workloads (secondary records; same JSON shape):
+  --variant 4b SURVEY 8d config 4b: the last third of the edges repulsive, PushAndPull(Log1p, Log)
   --config 5   BASELINE configs[4]: n = 500k, |E| = 20M, d = 128 (Log1p and Quadratic; the
-               Standardized projection kernels at that shape are timed too)
+               Standardized projection kernels at that shape are timed too); --embed: a Standardized
+               embed() at that shape, s/iter with a per-kernel breakdown
   --config 2   MNIST-like preserve_neighbors (70k points, 15-NN + repulsive edges, Standardized): embed() s/iter
   --config 3   Google-Scholar-like preserve_distances (40k-node scale-free graph, Huber loss): embed() s/iter
 """
@@ -91,13 +97,62 @@ def make_workload(device, n=N_ITEMS, deg=OUT_DEGREE, d=DIM):
     return edges, w, X.contiguous()
 
 
-def cpu_baseline(edges, w, X, p):
-    """Time the CPU oracle (OpenMP port of the reference algorithm) on the host cores.
+def torch_reference_sequence(X, lhs, rhs, w, exponent=1.5):
+    """The reference's op sequence for one evaluation [ref: pymde/average_distortion.py:68-105,
+    penalties.py:310-321], restated with plain torch ops: index gathers, pow / sum / sqrt, the
+    penalty differentiated by autograd, the NaN/Inf -> 1 fix-ups, two scatter_add_."""
+    diff = X[lhs] - X[rhs]
+    norms = diff.pow(2).sum(dim=1).sqrt()
+    with torch.enable_grad():
+        norms.requires_grad_(True)
+        E = (w * torch.log1p(norms.pow(exponent))).mean()
+        E.backward()
+    g = norms.grad / norms.detach()
+    g[torch.isnan(g)] = 1.0
+    g[torch.isinf(g)] = 1.0
+    contrib = g[:, None] * diff
+    out = torch.zeros_like(X)
+    idx = lhs[:, None].expand(-1, X.shape[1])
+    out.scatter_add_(0, idx, contrib)
+    out.scatter_add_(0, rhs[:, None].expand(-1, X.shape[1]), -contrib)
+    return float(E.detach()), out
 
-    The thread count is calibrated first on a 10 % sample (the oracle's per-thread gradient
-    accumulators make very wide runs slower), then the full workload is timed (bounded to
-    ~25 s)."""
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(edges, w, X, p):
+    """The CPU path timed on THIS host's cores: (1) the reference's torch op sequence on all cores,
+    on a bounded sample of the same workload (the first 10M edges against the full 1M x 2 table,
+    ~10-20 s of CPU work); (2) the OpenMP oracle (a port of the algorithm) on the full workload."""
     from oracle import oracle
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    ps = min(p, 10_000_000)
+    e_cpu = edges[:ps].cpu()
+    Xc, wc = X.cpu(), w[:ps].cpu()
+    lhs, rhs = e_cpu[:, 0].contiguous(), e_cpu[:, 1].contiguous()
+    torch_reference_sequence(Xc, lhs[:100000], rhs[:100000], wc[:100000])   # warm the thread pool
+    times = []
+    t_start = time.perf_counter()
+    while len(times) < 3 and (time.perf_counter() - t_start) < 20.0:
+        t0 = time.perf_counter()
+        torch_reference_sequence(Xc, lhs, rhs, wc)
+        times.append(time.perf_counter() - t0)
+    aten = {"value": ps / min(times), "unit": "edges/s/iter", "cores": int(ncores), "kind": "torch-aten-sequence",
+            "cpu": cpu_model(),
+            "sample": "first %d of the %d edges (same graph, full n=1M x 2 table, Log1p), min of %d fwd+bwd passes of "
+                      "the reference's op sequence (gathers, pow/sum/sqrt, autograd penalty, 2x scatter_add_) in "
+                      "torch %s with torch.set_num_threads(%d) on this host" % (ps, p, len(times), torch.__version__, ncores)}
+    # (2) the OpenMP port on the full workload; thread count calibrated on a 10 % sample (the oracle's
+    # per-thread gradient accumulators make very wide runs slower)
     e = edges.cpu().numpy()
     wn = w.cpu().numpy()
     Xn = X.cpu().numpy()
@@ -118,15 +173,15 @@ def cpu_baseline(edges, w, X, p):
     fd = oracle.func("LOG1P", wn, None, (1.5,))
     times = []
     t_start = time.perf_counter()
-    while len(times) < 3 and (time.perf_counter() - t_start) < 25.0:
+    while len(times) < 2 and (time.perf_counter() - t_start) < 12.0:
         t0 = time.perf_counter()
         E, _ = oracle.average_distortion(e, Xn, fd)
         times.append(time.perf_counter() - t0)
-    return {"value": p / min(times), "unit": "edges/s/iter", "cores": int(best_t), "kind": "port",
-            "sample": "full workload (n=1M, |E|=50M, d=2, Log1p), min of %d fwd+bwd evaluations of "
-                      "oracle/mde_oracle.c with OpenMP on %d of %d host threads (best of a thread sweep)"
-                      % (len(times), best_t, max_threads),
-            "reference_torch_cpu": REFERENCE_TORCH_CPU}, E
+    aten["port"] = {"value": p / min(times), "unit": "edges/s/iter", "cores": int(best_t), "kind": "port",
+                    "sample": "full workload, min of %d fwd+bwd evaluations of oracle/mde_oracle.c with OpenMP on %d "
+                              "of %d host threads (best of a thread sweep)" % (len(times), best_t, max_threads)}
+    aten["reference_torch_cpu_other_machine"] = REFERENCE_TORCH_CPU
+    return aten, E
 
 
 def time_launches(fn, count, device):
@@ -143,6 +198,23 @@ def time_launches(fn, count, device):
 
 
 # ------------------------------------------------------------------------------------------ config 4
+def timed_blocks(step, barrier, steps, blocks, world, device):
+    """`blocks` repetitions of the timed region (barrier + sync, `steps` steps, barrier + sync);
+    seconds per block, MAX over ranks."""
+    out = []
+    for _ in range(blocks):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        out.append(time.perf_counter() - t0)
+    t = torch.tensor(out, dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(v) for v in t.cpu()]
+
+
 def run_config4(args, world, rank, device):
     import pymde_amd
     from pymde_amd import distributed
@@ -151,12 +223,22 @@ def run_config4(args, world, rank, device):
     n, d = args.n, DIM
     edges, w, X = make_workload(device, n=n)
     p = edges.shape[0]
-    f = pymde_amd.penalties.Log1p(w)
+    if args.variant == "4b":
+        # the last third of the edges repulsive (w = -1), PushAndPull(Log1p, Log)
+        w = w.clone()
+        w[(2 * p) // 3:] = -1.0
+        f = pymde_amd.penalties.PushAndPull(w, pymde_amd.penalties.Log1p, pymde_amd.penalties.Log)
+        fname = "PushAndPull(Log1p(1.5), Log(1)), weights {1,2} on the first 2/3 of the edges, -1 on the last third"
+    else:
+        f = pymde_amd.penalties.Log1p(w)
+        fname = "penalties.Log1p(1.5), weights in {1,2}"
     bounds = None
     if world > 1 or args.emulate_world > 1:
         W = world if world > 1 else args.emulate_world
         bounds = distributed.shard_bounds(n, edges, W)
         lo, hi = distributed.shard_range(bounds, rank)
+        # (every rank holds the full edge list here -- 0.8 GB at this size; a rank only needs the
+        # edges with an endpoint in its range, which is what the plan keeps)
         plan = EdgePlan(n, edges, lo, hi)
     else:
         plan = EdgePlan(n, edges)
@@ -179,16 +261,10 @@ def run_config4(args, world, rank, device):
 
     for _ in range(args.warmup):
         step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # the timed region (exactly `steps` steps between barrier + synchronize), repeated: the median
+    # block is reported (a 5 ms region is at the mercy of one scheduler hiccup)
+    block_s = timed_blocks(step, barrier, args.steps, max(args.blocks, 1), world, device)
+    elapsed = float(np.median(block_s))
     # the same steps once more with a HIP-event pair around each one: the per-step median (the
     # events themselves cost a few microseconds per step, so they stay out of the timed region)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -203,15 +279,22 @@ def run_config4(args, world, rank, device):
     # dominant kernel: the fused gather/scatter kernel, timed per launch with HIP events on the
     # stream it is launched on (torch's current stream)
     k_ms, k_mean = time_launches(lambda: fused_evaluate(binding, X, grad, loss), max(args.steps, 1), device)
+    per_rank_ms = [k_ms]
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.float64, device=device)
+        t[rank] = k_ms
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank_ms = [float(v) for v in t.cpu()]
     edges_local = plan.half_edges / 2.0
     alg_bytes = ALG_BYTES_PER_EDGE * edges_local + 2.0 * 4.0 * d * (plan.row_hi - plan.row_lo)
     achieved = alg_bytes / (k_ms * 1e-3)
     layout = int(binding.struct(d).layout)
-    kernel = ("k_fused_ring<2,Log1p,%s> (LDS-resident rows + LDS-DMA chunk ring, loss reduced in the same launch)"
-              % ("codebook" if binding.codebook else "fp32 stream")) if layout == 1 \
-        else "k_fused_small<2,G,Log1p> (CSR) + 1-block loss finalize"
+    fn_name = "Log1p" if args.variant == "4a" else "PushPull<Log1p,Log>"
+    kernel = ("k_fused_ring<2,%s,%s> (LDS-resident rows + LDS-DMA chunk ring, loss reduced in the same launch)"
+              % (fn_name, "codebook" if binding.codebook else "fp32 stream")) if layout == 1 \
+        else "k_fused_small<2,G,%s> (CSR) + 1-block loss finalize" % fn_name
     traffic, traffic_src = (None, None)
-    if world == 1 and args.emulate_world <= 1 and n == N_ITEMS:
+    if world == 1 and args.emulate_world <= 1 and n == N_ITEMS and args.variant == "4a":
         traffic, traffic_src = pmc_traffic("ring_codebook" if binding.codebook else "ring_fp32" if layout == 1 else "csr")
 
     if rank != 0:
@@ -221,17 +304,20 @@ def run_config4(args, world, rank, device):
         "value": p * args.steps / elapsed, "unit": "edges/s/iter",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_median_events": float(np.median(step_ms)),
+        "blocks": len(block_s), "ms_per_step_blocks": [round(1e3 * b / args.steps, 5) for b in block_s],
         "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[3] / SURVEY 8d config 4a: n=%d, |E|=%d uniform-random edges "
-                               "(out-degree 50), d=2, penalties.Log1p(1.5), weights in {1,2}; seeded on the "
+        "config": {"workload": "BASELINE configs[3] / SURVEY 8d config %s: n=%d, |E|=%d uniform-random edges "
+                               "(out-degree 50), d=2, %s; seeded on the "
                                "device with torch.Generator(0) (the survey's recipe uses numpy default_rng(0): "
-                               "same distribution, another stream)" % (n, p),
+                               "same distribution, another stream)" % (args.variant, n, p, fname),
                    "parallelism": ("vertex-range shards x%d + %s of [grad|loss]" % (world, exchange.mode))
                    if world > 1 else ("single GPU" if args.emulate_world <= 1 else
                                       "rank 0 of a %d-way shard, kernel only (emulation, no collective)" % args.emulate_world),
-                   "parameter_stream": ("codebook: 2 distinct weights ride in the packed half-edge word "
-                                        "(4 B/half-edge)" if binding.codebook
+                   "exchange": exchange.mode if world > 1 else None,
+                   "kernel_ms_per_rank": per_rank_ms,
+                   "parameter_stream": ("codebook: %d distinct weights ride in the packed half-edge word "
+                                        "(4 B/half-edge)" % (2 if args.variant == "4a" else 3) if binding.codebook
                                         else "fp32 weight per half-edge (8 B/half-edge)"),
                    "loss": gpu_loss},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BPS / 1e9,
@@ -239,7 +325,7 @@ def run_config4(args, world, rank, device):
                      "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": k_ms,
                      "kernel_ms_mean": k_mean, "alg_bytes_per_launch": alg_bytes},
     }
-    if world == 1 and binding.codebook and not args.no_codebook:
+    if world == 1 and binding.codebook and not args.no_codebook and args.variant == "4a":
         # secondary: the general case (continuous per-edge parameters, configs 2 / 3) streams an
         # fp32 parameter per half-edge
         os.environ["MDE_CODEBOOK"] = "0"
@@ -250,12 +336,46 @@ def run_config4(args, world, rank, device):
         out["config"]["fp32_parameter_stream"] = {
             "kernel_ms": k2, "value": p / (k2 * 1e-3), "unit": "edges/s/iter (kernel time)",
             "roofline_frac": alg_bytes / (k2 * 1e-3) / HBM_PEAK_BPS}
-    if world == 1 and args.emulate_world <= 1 and not args.no_cpu_baseline:
+    if world == 1 and args.emulate_world <= 1 and not args.no_cpu_baseline and args.variant == "4a":
         cb, cpu_loss = cpu_baseline(edges, w, X, p)
         out["cpu_baseline"] = cb
         out["config"]["oracle_loss"] = cpu_loss
         assert abs(cpu_loss - gpu_loss) <= 1e-5 * abs(cpu_loss), (cpu_loss, gpu_loss)
     return out
+
+
+def run_exchange_only(args, world, rank):
+    """No kernel (CPU / gloo): every rank fills its own rows of [grad | loss] with a known pattern
+    and runs the product's exchange; checks the result and prints the N-rank line.  This is what
+    the CPU test of the self-launcher runs -- it is NOT a measurement of the hot path."""
+    from pymde_amd import distributed
+    n, d = args.n, DIM
+    step = (n + world - 1) // world
+    bounds = [min(r * step, n) for r in range(world + 1)]
+    lo, hi = bounds[rank], bounds[rank + 1]
+    ex = distributed.GradExchange(n, d, bounds, rank, world)
+    buf = torch.zeros(n * d + 1, dtype=torch.float32)
+    t = []
+    for _ in range(args.warmup + args.steps):
+        buf.zero_()
+        buf[lo * d:hi * d] = float(rank + 1)
+        buf[n * d] = 1.0
+        dist.barrier()
+        t0 = time.perf_counter()
+        ex(buf)
+        t.append(time.perf_counter() - t0)
+    for r in range(world):
+        assert bool((buf[bounds[r] * d:bounds[r + 1] * d] == float(r + 1)).all()), "exchange result"
+    assert abs(float(buf[n * d]) - world) < 1e-6
+    if rank != 0:
+        return None
+    ms = 1e3 * float(np.median(t[args.warmup:]))
+    return {"metric": "exchange only (no kernel): [grad|loss] of n=%d, d=2" % n, "value": ms, "unit": "ms/exchange",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": False,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "exchange-only self-launch check (backend %s), not the hot path" % args.backend,
+                       "parallelism": "vertex-range shards x%d + %s of [grad|loss]" % (world, ex.mode),
+                       "exchange": ex.mode}}
 
 
 # ------------------------------------------------------------------------------------------ config 5
@@ -308,6 +428,58 @@ def run_config5(args, device):
                              "%.1f GB per evaluation), so the attainable bound is the random-row gather rate "
                              "(tools/rowprobe: 7.4 TB/s from the 256 MB table) -> see row_gather_TBps"
                              % (gather_bytes / 1e9)},
+    }
+
+
+def run_config5_embed(args, device):
+    """BASELINE configs[4] as an embed(): n = 500k, |E| = 20M, d = 128, Log1p, Standardized -- seconds
+    per projected L-BFGS iteration, with the component kernels timed on their own beside it."""
+    import pymde_amd
+    from pymde_amd.average_distortion import fused_evaluate
+    n, deg, d = 500_000, 40, 128
+    edges, w, _ = make_workload(device, n=n, deg=deg, d=2)
+    p = edges.shape[0]
+    c = pymde_amd.Standardized()
+    mde = pymde_amd.MDE(n, d, edges, pymde_amd.penalties.Log1p(w), constraint=c, device=device)
+    torch.manual_seed(0)
+    X0 = c.initialization(n, d, device=device).contiguous()
+    iters = max(args.steps if args.steps != 200 else 20, 1)
+    mde.embed(X=X0.clone(), max_iter=3, eps=0.0)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    mde.embed(X=X0.clone(), max_iter=iters, eps=0.0)
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    st = mde.solve_stats
+    n_it = max(int(st.iterations), 1)
+    # the components of an iteration, each on its own (HIP events, median of 20)
+    X = mde.X.detach().contiguous()
+    buf = torch.zeros(n * d + 1, dtype=torch.float32, device=device)
+    grad, loss = buf[:n * d].view(n, d), buf[n * d:]
+    b = mde._binding()
+    t_eval, _ = time_launches(lambda: fused_evaluate(b, X, grad, loss), 20, device)
+    Z = torch.randn((n, d), device=device)
+    t_tan, _ = time_launches(lambda: c.project_onto_tangent_space(X, Z, inplace=True), 20, device)
+    Y = X.clone()
+    t_ret, _ = time_launches(lambda: c.project_onto_constraint(Y, inplace=True), 20, device)
+    vec_bytes = 4.0 * n * d
+    return {
+        "metric": "seconds/iteration of MDE.embed(), n=500k |E|=20M d=128 Standardized", "value": dt / n_it, "unit": "s/iter",
+        "n_gpus": 1, "steps": n_it, "warmup": 3, "ms_per_step": 1e3 * dt / n_it, "higher_is_better": False,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4] / SURVEY 8d config 5 as an embed(): n=%d, |E|=%d uniform-random edges "
+                               "(out-degree 40), d=128, penalties.Log1p(1.5), weights {1,2}, Standardized, L-BFGS memory 10, "
+                               "X0 = Standardized().initialization" % (n, p),
+                   "parallelism": "single GPU", "edges_per_s_per_iter": p * n_it / dt,
+                   "final_average_distortion": float(mde.value),
+                   "component_ms": {"average_distortion fwd+bwd (k_fused_wide4)": t_eval,
+                                    "Standardized tangent projection": t_tan,
+                                    "Standardized retraction": t_ret},
+                   "vector_bytes": vec_bytes,
+                   "note": "an iteration = >= 1 evaluation + tangent projection + retraction per line-search trial, "
+                           "plus the device L-BFGS update (4 + 5m inner products and the combine over %.0f MB "
+                           "vectors); the kernel-by-kernel split is in profiles/r03_config5_embed_kernel_stats.csv"
+                           % (vec_bytes / 1e6)},
     }
 
 
@@ -380,28 +552,87 @@ def run_embed_config(args, device, which):
     }
 
 
+def self_launch(args):
+    """--gpus N > 1 outside a launcher: start the N ranks of this script (one per GPU, rendezvous on
+    127.0.0.1); rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    if args.backend == "nccl":
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d needs %d visible GPUs for the RCCL ranks (one process per GPU); "
+                             "this host has %d" % (args.gpus, args.gpus, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    # one process per rank with the environment torch.distributed.run would give it (env:// rendezvous
+    # on 127.0.0.1); the script's own arguments go through untouched
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        for pr in procs:
+            code = pr.wait()
+            if code != 0 and rc == 0:
+                rc = code
+                for other in procs:       # a rank died: do not leave the others in a collective
+                    if other.poll() is None:
+                        other.terminate()
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--blocks", type=int, default=10, help="repetitions of the timed region (the median is reported)")
     ap.add_argument("--config", type=int, default=4, choices=(2, 3, 4, 5))
+    ap.add_argument("--variant", default="4a", choices=("4a", "4b"),
+                    help="config 4 only: 4a Log1p (the headline), 4b PushAndPull(Log1p, Log) with 1/3 repulsive edges")
+    ap.add_argument("--embed", action="store_true", help="config 5 only: a Standardized embed() at that shape")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-codebook", action="store_true",
                     help="stream the weights as fp32 (8 B/half-edge) even though they take 2 values")
     ap.add_argument("--n", type=int, default=N_ITEMS)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
+    ap.add_argument("--exchange-only", action="store_true",
+                    help="no kernel: run only the [grad|loss] exchange of an N-rank job (CPU / gloo check of the launcher)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single process: time only the kernel of rank 0 of a W-way shard (no collective)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     if args.no_codebook:
         os.environ["MDE_CODEBOOK"] = "0"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(args.gpus, 1):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU" % (args.gpus, world))
+    if args.exchange_only:
+        if world < 2:
+            raise SystemExit("--exchange-only needs --gpus N > 1")
+        dist.init_process_group(backend=args.backend)
+        out = run_exchange_only(args, world, rank)
+        if out is not None:
+            print(json.dumps(out))
+        dist.destroy_process_group()
+        return
     ndev = torch.cuda.device_count()
     if world > 1:
+        if args.backend == "nccl" and ndev < world:
+            raise SystemExit("%d ranks but %d visible GPUs: one process per GPU" % (world, ndev))
         torch.cuda.set_device(local_rank % ndev)
         dist.init_process_group(backend=args.backend)
     device = torch.device("cuda", (local_rank % ndev) if world > 1 else 0)
@@ -412,7 +643,7 @@ def main():
     elif world > 1:
         raise SystemExit("--config %d is a single-GPU record" % args.config)
     elif args.config == 5:
-        out = run_config5(args, device)
+        out = run_config5_embed(args, device) if args.embed else run_config5(args, device)
     else:
         out = run_embed_config(args, device, args.config)
     if out is not None:

@@ -114,3 +114,34 @@ def test_forced_exchange_in_a_world_of_one_is_the_identity():
     proc.start()
     proc.join(180)
     assert proc.exitcode == 0 and ret.get("ok") == 1
+
+
+def test_bench_self_launches_two_gloo_ranks():
+    """`bench.py --gpus 2` outside a launcher starts its own two ranks; rank 0 prints ONE JSON line
+    that says n_gpus = 2 and names the exchange (gloo, exchange-only: there is no GPU here)."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--n", "20000",
+                          "--exchange-only", "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1
+    assert rec["config"]["exchange"] in ("all_gather", "all_reduce")
+    assert "x2" in rec["config"]["parallelism"]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """With the RCCL backend, --gpus N on a host with fewer than N GPUs fails loudly (one process per GPU)."""
+    import subprocess
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert "needs 64 visible GPUs" in (out.stderr + out.stdout)
