@@ -1,0 +1,351 @@
+// mde_mfma.hip -- the Standardized projections at embedding widths 32, 64, 128: exact-f32 matrix
+// core kernels (v_mfma_f32_32x32x2_f32 runs at the f32 vector rate, 64 FLOP/clk/SIMD; at d = 128 the
+// d x d Gram matrix and the n x d by d x d product are ~16 GFLOP each for n = 500k, i.e. as long
+// on the matrix pipe as their operands take to stream from HBM -- the kernels below keep both busy).
+//   [ref: pymde/constraints.py:167-200 (Standardized), pymde/util.py:129-171 (proj_standardized)]
+//
+// k_gram_rows     G = (A - mean)^T (B - mean) over a chunk of rows.  One wave owns ALL W x W output
+//                 tiles (W = d / 32): lane (k, c) = (l >> 5, l & 31) loads W consecutive floats of
+//                 row r + k -- one fully coalesced 16-byte load per operand at d = 128 -- and holds
+//                 columns W c .. W c + W - 1.  The k index of the MFMA is the row, so register q of
+//                 the A-side and register q' of the B-side feed MFMA (q, q'): 16 MFMAs per two
+//                 16-byte loads, no LDS, no transposes.  Output tile (q, q'), register v, lane l is
+//                 G[W i + q][W (l & 31) + q'] with i = (v & 3) + 8 (v >> 2) + 4 (l >> 5).
+// k_rmul_rows     out = base + alpha (A - mean) M, 32 rows per wave.  The product is formed transposed
+//                 (M^T as the 32 x 2 operand, the rows as the 2 x 32 operand): lane l keeps HALF of
+//                 row l & 31 (columns (l >> 5) d/2 ...) in registers -- 16-byte loads along the row --
+//                 and step s multiplies inner indices s and d/2 + s.  M sits in LDS as fp32; a lane
+//                 ends up with 4-column groups of its row and stores them as float4.
+// invsqrt         coupled Newton-Schulz in double, two launches per step, convergence read back per
+//                 batch of steps (see mde_invsqrt_grid).
+#include "mde_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// W consecutive floats at p (p is 4 W-byte aligned when W is 1, 2, 4)
+template <int W>
+__device__ __forceinline__ void ldw(const float* p, float (&v)[W]) {
+  if constexpr (W == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else if constexpr (W == 2) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  } else {
+#pragma unroll
+    for (int q = 0; q < W; ++q) v[q] = p[q];
+  }
+}
+
+// ---------------------------------------------------------------- column sums (means)
+template <int W>
+__global__ __launch_bounds__(MDE_BLOCK) void k_colsum_rows(int64_t n, const float* __restrict__ Z, int64_t rows_per_wg,
+                                                           double* __restrict__ partial /* [gridDim.x][32 W] */) {
+  constexpr int D = 32 * W;
+  __shared__ double red[MDE_BLOCK / 64][64][W];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kk = lane >> 5, c = lane & 31;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = r0 + rows_per_wg < n ? r0 + rows_per_wg : n;
+  double acc[W];
+#pragma unroll
+  for (int q = 0; q < W; ++q) acc[q] = 0.0;
+  constexpr int U = 8;
+  for (int64_t r = r0 + 2 * wave; r < r1; r += 8 * U) {
+    float a[U][W];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t rr = r + 8 * u + kk;
+      if (rr < r1) {
+        ldw<W>(Z + rr * D + W * c, a[u]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < W; ++q) a[u][q] = 0.0f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int q = 0; q < W; ++q) acc[q] += (double)a[u][q];
+  }
+#pragma unroll
+  for (int q = 0; q < W; ++q) red[wave][lane][q] = acc[q];
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += MDE_BLOCK) {
+    const int cc = i / W, q = i % W;
+    double s = 0.0;
+    for (int w = 0; w < MDE_BLOCK / 64; ++w) s += red[w][cc][q] + red[w][32 + cc][q];
+    partial[(int64_t)blockIdx.x * D + i] = s;
+  }
+}
+
+// ---------------------------------------------------------------- Gram matrix
+// (The W x W tiles are split between the waves: wave w takes A-side register q = w mod W against all W
+// B-side registers -- 4 tiles = 64 accumulator registers at d = 128, which leaves room for a second
+// register set of operands in flight and for two or three waves per SIMD; sixteen tiles in one wave
+// spill, eight still do under hipcc.  The B-side rows are then read by W waves: L1 hits.)
+template <int W, bool SAME>
+__global__ __launch_bounds__(MDE_BLOCK, 2) void k_gram_rows(int64_t n, const float* __restrict__ A,
+                                                         const float* __restrict__ B,
+                                                         const double* __restrict__ mean, int64_t rows_per_wg,
+                                                         double* __restrict__ partial /* [gridDim.x][D * D] */) {
+  static_assert(W == 1 || W == 2 || W == 4, "A-side halves of equal size");
+  constexpr int D = 32 * W;
+  constexpr int NH = W;                       // parts of the A-side registers: one register per wave
+  constexpr int QH = W / NH;                  // A-side registers per part
+  constexpr int NRG = (MDE_BLOCK / 64) / NH;  // wave groups interleaving the row pairs
+  __shared__ float red[W * W * 16 * 64];
+  const int lane = threadIdx.x & 63, kk = lane >> 5, c = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int q0 = (wave % NH) * QH, rg = wave / NH;  // my A-side columns W c + q0 .. + QH - 1 (an address offset only)
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = r0 + rows_per_wg < n ? r0 + rows_per_wg : n;
+  float mub[W], mua[QH];
+#pragma unroll
+  for (int p = 0; p < W; ++p) mub[p] = mean ? (float)mean[W * c + p] : 0.0f;
+#pragma unroll
+  for (int q = 0; q < QH; ++q) mua[q] = mean ? (float)mean[W * c + q0 + q] : 0.0f;
+  f32x16 acc[QH][W];
+#pragma unroll
+  for (int q = 0; q < QH; ++q)
+#pragma unroll
+    for (int p = 0; p < W; ++p)
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[q][p][v] = 0.0f;
+  // Two register sets: the loads of the next batch of row pairs are in flight while the MFMAs of this
+  // one run.  (A == B: the A-side values are loaded again -- an L1 hit -- rather than picked out of the
+  // B-side registers with a wave-dependent register index.)
+  constexpr int U = 8;
+  const float* Aq = A + W * c + q0;
+  const float* Bq = B + W * c;
+  auto load = [&](int64_t r, float (&a)[U][QH], float (&b)[U][W]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t rr = r + 2 * NRG * u + kk;
+      if (rr < r1) {
+        ldw<W>(Bq + rr * D, b[u]);
+        ldw<QH>(Aq + rr * D, a[u]);
+      } else {
+#pragma unroll
+        for (int p = 0; p < W; ++p) b[u][p] = mub[p];  // (centred to zero below)
+#pragma unroll
+        for (int q = 0; q < QH; ++q) a[u][q] = mua[q];
+      }
+    }
+  };
+  auto mma = [&](float (&a)[U][QH], float (&b)[U][W]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int p = 0; p < W; ++p) b[u][p] -= mub[p];
+#pragma unroll
+      for (int q = 0; q < QH; ++q) a[u][q] -= mua[q];
+#pragma unroll
+      for (int q = 0; q < QH; ++q)
+#pragma unroll
+        for (int p = 0; p < W; ++p)
+          acc[q][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][q], b[u][p], acc[q][p], 0, 0, 0);
+    }
+  };
+  float a0[U][QH], b0[U][W], a1[U][QH], b1[U][W];
+  constexpr int STEP = 2 * NRG * U;  // rows per batch of a wave group
+  int64_t r = r0 + 2 * rg;
+  if (r < r1) load(r, a0, b0);
+  while (r < r1) {
+    load(r + STEP, a1, b1);
+    mma(a0, b0);
+    r += STEP;
+    if (r >= r1) break;
+    load(r + STEP, a0, b0);
+    mma(a1, b1);
+    r += STEP;
+  }
+  // add the wave groups' tiles in order (fixed order: reproducible), then write the chunk's Gram
+  // matrix in double
+  for (int g = 0; g < NRG; ++g) {
+    if (rg == g) {
+#pragma unroll
+      for (int q = 0; q < QH; ++q)
+#pragma unroll
+        for (int p = 0; p < W; ++p)
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int idx = ((((q0 + q) * W + p) * 16 + v) << 6) + lane;
+            red[idx] = (g == 0 ? 0.0f : red[idx]) + acc[q][p][v];
+          }
+    }
+    __syncthreads();
+  }
+  double* out = partial + (int64_t)blockIdx.x * D * D;
+  for (int idx = threadIdx.x; idx < W * W * 16 * 64; idx += MDE_BLOCK) {
+    const int l = idx & 63, v = (idx >> 6) & 15, t = idx >> 10;
+    const int q = t / W, p = t % W;
+    const int i = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5);
+    out[(W * i + q) * D + W * (l & 31) + p] = (double)red[idx];
+  }
+}
+
+// out[q] = scale * sum_c partial[c * m + q]: a block takes 32 consecutive outputs, eight threads per
+// output add every eighth chunk and the eight sums are added in a fixed order
+__global__ __launch_bounds__(MDE_BLOCK) void k_sum_chunks(int64_t m, int nc, const double* __restrict__ partial,
+                                                          double scale, double* __restrict__ out) {
+  __shared__ double sh[8][32];
+  const int t = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int64_t q = (int64_t)blockIdx.x * 32 + t;
+  double s = 0.0;
+  if (q < m)
+    for (int c = sl; c < nc; c += 8) s += partial[(int64_t)c * m + q];
+  sh[sl][t] = s;
+  __syncthreads();
+  if (sl == 0 && q < m) {
+    double tot = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tot += sh[k][t];
+    out[q] = tot * scale;
+  }
+}
+
+// ---------------------------------------------------------------- right-multiplication
+template <int W>
+__global__ __launch_bounds__(MDE_BLOCK) void k_rmul_rows(int64_t n, const float* A, const double* __restrict__ M,
+                                                         const double* __restrict__ mean, float alpha,
+                                                         const float* base, float* out) {
+  constexpr int D = 32 * W, KH = D / 2;
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [D][D] fp32 copy of M, then [D] column means
+  float* smean = sm + D * D;
+  for (int i = threadIdx.x; i < D * D; i += MDE_BLOCK) sm[i] = (float)M[i];
+  for (int i = threadIdx.x; i < D; i += MDE_BLOCK) smean[i] = mean ? (float)mean[i] : 0.0f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, rn = lane & 31;
+  const float* smh = sm + (size_t)h * KH * D + rn;
+  const int64_t ntiles = (n + 31) >> 5;
+  const int64_t tstep = (int64_t)gridDim.x * (MDE_BLOCK / 64);
+  // my half of my row (inner indices h KH .. h KH + KH - 1), as float4 loads along the row; the
+  // next tile's rows are requested before this tile's MFMAs start
+  float4 nx[KH / 4];
+  auto fetch = [&](int64_t tile) __attribute__((always_inline)) {
+    const int64_t row = tile * 32 + rn;
+    const float* ap = A + (row < n ? row : 0) * D + h * KH;
+#pragma unroll
+    for (int t = 0; t < KH / 4; ++t) nx[t] = *reinterpret_cast<const float4*>(ap + 4 * t);
+  };
+  int64_t tile = (int64_t)blockIdx.x * (MDE_BLOCK / 64) + wave;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += tstep) {
+    const int64_t row = tile * 32 + rn;
+    const bool ok = row < n;
+    float a[KH];
+#pragma unroll
+    for (int t = 0; t < KH / 4; ++t) {
+      a[4 * t] = nx[t].x; a[4 * t + 1] = nx[t].y; a[4 * t + 2] = nx[t].z; a[4 * t + 3] = nx[t].w;
+    }
+    if (tile + tstep < ntiles) fetch(tile + tstep);
+    if (mean) {
+#pragma unroll
+      for (int s = 0; s < KH; ++s) a[s] -= smean[h * KH + s];
+    }
+    if (!ok) {
+#pragma unroll
+      for (int s = 0; s < KH; ++s) a[s] = 0.0f;
+    }
+#pragma unroll 1
+    for (int jt = 0; jt < W; ++jt) {
+      f32x16 acc;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(smh[(size_t)s * D + jt * 32], a[s], acc, 0, 0, 0);
+      // lane: row rn, output columns jt 32 + 8 g + 4 h + (0..3), g = 0..3
+      if (ok) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int64_t o = row * D + jt * 32 + 8 * g + 4 * h;
+          float4 r = make_float4(alpha * acc[4 * g], alpha * acc[4 * g + 1], alpha * acc[4 * g + 2], alpha * acc[4 * g + 3]);
+          if (base) {
+            const float4 bq = *reinterpret_cast<const float4*>(base + o);
+            r.x += bq.x; r.y += bq.y; r.z += bq.z; r.w += bq.w;
+          }
+          *reinterpret_cast<float4*>(out + o) = r;
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------- host side
+static bool g_mfma_off() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MDE_NO_MFMA");
+    v = (e && atoi(e)) ? 1 : 0;
+  }
+  return v != 0;
+}
+// widths these kernels take (square d x d problems)
+bool mde_mfma_width_ok(int d) { return !g_mfma_off() && (d == 32 || d == 64 || d == 128); }
+
+// mean[c] = column mean of Z (partial: >= 1024 * d doubles)
+int mde_mfma_colmean(int64_t n, int d, const float* Z, double* partial, double* mean, hipStream_t st) {
+  int64_t nwg = (n + 2047) / 2048;
+  if (nwg > 1024) nwg = 1024;
+  if (nwg < 1) nwg = 1;
+  const int64_t rpw = ((n + nwg - 1) / nwg + 7) & ~(int64_t)7;
+  nwg = (n + rpw - 1) / rpw;
+#define CS(W_) hipLaunchKernelGGL(k_colsum_rows<W_>, dim3((unsigned)nwg), dim3(MDE_BLOCK), 0, st, n, Z, rpw, partial)
+  if (d == 32) CS(1); else if (d == 64) CS(2); else CS(4);
+#undef CS
+  MDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sum_chunks, dim3((d + 31) / 32), dim3(MDE_BLOCK), 0, st, (int64_t)d, (int)nwg, partial,
+                     1.0 / (double)n, mean);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+// out[d x d] = (A - mean)^T (B - mean) in double (f32 products and f32 sums over <= 2048 rows per
+// chunk, the chunks added in double); partial: max_partial doubles of scratch
+int mde_mfma_gram(int64_t n, int d, const float* A, const float* B, const double* mean, double* out, double* partial,
+                  int64_t max_partial, hipStream_t st) {
+  const int64_t m = (int64_t)d * d;
+  int64_t nwg = (n + 2047) / 2048;
+  if (nwg < 256 && n >= 256 * 64) nwg = 256;  // one workgroup per CU at least
+  if (nwg * m > max_partial) nwg = max_partial / m;
+  if (nwg < 1) return MDE_E_UNSUPPORTED;
+  const int64_t rpw = ((n + nwg - 1) / nwg + 7) & ~(int64_t)7;
+  nwg = (n + rpw - 1) / rpw;
+  const bool same = (A == B);
+#define GR(W_)                                                                                                   \
+  do {                                                                                                           \
+    if (same)                                                                                                    \
+      hipLaunchKernelGGL((k_gram_rows<W_, true>), dim3((unsigned)nwg), dim3(MDE_BLOCK), 0, st, n, A, B, mean, rpw, partial); \
+    else                                                                                                         \
+      hipLaunchKernelGGL((k_gram_rows<W_, false>), dim3((unsigned)nwg), dim3(MDE_BLOCK), 0, st, n, A, B, mean, rpw, partial); \
+  } while (0)
+  if (d == 32) GR(1); else if (d == 64) GR(2); else GR(4);
+#undef GR
+  MDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((m + 31) / 32)), dim3(MDE_BLOCK), 0, st, m, (int)nwg, partial, 1.0, out);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+// out = base + alpha (A - mean) M  (M: d x d doubles; base may be null; out may alias A or base)
+int mde_mfma_rmul(int64_t n, int d, const float* A, const double* M, const double* mean, float alpha, const float* base,
+                  float* out, hipStream_t st) {
+  const size_t lds = ((size_t)d * d + d) * sizeof(float);
+  int64_t nb = ((n + 31) / 32 + 3) / 4;
+  const int64_t cap = (lds > 40960) ? 512 : 1024;  // two (three) workgroups per CU fit their copy of M
+  if (nb > cap) nb = cap;
+  if (d == 128) {
+    // 64.5 KB of dynamic LDS: above the default cap of a launch
+    static bool raised = false;
+    if (!raised) {
+      MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rmul_rows<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+      raised = true;
+    }
+  }
+#define RM(W_) hipLaunchKernelGGL(k_rmul_rows<W_>, dim3((unsigned)nb), dim3(MDE_BLOCK), lds, st, n, A, M, mean, alpha, base, out)
+  if (d == 32) RM(1); else if (d == 64) RM(2); else RM(4);
+#undef RM
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}

@@ -7,7 +7,17 @@
 // atomics, bitwise reproducible.
 #include "mde_common.h"
 
+#include <algorithm>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// mde_mfma.hip: the projections' kernels at widths 32 / 64 / 128
+bool mde_mfma_width_ok(int d);
+int mde_mfma_colmean(int64_t n, int d, const float* Z, double* partial, double* mean, hipStream_t st);
+int mde_mfma_gram(int64_t n, int d, const float* A, const float* B, const double* mean, double* out, double* partial,
+                  int64_t max_partial, hipStream_t st);
+int mde_mfma_rmul(int64_t n, int d, const float* A, const double* M, const double* mean, float alpha, const float* base,
+                  float* out, hipStream_t st);
 
 // ---------------------------------------------------------------- work buffer layout
 // [0, 4096)                    small scalars / staging
@@ -611,6 +621,11 @@ extern "C" int mde_std_tangent(int64_t n, int32_t d, const float* X, float* Z, d
   if (n <= 0 || d <= 0 || d > 2048 || !X || !Z || !work) return MDE_E_INVALID;
   hipStream_t st = mde_stream(stream);
   double* G = work_mats(work);  // d x d : G[i][j] = sum_r Z[r][i] X[r][j]
+  if (mde_mfma_width_ok(d)) {
+    int rc = mde_mfma_gram(n, d, Z, X, nullptr, G, work_partials(work, d), MDE_PARTIAL_DOUBLES, st);
+    if (rc != MDE_OK) return rc;
+    return mde_mfma_rmul(n, d, X, G, nullptr, (float)(-1.0 / (double)n), Z, Z, st);
+  }
   int rc = gram_impl(n, d, d, Z, X, G, work_partials(work, d), work_ticket(work, TK_GRAM), st);
   if (rc != MDE_OK) return rc;
   return rmul_impl(n, d, d, X, G, (float)(-1.0 / (double)n), Z, Z, st);
@@ -803,97 +818,159 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_center_rmul_tiny(int64_t n, const
 }
 
 
-// ---------------------------------------------------------------- C^{-1/2}, d >= 32: one launch per half step
+// ---------------------------------------------------------------- C^{-1/2}, d >= 32: two launches per step
 // The single-workgroup iteration above needs three d^3 double products per step out of global
 // memory with 256 threads (22 ms at d = 128).  Here every product is spread over d^2 / 256
-// workgroups; the convergence test lives in a device flag that turns the remaining launches of
-// the fixed-length sequence into no-ops.
-//   ctl[0] = state: 0 iterating, 1 converged, 2 failed     ctl[1] = residual bits (max |I - Z Y|)
+// workgroups, two launches per step (T = (3 I - Z Y) / 2 with the residual; then Y T and T Z).
+// Every step has its own residual word, so a kernel can tell from the words of the earlier steps
+// whether the iteration is over -- no flag kernel, no state to reset -- and the host reads the
+// words back after each batch of MDE_NS_BATCH steps instead of enqueuing the worst-case count
+// (round 2 enqueued 180 launches + a memset per retraction; near-orthonormal iterates need 6 - 9
+// steps).
+//   ctl[0] = 2 when C is not usable, ctl[2] = the scale s, ctl[8 + s] = max |I - Z Y| of step s
+#define MDE_NS_MAX_STEPS 64
+#define MDE_NS_BATCH 6
+#define MDE_NS_TOL 1e-13
+// 0: still iterating after steps [0, upto); 1: converged (at *where); 2: failed
+__device__ __forceinline__ int ns_state(const double* __restrict__ ctl, int upto, int* where) {
+  if (ctl[0] == 2.0) return 2;
+  for (int s = 0; s < upto; ++s) {
+    const double r = ctl[8 + s];
+    if (r < MDE_NS_TOL) {
+      if (where) *where = s;
+      return 1;
+    }
+    if (!(r < 1e300)) return 2;
+  }
+  return 0;
+}
+// Y0 = sym(C) / s, Z0 = I with s = max_i sum_j |sym(C)_ij| >= lambda_max (Gershgorin): for the solver's
+// near-orthonormal iterates C ~ n I the eigenvalues of Y0 start close to 1 and the iteration is over
+// in 3 - 5 steps (the Frobenius norm used before starts them at 1 / sqrt(d): 9 - 10 steps).
+// Every workgroup forms s itself (d^2 doubles out of L2) and initialises its own slice.
 __global__ __launch_bounds__(MDE_BLOCK) void k_ns_init(int d, const double* __restrict__ C, double* __restrict__ Y,
                                                        double* __restrict__ Z, double* __restrict__ ctl) {
   __shared__ double smem[8];
-  const int m = d * d;
-  double ss = 0.0;
-  for (int i = threadIdx.x; i < m; i += MDE_BLOCK) ss += C[i] * C[i];
-  const double tot = mde_block_sum(ss, smem);
   __shared__ double sh;
-  if (threadIdx.x == 0) sh = sqrt(tot);
+  const int m = d * d;
+  // (column sums of |C|: coalesced; C is symmetric up to rounding, the symmetrised row sums differ in
+  // the last bits, which the iteration does not mind)
+  double mx = 0.0;
+  for (int c = threadIdx.x; c < d; c += MDE_BLOCK) {
+    double t = 0.0;
+#pragma unroll 8
+    for (int r = 0; r < d; ++r) t += fabs(C[r * d + c]);
+    t = (t == t) ? t : 1e308;
+    mx = t > mx ? t : mx;
+  }
+  const double tot = mde_block_max(mx, smem);
+  if (threadIdx.x == 0) sh = tot;
   __syncthreads();
   const double s = sh;
   const bool ok = (s > 0.0) && (s < 1e300);
-  for (int i = threadIdx.x; i < m; i += MDE_BLOCK) {
+  for (int i = blockIdx.x * MDE_BLOCK + threadIdx.x; i < m; i += gridDim.x * MDE_BLOCK) {
     const int r = i / d, c = i % d;
     Y[i] = ok ? 0.5 * (C[i] + C[c * d + r]) / s : 0.0;  // symmetrise
     Z[i] = (r == c) ? 1.0 : 0.0;
   }
-  if (threadIdx.x == 0) {
-    ctl[0] = ok ? 0.0 : 2.0;
-    ctl[1] = 0.0;
-    ctl[2] = s;
+  if (blockIdx.x == 0) {
+    for (int i = threadIdx.x; i < MDE_NS_MAX_STEPS; i += MDE_BLOCK) ctl[8 + i] = 0.0;
+    if (threadIdx.x == 0) {
+      ctl[0] = ok ? 0.0 : 2.0;
+      ctl[2] = s;
+    }
   }
 }
-// T = (3 I - Z Y) / 2 and the residual max |I - Z Y| (atomic max on the bit pattern of a non-negative double)
-__global__ __launch_bounds__(MDE_BLOCK) void k_ns_t(int d, const double* __restrict__ Y, const double* __restrict__ Z,
-                                                    double* __restrict__ T, double* __restrict__ ctl) {
-  if (ctl[0] != 0.0) return;
+// One 32 x 32 tile of P = A B (d x d doubles, row-major) per 256-thread workgroup: thread (ty, tx) owns
+// the 2 x 2 outputs at rows 2 ty, columns 2 tx of the tile; the operands pass through LDS in 32-wide
+// slabs of the inner index (row stride 33: no bank conflicts on the column reads).
+__device__ __forceinline__ void ns_tile_product(int d, const double* __restrict__ A, const double* __restrict__ B,
+                                                int ti, int tj, double (&o)[2][2]) {
+  __shared__ double As[32][33], Bs[32][33];
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  o[0][0] = o[0][1] = o[1][0] = o[1][1] = 0.0;
+  for (int k0 = 0; k0 < d; k0 += 32) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 1024; e += MDE_BLOCK) {
+      const int rr = e >> 5, cc = e & 31;
+      const int ar = ti * 32 + rr, ac = k0 + cc, br = k0 + rr, bc = tj * 32 + cc;
+      As[rr][cc] = (ar < d && ac < d) ? A[ar * d + ac] : 0.0;
+      Bs[rr][cc] = (br < d && bc < d) ? B[br * d + bc] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const double a0 = As[2 * ty][k], a1 = As[2 * ty + 1][k], b0 = Bs[k][2 * tx], b1 = Bs[k][2 * tx + 1];
+      o[0][0] = fma(a0, b0, o[0][0]);
+      o[0][1] = fma(a0, b1, o[0][1]);
+      o[1][0] = fma(a1, b0, o[1][0]);
+      o[1][1] = fma(a1, b1, o[1][1]);
+    }
+  }
+}
+// step: T = (3 I - Z Y) / 2 and the residual max |I - Z Y| (atomic max on the bit pattern of a
+// non-negative double; the word starts at +0.0).  grid = (tiles, tiles)
+__global__ __launch_bounds__(MDE_BLOCK) void k_ns_t(int d, int step, const double* __restrict__ Y,
+                                                    const double* __restrict__ Z, double* __restrict__ T,
+                                                    double* __restrict__ ctl) {
+  if (ns_state(ctl, step, nullptr) != 0) return;
   __shared__ double smem[8];
-  const int i = blockIdx.x * MDE_BLOCK + threadIdx.x;
-  double e = 0.0;
-  if (i < d * d) {
-    const int r = i / d, c = i % d;
-    double acc = 0.0;
-    for (int k = 0; k < d; ++k) acc = fma(Z[r * d + k], Y[k * d + c], acc);
-    e = ((r == c) ? 1.0 : 0.0) - acc;
-    T[i] = ((r == c) ? 1.0 : 0.0) + 0.5 * e;
-    e = (e == e) ? fabs(e) : 1e308;
-  }
-  const double mx = mde_block_max(e, smem);
+  double o[2][2];
+  ns_tile_product(d, Z, Y, blockIdx.y, blockIdx.x, o);
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+  double emax = 0.0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int r = blockIdx.y * 32 + 2 * ty + a, c = blockIdx.x * 32 + 2 * tx + b;
+      if (r < d && c < d) {
+        const double e = ((r == c) ? 1.0 : 0.0) - o[a][b];
+        T[r * d + c] = ((r == c) ? 1.0 : 0.0) + 0.5 * e;
+        const double ae = (e == e) ? fabs(e) : 1e308;
+        emax = ae > emax ? ae : emax;
+      }
+    }
+  const double mx = mde_block_max(emax, smem);
   if (threadIdx.x == 0)
-    atomicMax(reinterpret_cast<unsigned long long*>(ctl + 1), (unsigned long long)__double_as_longlong(mx));
+    atomicMax(reinterpret_cast<unsigned long long*>(ctl + 8 + step), (unsigned long long)__double_as_longlong(mx));
 }
-// (Y, Z) <- (Y T, T Z) unless the residual of this step says converged / failed
-__global__ __launch_bounds__(MDE_BLOCK) void k_ns_yz(int d, const double* __restrict__ Y, const double* __restrict__ Z,
-                                                     const double* __restrict__ T, double* __restrict__ Yn,
-                                                     double* __restrict__ Zn, const double* __restrict__ ctl) {
-  if (ctl[0] != 0.0) return;
-  const double res = ctl[1];
-  if (res < 1e-13 || !(res < 1e300)) return;  // k_ns_flag records it
-  const int i = blockIdx.x * MDE_BLOCK + threadIdx.x;
-  if (i >= d * d) return;
-  const int r = i / d, c = i % d;
-  double ay = 0.0, az = 0.0;
-  for (int k = 0; k < d; ++k) {
-    ay = fma(Y[r * d + k], T[k * d + c], ay);
-    az = fma(T[r * d + k], Z[k * d + c], az);
-  }
-  Yn[i] = ay;
-  Zn[i] = az;
+// step: (Yn, Zn) = (Y T, T Z) unless the iteration ended with this step's residual.
+// grid = (tiles, tiles, 2): z = 0 forms Y T, z = 1 forms T Z
+__global__ __launch_bounds__(MDE_BLOCK) void k_ns_yz(int d, int step, const double* __restrict__ Y,
+                                                     const double* __restrict__ Z, const double* __restrict__ T,
+                                                     double* __restrict__ Yn, double* __restrict__ Zn,
+                                                     const double* __restrict__ ctl) {
+  if (ns_state(ctl, step + 1, nullptr) != 0) return;
+  double o[2][2];
+  const bool first = blockIdx.z == 0;
+  ns_tile_product(d, first ? Y : T, first ? T : Z, blockIdx.y, blockIdx.x, o);
+  double* out = first ? Yn : Zn;
+  const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int r = blockIdx.y * 32 + 2 * ty + a, c = blockIdx.x * 32 + 2 * tx + b;
+      if (r < d && c < d) out[r * d + c] = o[a][b];
+    }
 }
-// after k_ns_yz: fold the residual into the state and reset it for the next step
-__global__ void k_ns_flag(double* __restrict__ ctl, int* __restrict__ which) {
-  if (ctl[0] != 0.0) return;
-  const double res = ctl[1];
-  if (res < 1e-13)
-    ctl[0] = 1.0;
-  else if (!(res < 1e300))
-    ctl[0] = 2.0;
-  else
-    *which ^= 1;  // the new (Y, Z) pair is the current one
-  ctl[1] = 0.0;
-}
-__global__ __launch_bounds__(MDE_BLOCK) void k_ns_finish(int d, const double* __restrict__ Z0, const double* __restrict__ Z1,
-                                                         const int* __restrict__ which, const double* __restrict__ ctl,
+// M = out_scale / sqrt(s) * Z of the step that converged (step s left its pair in buffer s & 1)
+__global__ __launch_bounds__(MDE_BLOCK) void k_ns_finish(int d, int nsteps, const double* __restrict__ Z0,
+                                                         const double* __restrict__ Z1, const double* __restrict__ ctl,
                                                          double out_scale, double* __restrict__ M,
                                                          int32_t* __restrict__ status) {
-  const bool ok = ctl[0] == 1.0;
-  const double* Z = *which ? Z1 : Z0;
+  int where = 0;
+  const bool ok = ns_state(ctl, nsteps, &where) == 1;
+  const double* Z = (where & 1) ? Z1 : Z0;
   const double k = ok ? out_scale / sqrt(ctl[2]) : 0.0;
   for (int i = blockIdx.x * MDE_BLOCK + threadIdx.x; i < d * d; i += gridDim.x * MDE_BLOCK) M[i] = ok ? Z[i] * k : 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 0 && status && !ok) *status = 1;
 }
 
-// M = out_scale * C^{-1/2}: the single-workgroup kernel for small d, the launch sequence above otherwise
-static int invsqrt_impl(int d, const double* C, double out_scale, double* M, double* scratch /* 5 d^2 + 8 */,
+// M = out_scale * C^{-1/2}: the single-workgroup kernel for small d, the launch sequence above
+// otherwise (SYNC for d >= 32: the residual words are read back after every batch of steps)
+static int invsqrt_impl(int d, const double* C, double out_scale, double* M, double* scratch /* 5 d^2 + 8 + 64 */,
                         int32_t* status_dev, hipStream_t st) {
   if (d < 32) {
     hipLaunchKernelGGL(k_invsqrt, dim3(1), dim3(MDE_BLOCK), 0, st, d, C, out_scale, M, scratch, status_dev);
@@ -904,25 +981,27 @@ static int invsqrt_impl(int d, const double* C, double out_scale, double* M, dou
   double* Y[2] = {scratch, scratch + 3 * m};
   double* Z[2] = {scratch + m, scratch + 4 * m};
   double* T = scratch + 2 * m;
-  double* ctl = scratch + 5 * m;         // 3 doubles
-  int* which = reinterpret_cast<int*>(ctl + 4);
-  MDE_HIP(hipMemsetAsync(which, 0, sizeof(int), st));
-  hipLaunchKernelGGL(k_ns_init, dim3(1), dim3(MDE_BLOCK), 0, st, d, C, Y[0], Z[0], ctl);
+  double* ctl = scratch + 5 * m;         // 8 + MDE_NS_MAX_STEPS doubles
+  hipLaunchKernelGGL(k_ns_init, dim3(mde_grid(m, MDE_BLOCK, 64)), dim3(MDE_BLOCK), 0, st, d, C, Y[0], Z[0], ctl);
   MDE_LAUNCH_CHECK();
-  const int nb = (int)((m + MDE_BLOCK - 1) / MDE_BLOCK);
-  // Near-orthonormal inputs (the solver's iterates) converge in < 10 steps; the 60 launched here
-  // cover condition numbers up to ~1e12.  The (Y, Z) pair alternates between two buffers (two
-  // steps per trip); once the state word leaves 0 the remaining launches return at once, and the
-  // device word `which` says which buffer holds the result.
-  for (int it = 0; it < 30; ++it) {
-    for (int h = 0; h < 2; ++h) {
-      hipLaunchKernelGGL(k_ns_t, dim3(nb), dim3(MDE_BLOCK), 0, st, d, Y[h], Z[h], T, ctl);
-      hipLaunchKernelGGL(k_ns_yz, dim3(nb), dim3(MDE_BLOCK), 0, st, d, Y[h], Z[h], T, Y[h ^ 1], Z[h ^ 1], ctl);
-      hipLaunchKernelGGL(k_ns_flag, dim3(1), dim3(1), 0, st, ctl, which);
+  const unsigned nt = (unsigned)((d + 31) / 32);
+  int steps = 0;
+  double host[8 + MDE_NS_MAX_STEPS];
+  bool done = false;
+  while (!done && steps < MDE_NS_MAX_STEPS) {
+    const int upto = std::min(MDE_NS_MAX_STEPS, steps + MDE_NS_BATCH);
+    for (; steps < upto; ++steps) {
+      const int h = steps & 1;
+      hipLaunchKernelGGL(k_ns_t, dim3(nt, nt), dim3(MDE_BLOCK), 0, st, d, steps, Y[h], Z[h], T, ctl);
+      hipLaunchKernelGGL(k_ns_yz, dim3(nt, nt, 2), dim3(MDE_BLOCK), 0, st, d, steps, Y[h], Z[h], T, Y[h ^ 1], Z[h ^ 1], ctl);
     }
+    MDE_LAUNCH_CHECK();
+    MDE_HIP(hipMemcpyAsync(host, ctl, sizeof(double) * (8 + (size_t)steps), hipMemcpyDeviceToHost, st));
+    MDE_HIP(hipStreamSynchronize(st));
+    if (host[0] == 2.0) done = true;
+    for (int s = 0; s < steps && !done; ++s) done = (host[8 + s] < MDE_NS_TOL) || !(host[8 + s] < 1e300);
   }
-  MDE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_ns_finish, dim3(mde_grid(m, MDE_BLOCK, 64)), dim3(MDE_BLOCK), 0, st, d, Z[0], Z[1], which, ctl,
+  hipLaunchKernelGGL(k_ns_finish, dim3(mde_grid(m, MDE_BLOCK, 64)), dim3(MDE_BLOCK), 0, st, d, steps, Z[0], Z[1], ctl,
                      out_scale, M, status_dev);
   MDE_LAUNCH_CHECK();
   return MDE_OK;
@@ -956,6 +1035,20 @@ extern "C" int mde_std_retract(int64_t n, int32_t d, float* Z, int32_t demean, d
   }
     TINY(1) TINY(2) TINY(3) TINY(4)
 #undef TINY
+  }
+  if (mde_mfma_width_ok(d)) {
+    // three reads and one write of Z: column means, the Gram matrix of the centred rows (the mean is
+    // subtracted in registers), C^{-1/2}, and (Z - mean) M written in place
+    double* mean = work;  // small area
+    if (demean) {
+      rc = mde_mfma_colmean(n, d, Z, work_partials(work, d), mean, st);
+      if (rc != MDE_OK) return rc;
+    }
+    rc = mde_mfma_gram(n, d, Z, Z, demean ? mean : nullptr, C, work_partials(work, d), MDE_PARTIAL_DOUBLES, st);
+    if (rc != MDE_OK) return rc;
+    rc = invsqrt_impl(d, C, sqrt((double)n), M, scratch, status_dev, st);
+    if (rc != MDE_OK) return rc;
+    return mde_mfma_rmul(n, d, Z, M, demean ? mean : nullptr, 1.0f, nullptr, Z, st);
   }
   if (demean) {
     rc = center_impl(n, d, Z, work, st);
