@@ -354,21 +354,11 @@ int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, const float*
                        float* d_out, double* stats, double* work, void* stream);
 int mde_lbfgs_dev_info(const mde_lbfgs* o, int32_t* count_host, int32_t* accepted_host, void* stream);
 
-/* ---- replaying an iteration's launch sequence as one HIP graph ------------------------------------
- * [ref: the loop accelerated is optim.py:100-175 + lbfgs.py:390-590; the reference has no counterpart.]
- * Between mde_capture_begin(stream) and mde_capture_end(stream, &c) every ASYNC entry point above
- * called on `stream` is RECORDED instead of executed (HIP stream capture; `stream` must be a created
- * stream, not the legacy default one, and no SYNC entry point may be called in between);
- * mde_capture_launch replays the recorded kernels, memsets and copies with one launch -- same kernels,
- * same arguments, same order, hence the same bits as calling the entry points again.
- * mde_capture_abort leaves capture mode and discards what was recorded (error paths).
- * mde_copy_to_host is the device -> pinned-host read-back to use inside a captured sequence. */
-typedef struct mde_capture mde_capture;
-int mde_capture_begin(void* stream);
-int mde_capture_end(void* stream, mde_capture** out);
-int mde_capture_abort(void* stream);
-int mde_capture_launch(mde_capture* c, void* stream);
-int mde_capture_destroy(mde_capture* c);
+/* ---- the solver's read-back -------------------------------------------------------------------------
+ * device -> pinned-host copy on the stream: [loss | status | statistics board] travels in one copy per
+ * objective evaluation [ref: the loop accelerated is optim.py:100-175 + lbfgs.py:390-590, which
+ * synchronises >= 12 times per iteration].  (Round 2 also exported mde_capture_* to replay an
+ * iteration as one HIP graph; measured slower than the launches it replaced, removed in round 3.) */
 int mde_copy_to_host(void* dst_host, const void* src_dev, int64_t bytes, void* stream);
 
 #ifdef __cplusplus

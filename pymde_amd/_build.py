@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libmde_hip.so")
-SOURCES = ["mde_plan.hip", "mde_distortion.hip", "mde_ring.hip", "mde_vec.hip", "mde_mfma.hip", "mde_edges.hip", "mde_knn.hip", "mde_graph.hip", "mde_capture.hip"]
+SOURCES = ["mde_plan.hip", "mde_distortion.hip", "mde_ring.hip", "mde_vec.hip", "mde_mfma.hip", "mde_edges.hip", "mde_knn.hip", "mde_graph.hip"]
 ARCH = "gfx950"
 
 

@@ -90,11 +90,6 @@ SYMBOLS = {
     "mde_lbfgs_dev_info": (c_i32, [c_vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), c_vp]),
     "mde_lbfgs_combine": (c_i32, [c_vp, c_vp, c_f32, ctypes.POINTER(c_f32),
                                   ctypes.POINTER(c_f32), c_vp, c_vp, c_vp, c_vp]),
-    "mde_capture_begin": (c_i32, [c_vp]),
-    "mde_capture_end": (c_i32, [c_vp, ctypes.POINTER(c_vp)]),
-    "mde_capture_abort": (c_i32, [c_vp]),
-    "mde_capture_launch": (c_i32, [c_vp, c_vp]),
-    "mde_capture_destroy": (c_i32, [c_vp]),
     "mde_copy_to_host": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
 }
 

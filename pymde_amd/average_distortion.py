@@ -29,7 +29,8 @@ def _check_X(X, n=None, d=None):
         raise ValueError("the embedding must be a 2-D tensor")
     if X.dtype != torch.float32:
         raise ValueError(
-            "pymde_amd computes in float32; got an embedding of dtype %s" % X.dtype)
+            "pymde_amd computes in float32; got an embedding of dtype %s (MDE.embed and "
+            "MDE.average_distortion cast float64 inputs with a warning; the kernels themselves do not)" % X.dtype)
     util.require_cuda_device(X.device)
     if n is not None and X.shape[0] != n:
         raise ValueError("embedding has %d rows, the problem has %d items" % (X.shape[0], n))
@@ -316,17 +317,21 @@ def _average_distortion(X, f, lhs, rhs):
     (average_distortion.py:109): lhs/rhs are the (expanded) endpoint index tensors."""
     li = lhs[:, 0] if lhs.dim() == 2 else lhs
     ri = rhs[:, 0] if rhs.dim() == 2 else rhs
-    key = (id(lhs), id(rhs), X.shape[0], str(X.device), id(f))
+    # keyed on what the index tensors ARE (storage address, offset, strides, length, in-place
+    # version), not on the Python objects: a caller that slices edges[:, 0] / edges[:, 1] afresh on
+    # every call gets the same plan back.  The entry keeps the storages and f alive, so an address
+    # cannot be reused while it is cached.
+    def ident(t):
+        return (t.untyped_storage().data_ptr(), t.storage_offset(), tuple(t.stride()), tuple(t.shape), t._version,
+                str(t.dtype), str(t.device))
+    key = (ident(lhs), ident(rhs), X.shape[0], str(X.device), id(f))
     hit = _PLAN_CACHE.get(key)
-    # an entry is valid only for the very same tensor / function objects, unmodified since: the
-    # entry keeps them alive (no address reuse) and remembers their in-place version counters
-    if hit is not None and (hit[1] is not lhs or hit[2] is not rhs or hit[3] is not f
-                            or hit[4] != (lhs._version, rhs._version)):
+    if hit is not None and hit[3] is not f:
         hit = None
     if hit is None:
         edges = torch.stack([li, ri], dim=1).to(device=X.device, dtype=torch.int64).contiguous()
         binding = Binding(EdgePlan(X.shape[0], edges), f)
         if len(_PLAN_CACHE) > 8:
             _PLAN_CACHE.clear()
-        hit = _PLAN_CACHE[key] = (binding, lhs, rhs, f, (lhs._version, rhs._version))
+        hit = _PLAN_CACHE[key] = (binding, lhs.untyped_storage(), rhs.untyped_storage(), f)
     return _AverageDistortion.apply(X, hit[0])

@@ -42,6 +42,14 @@ static inline double* work_partials(double* work, int d) {
   return work + MDE_SMALL_DOUBLES + 8 * (int64_t)d * d;
 }
 
+// device -> pinned host copy on the stream (the solver's one read-back per evaluation)
+extern "C" int mde_copy_to_host(void* dst_host, const void* src_dev, int64_t bytes, void* stream) {
+  if (!dst_host || !src_dev || bytes < 0) return MDE_E_INVALID;
+  if (bytes == 0) return MDE_OK;
+  MDE_HIP(hipMemcpyAsync(dst_host, src_dev, (size_t)bytes, hipMemcpyDeviceToHost, mde_stream(stream)));
+  return MDE_OK;
+}
+
 // ---------------------------------------------------------------- generic row reduction
 // out[q] = reduce_b partial[q * nb + b]; mode_mask bit q set -> max, else sum
 __global__ void k_reduce_rows(int nq, int nb, const double* __restrict__ partial,

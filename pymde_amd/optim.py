@@ -60,8 +60,6 @@ class SolveStats(object):
         p.text(self.__str__())
 
 
-GRAPH_REPLAYS = 0  # iterations replayed as one HIP graph in this process (diagnostics / tests)
-
 # indices into the statistics board (mde_vec_stats)
 _GD, _GG, _G1, _GMAX, _NONFINITE, _DD, _DMAX, _XX, _LOSS = range(9)
 _DIR = 16  # offset (doubles) of the direction statistics written by update_direction
@@ -93,6 +91,7 @@ class _Engine(object):
         self.g_prev = torch.empty_like(self.X)
         self.dir = torch.empty_like(self.X)
         self.work = util.work_buffer(dev, self.d)
+        util.reset_work_tickets(self.work)
         self.board = self.gtail[self._board_off:].view(torch.float64)
         self.status = self.gtail[self.N + 1:self.N + 2].view(torch.int32)
         # pinned mirror of [loss | status | pad | board]
@@ -108,10 +107,6 @@ class _Engine(object):
         # the solve runs on the stream that is current now; its handle is looked up once
         self._stream_obj = torch.cuda.current_stream(dev)
         self._stream = ctypes.c_void_p(self._stream_obj.cuda_stream)
-        # replaying the usual iteration as one HIP graph needs a created stream (the legacy default
-        # stream cannot be captured); lbfgs() provides one for native problems
-        self.graph_ok = False
-        self._captures = []
         # the solve runs on the stream that is current now; its handle is looked up once
         self._stream_obj = torch.cuda.current_stream(dev)
         self._stream = ctypes.c_void_p(self._stream_obj.cuda_stream)
@@ -124,9 +119,6 @@ class _Engine(object):
         self.lbfgs = handle
 
     def close(self):
-        for handle in self._captures:
-            self.lib.mde_capture_destroy(handle)
-        self._captures = []
         if self.lbfgs is not None:
             self.lib.mde_lbfgs_destroy(self.lbfgs)
             self.lbfgs = None
@@ -145,7 +137,7 @@ class _Engine(object):
 
     def enqueue_read(self, count):
         """Enqueue the device->host copy of [loss | status | first ``count`` doubles of the board]
-        (one contiguous range; a graph node when the stream is being captured)."""
+        (one contiguous range)."""
         _lib.check(self.lib.mde_copy_to_host(self._host_ptr, self._tail_ptr, self._head_bytes + 8 * int(count),
                                              self.stream()))
 
@@ -158,33 +150,6 @@ class _Engine(object):
         """One device->host read-back of the first ``count`` doubles plus the loss."""
         self.enqueue_read(count)
         return self.finish_read(count)
-
-    # ---- one launch for the usual iteration (mde_capture_*)
-    def capture(self, enqueue):
-        """Record what ``enqueue()`` puts on the solve's stream; returns a replayable handle, or None
-        when recording is not possible (the solver then keeps enqueueing call by call)."""
-        if not self.graph_ok:
-            return None
-        try:
-            _lib.check(self.lib.mde_capture_begin(self.stream()))
-        except _lib.MdeHipError:
-            self.graph_ok = False
-            return None
-        handle = ctypes.c_void_p()
-        try:
-            enqueue()
-            _lib.check(self.lib.mde_capture_end(self.stream(), ctypes.byref(handle)))
-        except Exception:
-            self.lib.mde_capture_abort(self.stream())
-            self.graph_ok = False
-            return None
-        self._captures.append(handle)
-        return handle
-
-    def replay(self, handle):
-        global GRAPH_REPLAYS
-        _lib.check(self.lib.mde_capture_launch(handle, self.stream()))
-        GRAPH_REPLAYS += 1
 
     # ---- L-BFGS memory
     def reset_memory(self):
@@ -331,21 +296,13 @@ def lbfgs(X, objective_fn, constraint, eps, max_iter, memory_size, use_line_sear
     start_time = time.time()
     average_distortions, grad_norms, step_size_percents, times, snapshots = [], [], [], [], []
 
-    # PYMDE_AMD_GRAPH=1: a native problem (built-in function and constraint, single GPU) is solved on
-    # a stream of its own and its usual iteration is recorded once and replayed as one HIP graph
-    # (_solve; the legacy default stream cannot be captured).  Off by default: with ROCm 7.2 the
-    # replay of the ~25-node graph is slower than the 25 launches it replaces (config 2: 0.249 vs
-    # 0.178 ms per iteration, config 3: 0.82 vs 0.70), see DESIGN.md section 3.
+    # (Replaying the usual iteration as one HIP graph was built in round 2 and measured SLOWER than the
+    # launches it replaces on ROCm 7.2 -- config 2: 0.249 vs 0.178 ms per iteration -- and was removed in
+    # round 3; cutting the launch count is what paid.)
     device = util.require_cuda_device(X.device)
-    use_graph = (os.environ.get("PYMDE_AMD_GRAPH", "0") == "1" and use_line_search
-                 and _is_native(objective_fn, constraint, require_fused_single_gpu=True))
     caller_stream = torch.cuda.current_stream(device)
-    side = torch.cuda.Stream(device) if use_graph else None
-    if side is not None:
-        side.wait_stream(caller_stream)
-    with torch.cuda.device(device), torch.cuda.stream(side if side is not None else caller_stream):
+    with torch.cuda.device(device), torch.cuda.stream(caller_stream):
         engine = _Engine(X, memory_size)
-        engine.graph_ok = use_graph
         try:
             with torch.no_grad():
                 problem = _make_problem(engine, objective_fn, constraint)
@@ -356,8 +313,6 @@ def lbfgs(X, objective_fn, constraint, eps, max_iter, memory_size, use_line_sear
         finally:
             engine._stream_obj.synchronize()
             engine.close()
-    if side is not None:
-        caller_stream.wait_stream(side)
     if isinstance(X, torch.Tensor) and X.shape == X_final.shape and X.device == X_final.device \
             and X.is_contiguous() and not X.requires_grad:
         X.copy_(X_final)  # the reference updates the caller's tensor in place
@@ -378,7 +333,6 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
     last_gg = 0.0       # ||g||^2 of the last evaluated gradient (X.grad)
     norm_X = None       # ||X||_F of the current iterate (None: not known yet)
     t = 0.0
-    graphs = {}         # buffer parity -> recorded launch sequence of the usual iteration
 
     def evaluate_at_current():
         """closure() at X: no move, no retraction (lbfgs.py:426)."""
@@ -440,31 +394,12 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
             # the first trial point is enqueued before the direction statistics are known; both
             # come back in one read
             t_prev, t = t, 1.0
-            if use_line_search and e.graph_ok and t_prev == 1.0 and n_iter > 3:
-                # the usual iteration (previous step accepted at t = 1, first trial at t = 1): its
-                # launch sequence -- direction update, trial point, evaluation, statistics, read-back
-                # -- is recorded once per buffer parity and replayed as one HIP graph
-                key = e.X.data_ptr()
-                cap = graphs.get(key)
-                if cap is None:
-                    def usual():
-                        e.update_direction(1.0)
-                        enqueue_trial(1.0)
-                        e.enqueue_read(8 + _DIR)
-                    cap = graphs[key] = e.capture(usual) or False
-                if cap:
-                    e.replay(cap)
-                    first, v = finish_trial(1.0, extra=_DIR)
-                else:
-                    e.update_direction(t_prev)
-                    first, v = phi(t, extra=_DIR)
+            e.update_direction(t_prev)
+            if use_line_search:
+                first, v = phi(t, extra=_DIR)
             else:
-                e.update_direction(t_prev)
-                if use_line_search:
-                    first, v = phi(t, extra=_DIR)
-                else:
-                    first = None
-                    v, _ = e.read_board(_DIR + 8)
+                first = None
+                v, _ = e.read_board(_DIR + 8)
             dv = v[_DIR:_DIR + 8]
             gtd, d_norm2, d_max = dv[_GD], math.sqrt(dv[_DD]), dv[_DMAX]
         else:

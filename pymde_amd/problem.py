@@ -41,6 +41,9 @@ def _module_device(module):
     return dev if all(str(b.device) == dev for b in bufs) else None
 
 
+_WARNED_F64 = False
+
+
 class MDE(torch.nn.Module):
     """An MDE problem: ``n_items`` items embedded in ``R^embedding_dim``, a list of ``edges``
     (pairs i != j), a vector distortion function mapping the p embedding distances to p
@@ -167,6 +170,15 @@ class MDE(torch.nn.Module):
                 "provide a value for the embedding argument `X`")
         if X.device != self.device:
             X = X.to(self.device)
+        if X.dtype == torch.float64:
+            # the reference follows the dtype of X (average_distortion.py:96-98); this package
+            # computes in float32: cast (differentiably) and say so once
+            global _WARNED_F64
+            if not _WARNED_F64:
+                LOGGER.warning("pymde_amd computes in float32: float64 embeddings are cast to float32 "
+                               "(gradients flow back through the cast)")
+                _WARNED_F64 = True
+            X = X.to(torch.float32)
         return X
 
     # ------------------------------------------------------------------ evaluators

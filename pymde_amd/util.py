@@ -110,10 +110,12 @@ _WORK = {}
 
 
 def work_buffer(device, d):
-    """Per-device scratch (doubles) for the reduction / Gram kernels."""
+    """Scratch (doubles) for the reduction / Gram kernels, one buffer per (device, current stream):
+    the kernels that finish their reduction in the last workgroup keep arrival counters in it, so
+    two streams must never share one."""
     lib = _lib.load()
     need = int(lib.mde_work_doubles(int(d)))
-    key = str(device)
+    key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
     buf = _WORK.get(key)
     if buf is None or buf.numel() < need:
         # zeroed once: the small area holds the arrival counters of the kernels that finish their
@@ -121,6 +123,13 @@ def work_buffer(device, d):
         buf = torch.zeros(need, dtype=torch.float64, device=device)
         _WORK[key] = buf
     return buf
+
+
+def reset_work_tickets(buf):
+    """Zero the arrival counters of a work buffer (the last 32 doubles of its 4096-double small
+    area): a launch that faulted may have left one non-zero, after which no workgroup would ever see
+    itself as the last one."""
+    buf[4096 - 32:4096].zero_()
 
 
 def proj_standardized(X, demean=False, inplace=False):

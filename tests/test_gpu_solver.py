@@ -339,11 +339,11 @@ def test_device_driven_lbfgs_step_matches_explicit_two_loop():
 
 
 @pytest.mark.parametrize("cname", ["centered", "standardized", "anchored"])
-def test_graph_replay_equals_call_by_call_launches(cname, monkeypatch):
-    """The usual iteration replayed as one HIP graph (mde_capture_*) runs the same kernels with the
-    same arguments in the same order as the call-by-call path: identical iterates and statistics."""
+def test_solve_is_bitwise_reproducible(cname):
+    """Two solves of the same problem from the same start give identical iterates and statistics:
+    every reduction on the path (loss, vector statistics, L-BFGS inner products, projections) has a
+    fixed order and the fused kernels use no atomics on data."""
     import pymde_amd
-    from pymde_amd import optim
     rng = np.random.default_rng(3)
     n, p = 20000, 150000
     i = rng.integers(0, n, p)
@@ -359,20 +359,17 @@ def test_graph_replay_equals_call_by_call_launches(cname, monkeypatch):
             return pymde_amd.Anchored(anchors, values)
         return pymde_amd.Centered() if cname == "centered" else pymde_amd.Standardized()
 
-    results = {}
-    for mode in ("0", "1"):
+    results = []
+    for _ in range(2):
         rng2 = np.random.default_rng(9)
-        monkeypatch.setenv("PYMDE_AMD_GRAPH", mode)
         c = make()
         f = pymde_amd.penalties.PushAndPull(torch.tensor(w, device="cuda"))
         mde = pymde_amd.MDE(n, 2, edges, f, constraint=c)
         X0 = c.project_onto_constraint(torch.tensor(np.random.default_rng(4).standard_normal((n, 2)).astype(np.float32),
                                                     device="cuda"))
-        before = optim.GRAPH_REPLAYS
         X = mde.embed(X=X0.clone(), max_iter=60, eps=0.0, snapshot_every=25).clone()
-        results[mode] = (X, mde.solve_stats, optim.GRAPH_REPLAYS - before)
-    (Xe, se, ne), (Xg, sg, ng) = results["0"], results["1"]
-    assert ne == 0 and ng >= 30, (ne, ng)
+        results.append((X, mde.solve_stats))
+    (Xe, se), (Xg, sg) = results
     assert torch.equal(Xe, Xg), float((Xe - Xg).abs().max())
     assert se.average_distortions == sg.average_distortions
     assert se.residual_norms == sg.residual_norms
