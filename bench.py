@@ -440,7 +440,12 @@ def run_config5_embed(args, device):
     edges, w, _ = make_workload(device, n=n, deg=deg, d=2)
     p = edges.shape[0]
     c = pymde_amd.Standardized()
-    mde = pymde_amd.MDE(n, d, edges, pymde_amd.penalties.Log1p(w), constraint=c, device=device)
+    # The mean over 2e7 edges of an O(1) penalty has gradient entries of ~5e-9: below the float32
+    # resolution of the O(1) coordinates, so X + t d == X and the unscaled problem cannot leave its start in
+    # float32 (the reference forms the same update in float32).  The weights are therefore scaled by 1e5
+    # for the embed() record -- the arithmetic per iteration is the same.
+    wscale = 1.0e5
+    mde = pymde_amd.MDE(n, d, edges, pymde_amd.penalties.Log1p(w * wscale), constraint=c, device=device)
     torch.manual_seed(0)
     X0 = c.initialization(n, d, device=device).contiguous()
     iters = max(args.steps if args.steps != 200 else 20, 1)
@@ -468,10 +473,11 @@ def run_config5_embed(args, device):
         "n_gpus": 1, "steps": n_it, "warmup": 3, "ms_per_step": 1e3 * dt / n_it, "higher_is_better": False,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[4] / SURVEY 8d config 5 as an embed(): n=%d, |E|=%d uniform-random edges "
-                               "(out-degree 40), d=128, penalties.Log1p(1.5), weights {1,2}, Standardized, L-BFGS memory 10, "
-                               "X0 = Standardized().initialization" % (n, p),
+                               "(out-degree 40), d=128, penalties.Log1p(1.5), weights {1,2} x 1e5 (unscaled, the gradient "
+                               "entries of ~5e-9 are below float32 resolution of the coordinates and no float32 solver "
+                               "moves), Standardized, L-BFGS memory 10, X0 = Standardized().initialization" % (n, p),
                    "parallelism": "single GPU", "edges_per_s_per_iter": p * n_it / dt,
-                   "final_average_distortion": float(mde.value),
+                   "average_distortions": [float(v) for v in st.average_distortions],
                    "component_ms": {"average_distortion fwd+bwd (k_fused_wide4)": t_eval,
                                     "Standardized tangent projection": t_tan,
                                     "Standardized retraction": t_ret},

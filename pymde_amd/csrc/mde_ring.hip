@@ -1299,6 +1299,12 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
             // kept apart and combined (with 1 / 1.5) once per wave
             const float c = d * sd - (t - 1.0f);
             float wl = x.p0, gc = gd;
+            if (!LIN) {
+              // (one scalar parameter for every lane: the padding lanes carry it too)
+              const bool real = rowaddr < dummy_row;
+              wl = real ? wl : 0.0f;
+              gc = real ? gc : 0.0f;
+            }
             if (lcls == 2u) {
               const bool here = counts_here(w, hm);
               wl = here ? wl : 0.0f;

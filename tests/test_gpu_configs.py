@@ -118,6 +118,43 @@ def test_config4_full_size_against_oracle_and_invariants():
         total += part
     np.testing.assert_allclose(total[:n * d].cpu().numpy(), buf[:n * d].cpu().numpy(), rtol=1e-5, atol=1e-12)
     assert float(total[n * d]) == pytest.approx(float(buf[n * d]), rel=1e-6)
+    # ... and the 4-way sharded ring result against the ORACLE at the kernel tolerances
+    assert float(total[n * d]) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(total[:n * d].view(n, d).cpu().numpy(), wgrad)
+
+
+def test_config4b_pushpull_full_size_against_oracle():
+    """SURVEY 8d config 4b at full size: n = 1M, |E| = 50M, d = 2, PushAndPull(Log1p, Log) with the
+    last third of the edges repulsive (w = -1) -- the LDS-ring kernel (compile-time functor pair,
+    codebook stream of three values) against the OpenMP oracle, unsharded and as an 8-way shard."""
+    import bench
+    import pymde_amd
+    from pymde_amd import distributed
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    dev = torch.device(DEV, 0)
+    edges, w, X = bench.make_workload(dev)
+    n, d, p = X.shape[0], 2, edges.shape[0]
+    w = w.clone()
+    w[(2 * p) // 3:] = -1.0
+    pen = pymde_amd.penalties
+    f = pen.PushAndPull(w, pen.Log1p, pen.Log)
+    binding = Binding(EdgePlan(n, edges), f)
+    buf = torch.zeros(n * d + 1, device=dev)
+    fused_evaluate(binding, X, buf[:n * d].view(n, d), buf[n * d:])
+    assert binding.struct(d).layout == 1 and binding.codebook
+    wE, wgrad = oracle.average_distortion(edges.cpu().numpy(), X.cpu().numpy(),
+                                          oracle.func("LOG1P", w.cpu().numpy(), None, (1.5,), "LOG", (1.0,)))
+    assert float(buf[n * d]) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(buf[:n * d].view(n, d).cpu().numpy(), wgrad)
+    bounds = distributed.shard_bounds(n, edges, 8)
+    total = torch.zeros_like(buf)
+    for r in range(8):
+        lo, hi = distributed.shard_range(bounds, r)
+        part = torch.zeros_like(buf)
+        fused_evaluate(Binding(EdgePlan(n, edges, lo, hi), f), X, part[:n * d].view(n, d), part[n * d:])
+        total += part
+    assert float(total[n * d]) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(total[:n * d].view(n, d).cpu().numpy(), wgrad)
 
 
 def test_config5_high_dim_standardized():
@@ -167,3 +204,32 @@ def test_config5_high_dim_standardized():
                                           oracle.func("LOG1P", ws.cpu().numpy(), None, (1.5,)))
     assert float(out[m * d]) == pytest.approx(wE, rel=1e-5)
     assert_grad_close(out[:m * d].view(m, d).cpu().numpy(), wgrad)
+
+
+def test_config5_full_size_against_oracle():
+    """configs[4] at FULL size against the oracle: n = 500k, |E| = 20M, d = 128, Quadratic and Log1p
+    (the OpenMP oracle on 8 threads keeps 8 x 512 MB of per-thread gradient accumulators)."""
+    import pymde_amd
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    dev = torch.device(DEV, 0)
+    n, d, deg = 500_000, 128, 40
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0)
+    src = torch.arange(n, device=dev).repeat_interleave(deg)
+    dst = torch.randint(0, n - 1, (n * deg,), device=dev, generator=gen)
+    dst += (dst >= src).long()
+    edges = torch.stack([torch.minimum(src, dst), torch.maximum(src, dst)], 1).contiguous()
+    w = 1.0 + (torch.rand(n * deg, device=dev, generator=gen) < 0.3).float()
+    torch.manual_seed(0)
+    X = pymde_amd.Standardized().initialization(n, d, device=dev)
+    plan = EdgePlan(n, edges)
+    e_np, w_np, X_np = edges.cpu().numpy(), w.cpu().numpy(), X.cpu().numpy()
+    L = oracle.lib()
+    L.oracle_set_num_threads(min(8, L.oracle_num_threads()))
+    buf = torch.zeros(n * d + 1, device=dev)
+    for name, f, scal in (("QUADRATIC", pymde_amd.penalties.Quadratic(w), ()), ("LOG1P", pymde_amd.penalties.Log1p(w), (1.5,))):
+        buf.zero_()
+        fused_evaluate(Binding(plan, f), X, buf[:n * d].view(n, d), buf[n * d:])
+        wE, wgrad = oracle.average_distortion(e_np, X_np, oracle.func(name, w_np, None, scal))
+        assert float(buf[n * d]) == pytest.approx(wE, rel=1e-5), name
+        assert_grad_close(buf[:n * d].view(n, d).cpu().numpy(), wgrad)

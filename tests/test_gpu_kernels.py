@@ -497,7 +497,8 @@ rng = np.random.default_rng(7)
 for (n, p, d, fname) in [(30000, 400000, 2, 'log1p'), (30000, 400000, 2, 'pushpull'), (50000, 300000, 3, 'quad'),
                          (30000, 400000, 2, 'log1p_cb'), (70001, 500003, 2, 'pushpull_cb'), (20000, 250000, 3, 'quad_cb'),
                          (20000, 250000, 1, 'absolute'), (70001, 500003, 2, 'pushpull_lr'), (9000, 200000, 4, 'huber'),
-                         (30000, 400000, 2, 'huber'), (30000, 400000, 3, 'absolute'), (30000, 400000, 2, 'lquad')]:
+                         (30000, 400000, 2, 'huber'), (30000, 400000, 3, 'absolute'), (30000, 400000, 2, 'lquad'),
+                         (30000, 400000, 2, 'log1p_scalar'), (30000, 400000, 2, 'quad_scalar')]:
     i = rng.integers(0, n, p); j = (i + 1 + rng.integers(0, n - 1, p)) %% n
     # hub vertices (degree ~ p/20 and p/50): rows with far more entries per tile than a wave has
     # iterations exercise the run-folding slow path; vertex n-1 is isolated (empty row)
@@ -528,6 +529,9 @@ for (n, p, d, fname) in [(30000, 400000, 2, 'log1p'), (30000, 400000, 2, 'pushpu
         'absolute': (los.Absolute(dt), oracle.func('L_ABSOLUTE', dev)),
         'huber': (los.Huber(dt, 0.5), oracle.func('L_HUBER', dev, None, (0.5,))),
         'lquad': (los.Quadratic(dt), oracle.func('L_QUADRATIC', dev)),
+        # ONE weight for every edge (a0_scalar = 1): the ring kernel's padding lanes must not carry it
+        'log1p_scalar': (pen.Log1p(torch.tensor(2.0)), oracle.func('LOG1P', [2.0], None, (1.5,))),
+        'quad_scalar': (pen.Quadratic(torch.tensor(0.5)), oracle.func('QUADRATIC', [0.5])),
     }[fname]
     mde = pymde_amd.MDE(n, d, torch.tensor(edges, device='cuda'), f)
     Xt = torch.tensor(X, device='cuda', requires_grad=True)
