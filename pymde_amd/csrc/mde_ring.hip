@@ -1426,9 +1426,11 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     for (int i = tid; i < nr * D; i += BS) grow[i] = GR[i] * sc;
   }
   // block-wide loss partial (the x_v region is free now), then the loss itself: the last
-  // workgroup to arrive adds the partials of all of them in a fixed order (no second launch)
+  // workgroup to arrive adds the partials of all of them in a fixed order (no second launch).  The
+  // partials travel as relaxed device-scope atomic stores / loads (mde_common.h: a device-scope fence
+  // here writes the whole L2 back -- it cost 5 us of the 230 at config 4 and 8 of the 64 us of an
+  // 8-way shard's evaluation).
   double* red = reinterpret_cast<double*>(L);
-  int* last_flag = reinterpret_cast<int*>(L + 256);
   unsigned int* ticket = reinterpret_cast<unsigned int*>(loss_partials + MDE_MAX_PARTIALS);
   const double v = mde_wave_sum((double)loss);
   if (lane == 0) red[wave] = v;
@@ -1436,25 +1438,29 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
   if (tid == 0) {
     double s = 0.0;
     for (int i = 0; i < NCW; ++i) s += red[i];
-    loss_partials[blockIdx.x] = s;
-    __threadfence();  // publish the partial (and this block's gradient rows) device-wide
-    *last_flag = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    mde_st_partial(loss_partials + blockIdx.x, s);
+  }
+  // (mde_last_block's logic with the flag inside L: this kernel's LDS is full)
+  int* last_flag = reinterpret_cast<int*>(L + 256);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the partial store has completed
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned int k = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last_flag = (k == gridDim.x - 1u) ? 1 : 0;
+    if (*last_flag) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
-  if (*last_flag) {
-    __threadfence();  // see the other workgroups' partials (L2 is not coherent across XCDs)
-    double t = 0.0;
-    for (int i = tid; i < (int)gridDim.x; i += BS) t += __builtin_nontemporal_load(loss_partials + i);
-    t = mde_wave_sum(t);
-    __syncthreads();
-    if (lane == 0) red[wave] = t;
-    __syncthreads();
-    if (tid == 0) {
-      double s = 0.0;
-      for (int i = 0; i < BS / 64; ++i) s += red[i];
-      *loss_out = (float)(s * loss_scale);
-      *ticket = 0u;  // ready for the next launch (stream order)
-    }
+  if (!*last_flag) return;
+  double t = 0.0;
+  for (int i = tid; i < (int)gridDim.x; i += BS) t += mde_ld_partial(loss_partials + i);
+  t = mde_wave_sum(t);
+  __syncthreads();
+  if (lane == 0) red[wave] = t;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int i = 0; i < BS / 64; ++i) s += red[i];
+    *loss_out = (float)(s * loss_scale);
   }
 }
 
@@ -1580,6 +1586,11 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
     }
   }
 #endif
+  // Q column groups per row block (sharded plans): the per-group partials are added by a second, 6 us
+  // launch.  Folding that into the ring kernel (the last group of a row block to arrive adds the Q
+  // partials) was built twice -- round 2 with a fence, round 3 with write-through stores and relaxed
+  // loads -- and measured slower both times (8-way shard: 77 vs 57 us per evaluation): 8 x 32 KB of
+  // partials per row block are an order of magnitude more than an in-launch reducer reads for free.
   if (Q > 1 && A.grad) {
     const int64_t nlocD = (A.plan->row_hi - A.plan->row_lo) * (int64_t)D;
     float* out = A.grad + (size_t)A.plan->row_lo * D;
