@@ -78,8 +78,8 @@
 #ifndef MDE_RING_DEPTH
 #define MDE_RING_DEPTH 2           // chunks in flight per producer (all producers together when they share chunks), <= 4
 #endif
-#ifndef MDE_RING_PF
-#define MDE_RING_PF 8              // stream slots prefetched per consumer wave
+#ifndef MDE_RING_PFB
+#define MDE_RING_PFB 3             // stream blocks (4 iterations each) in flight per consumer wave
 #endif
 #define MDE_RING_CB_VALUES 8
 #ifndef MDE_RING_ABLATE
@@ -1235,13 +1235,14 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       const ring_f4* ap = reinterpret_cast<const ring_f4*>(a0_arr ? a0 : reinterpret_cast<const float*>(packed)) +
                           (size_t)(ib >> 2) * 64 + lane;
       const int lastb = NB - 1;
-      // Three blocks (12 iterations) of packed words, parameters and headers in flight.  All
+      // PFB blocks (4 iterations each) of packed words, parameters and headers in flight.  All
       // stream loads are issued from ONE place (the refill after a block is consumed),
       // unconditional and clamped, never predicated: on every path the same loads are in flight
       // when a block is consumed, so the compiler's vmcnt counts are exact and nothing waits for a
       // load just issued.  The headers of a block come with two scalar loads (uniform address).
-      ring_u4 pq[3] = {}, hq[3][4] = {};
-      ring_f4 wq[3] = {};
+      constexpr int PFB = MDE_RING_PFB;
+      ring_u4 pq[PFB] = {}, hq[PFB][4] = {};
+      ring_f4 wq[PFB] = {};
       auto load_block = [&](int u, int b) __attribute__((always_inline)) {
         const int bc = min(b, lastb);
         pq[u] = sp[(size_t)((dbg & 1024) ? (bc & 7) : bc) * 64];  // (probe: packed words from L2, real headers)
@@ -1365,21 +1366,20 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       // (x_v, x_u, parameter -- after the hand-shake for ITS chunks) are already on their way; the
       // accumulator of k + 1 is read right behind the write of k (the LDS executes a wave's
       // accesses in order, so a row shared by consecutive iterations sees the update).
-      load_block(0, 0);
-      load_block(1, 1);
-      load_block(2, 2);
+#pragma unroll
+      for (int u = 0; u < PFB; ++u) load_block(u, u);
       sync_for(hword(0, 0, 0), hword(0, 0, 1));
       Pre x = issue_x(pq[0][0], (a0_scalar || CB) ? a0s : wq[0][0]);
       float acc[D];
       if (HAS_GRAD) ring_ld<D>(L + GR_OFF + (pq[0][0] >> 17), acc);
-      for (int base = 0; base < NB; base += 3) {
+      for (int base = 0; base < NB; base += PFB) {
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
+        for (int u = 0; u < PFB; ++u) {
           const int b = base + u;
           if (b < NB) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              const int un = q < 3 ? u : (u + 1) % 3, qn = q < 3 ? q + 1 : 0;
+              const int un = q < 3 ? u : (u + 1) % PFB, qn = q < 3 ? q + 1 : 0;
               // (past the end of the stream "next" is a copy of the last block: resident chunks,
               // harmless reads, nothing published)
               const uint32_t wn = pq[un][qn];
@@ -1394,7 +1394,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
               x = xn;
             }
           }
-          load_block(u, b + 3);
+          load_block(u, b + PFB);
         }
       }
 #if MDE_RING_ABLATE

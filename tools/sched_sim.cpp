@@ -16,6 +16,7 @@ struct Ent { int chunk, row, col, age; };
 
 struct Res { double iters, padpct, Kr, Kc, rd_r, rd_c, wr, forced, xr, xc, xw; };
 
+static int g_adjacent = 0;  // 1: a row taken in iteration k is not taken in k + 1 either
 static Res run(int ROWS, double PER_CHUNK, int NCHUNK, int SPAN, int capR, int capC, int force, int CARRY, unsigned seed) {
   std::mt19937_64 rng(seed);
   std::poisson_distribution<int> pois(PER_CHUNK);
@@ -30,7 +31,7 @@ static Res run(int ROWS, double PER_CHUNK, int NCHUNK, int SPAN, int capR, int c
   std::vector<Ent> q;  // deferred, FIFO
   size_t pos = 0;
   long x_rr = 0, x_rc = 0, x_w = 0; long iters = 0, pad = 0, sKr = 0, sKc = 0, srr = 0, src = 0, swr = 0, nforced = 0;
-  std::vector<int> rowtaken(ROWS, -1);
+  std::vector<int> rowtaken(ROWS, -5);
   while (pos < st.size() || !q.empty()) {
     const int m = !q.empty() ? std::min(q[0].chunk, pos < st.size() ? st[pos].chunk : 1 << 30) : st[pos].chunk;
     int mm = m;
@@ -40,7 +41,7 @@ static Res run(int ROWS, double PER_CHUNK, int NCHUNK, int SPAN, int capR, int c
     std::vector<Ent> take, keep;
     auto offer = [&](Ent e) {
       const int a = e.row & 31, b = e.col & 31;
-      const bool rowfree = rowtaken[e.row] != (int)iters;
+      const bool rowfree = rowtaken[e.row] != (int)iters && !(g_adjacent && rowtaken[e.row] == (int)iters - 1);
       const bool capok = (rc[a] < capR && cc[b] < capC) || e.age >= force;
       if (take.size() < 64 && rowfree && capok) {
         if (!(rc[a] < capR && cc[b] < capC)) ++nforced;
@@ -94,11 +95,12 @@ static Res run(int ROWS, double PER_CHUNK, int NCHUNK, int SPAN, int capR, int c
 int main(int argc, char** argv) {
   const int ROWS = argc > 1 ? atoi(argv[1]) : 326;
   const double PER = argc > 2 ? atof(argv[2]) : 32.0;
+  g_adjacent = argc > 3 ? atoi(argv[3]) : 0;
   const int NCH = 977;
   printf("rows/wave %d, %.0f entries per chunk\n", ROWS, PER);
   printf("span capR capC force | iters  pad%%   Krow Kcol | LDS clk: 2 row reads + col read + write + codebook = total | x(1+pad) | forced/iter\n");
-  const int caps[][2] = {{64, 64}, {5, 5}, {4, 4}, {3, 4}, {3, 3}, {2, 4}, {2, 2}};
-  for (int span : {6, 8})
+  const int caps[][2] = {{64, 64}, {4, 4}};
+  for (int span : {4, 5, 6})
     for (auto& c : caps)
       for (int force : {2, 3, 1000}) {
         if (c[0] == 64 && force != 2) continue;
