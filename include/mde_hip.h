@@ -188,7 +188,8 @@ int64_t mde_plan_layout_half_edges(const mde_plan* plan, int32_t layout);
  * entries 1..7 the values in ascending bit order), and set *n_values_host to the number of values;
  * the fused kernel then streams 4 instead of 8 bytes per half-edge (mde_func.a0 = out_half,
  * a0_scalar = 2).  *n_values_host = 0: not applicable, nothing written -- use
- * mde_plan_expand_layout.  Results are identical either way.  SYNC. */
+ * mde_plan_expand_layout (also when a value is NaN or infinite: the kernel skips the NaN/Inf -> 1
+ * fix-up of f'/d for codebook streams).  Results are identical either way.  SYNC. */
 int mde_plan_expand_codebook(const mde_plan* plan, const float* in_edge, float* out_half,
                              int32_t* n_values_host, void* stream);
 int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in_edge,
@@ -283,9 +284,11 @@ int mde_anchor_rows(int64_t n_anchors, int32_t d, const int64_t* anchors, const 
 /* Standardized tangent projection Z -= (1/n) X (Z^T X)  (constraints.py:186-192). */
 int mde_std_tangent(int64_t n, int32_t d, const float* X, float* Z, double* work, void* stream);
 /* Standardized retraction: Z <- sqrt(n) * polar factor of (Z - mean)  (util.py:129-161),
- * computed as sqrt(n) (Z-mean) C^{-1/2}, C = (Z-mean)^T (Z-mean) via a d x d
- * eigendecomposition on device.  status_dev (device int32, may be NULL) is set non-zero
- * when C is numerically singular.  demean = 0 skips the centring (util.py:130-134). */
+ * computed as sqrt(n) (Z-mean) C^{-1/2}, C = (Z-mean)^T (Z-mean), with C^{-1/2} from a closed
+ * form (d <= 2) or a coupled Newton-Schulz iteration in double on the device.  status_dev (device
+ * int32, may be NULL) is set non-zero when C is numerically singular.  demean = 0 skips the
+ * centring (util.py:130-134).  ASYNC for d < 32; for d >= 32 the iteration's residual words are
+ * read back after every batch of steps (one stream synchronisation per 6 steps, usually one). */
 int mde_std_retract(int64_t n, int32_t d, float* Z, int32_t demean, double* work,
                     int32_t* status_dev, void* stream);
 /* Gram matrix out[d_a, d_b] (double, device) = A^T B for A [n,d_a], B [n,d_b]; uses the

@@ -68,15 +68,12 @@
 #ifndef MDE_RING_PRODPRIO
 #define MDE_RING_PRODPRIO 3
 #endif
-#ifndef MDE_RING_COOP
-#define MDE_RING_COOP 0            // 1: the producers share every chunk (producer p moves pieces p, p + NPROD, ...); 0: they alternate whole chunks
-#endif
 #ifndef MDE_RING_NPROD
 #define MDE_RING_NPROD 2           // producer waves
 #endif
 #define MDE_RING_BS (64 * (MDE_RING_NCW + MDE_RING_NPROD))
 #ifndef MDE_RING_DEPTH
-#define MDE_RING_DEPTH 2           // chunks in flight per producer (all producers together when they share chunks), <= 4
+#define MDE_RING_DEPTH 2           // chunks in flight per producer (<= 4)
 #endif
 #ifndef MDE_RING_PFB
 #define MDE_RING_PFB 3             // stream blocks (4 iterations each) in flight per consumer wave
@@ -94,8 +91,7 @@
 #ifndef MDE_RING_C2
 #define MDE_RING_C2 1024
 #endif
-// (a chunk is a multiple of NPROD KiB: every producer moves the same number of 1 KiB pieces)
-__host__ __device__ constexpr int ring_chunk_cols(int d) { return d == 1 ? 2048 : (d == 2 ? MDE_RING_C2 : (d == 3 ? 1024 : 512)); }
+__host__ __device__ constexpr int ring_chunk_cols(int d) { return d == 1 ? 2048 : (d == 2 ? MDE_RING_C2 : 512); }
 __host__ __device__ constexpr int ring_chunk_bytes(int d) { return ring_chunk_cols(d) * 4 * d; }
 __host__ __device__ constexpr int ring_slots(int d) { return MDE_RING_BYTES / ring_chunk_bytes(d); }
 // an iteration may reference chunks m .. m + span: the ring also holds the chunks in flight
@@ -106,7 +102,7 @@ __host__ __device__ constexpr int ring_max_span(int d) {
   return MDE_RING_SPAN;
 #endif
   // (measured at config 4: 4..6 chunks of window leave the waves the most slack; 8 costs 4 %)
-  constexpr int inflight = MDE_RING_COOP ? MDE_RING_DEPTH : MDE_RING_NPROD * MDE_RING_DEPTH;
+  constexpr int inflight = MDE_RING_NPROD * MDE_RING_DEPTH;
   // (config 4: windows of 4 and 5 chunks measure the same, 6 costs 2 %: the slack is worth more than the padding)
   return ring_slots(d) - inflight - 2 > 5 ? 5 : ring_slots(d) - inflight - 2;
 }
@@ -203,7 +199,7 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
                                                       const uint32_t* __restrict__ vals,
                                                       const int32_t* __restrict__ hrow,
                                                       const int32_t* __restrict__ nbr, uint32_t JM, int SPAN,
-                                                      int R, int Q, int NC, int d, int cap,
+                                                      int R, int Q, int NC, int d, int cap, int bail_factor,
                                                       int32_t* __restrict__ iters,
                                                       const int32_t* __restrict__ iter_base,
                                                       int32_t* __restrict__ it_ent, int32_t* __restrict__ it_cnt,
@@ -222,6 +218,9 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
   const int sh = ring_cls_shift(d), cm = ring_cls_mask(d), rowbytes = 4 * d;
   const int first = FILL ? iter_base[i] : 0;
   int out = first, next = beg, nc = 0, cur = 0;
+  // counting pass, auto mode: a stream that needs several times the iterations its entries would fill
+  // (a hub row: one entry per iteration) makes the caller give the layout up -- stop counting there
+  const int bail = (!FILL && bail_factor > 0) ? bail_factor * ((end - beg + 63) / 64) + 64 : 0x7fffffff;
   int last_chunk = (int)(((int64_t)((i / MDE_RING_NCW) % Q) * NC + Q - 1) / Q);
   while (nc > 0 || next < end) {
     const int m = (int)(keys[nc > 0 ? cq_pos[cur][0] : next] & JM);  // oldest candidate's chunk
@@ -313,6 +312,10 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
     nc = nnew;
     cur ^= 1;
     __syncthreads();
+    if (out - first > bail) {
+      if (lane == 0) iters[i] = 1 << 25;  // (x 64 entries = 2^31: over the 32-bit position limit checked below)
+      return;
+    }
   }
   // a stream is stored in blocks of 4 iterations (one 16-byte load per lane): pad with empty ones
   while ((out - first) & 3) {
@@ -580,7 +583,7 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   const int place = getenv("MDE_RING_PLACE") ? atoi(getenv("MDE_RING_PLACE")) : 1;
   const int span = getenv("MDE_RING_SPAN") ? std::min(ring_max_span(d), std::max(1, atoi(getenv("MDE_RING_SPAN")))) : ring_max_span(d);
   hipLaunchKernelGGL(k_ring_schedule<false>, dim3(nseg), dim3(64), 0, st, nseg, seg, bounds, keys2, vals2, hrow, plan->nbr,
-                     JM, span, z.R, z.Q, z.NC, d, cap, iters, nullptr, nullptr, nullptr, nullptr);
+                     JM, span, z.R, z.Q, z.NC, d, cap, panel_mode() == 1 ? 0 : 4, iters, nullptr, nullptr, nullptr, nullptr);
   RB(hipGetLastError());
   RB(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, iters, iter_base, nseg + 1, st));
   int32_t total_iters = 0;
@@ -604,7 +607,7 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   RB(hipMalloc(&hdr, (size_t)total_iters * MDE_RING_HW * sizeof(uint32_t)));
   if (z.Q > 1) RB(hipMalloc(&partial, sizeof(float) * (size_t)z.Q * (size_t)nloc * (size_t)d));
   hipLaunchKernelGGL(k_ring_schedule<true>, dim3(nseg), dim3(64), 0, st, nseg, seg, bounds, keys2, vals2, hrow, plan->nbr,
-                     JM, span, z.R, z.Q, z.NC, d, cap, nullptr, iter_base, it_ent, it_cnt, it_m);
+                     JM, span, z.R, z.Q, z.NC, d, cap, 0, nullptr, iter_base, it_ent, it_cnt, it_m);
   RB(hipGetLastError());
   hipLaunchKernelGGL(k_ring_pack, dim3(mde_grid((int64_t)total_iters * 64, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st,
                      (int64_t)total_iters, it_ent, it_cnt, it_m, keys2, vals2, hrow, plan->nbr, plan->eid, z.R, z.Q, z.C,
@@ -984,7 +987,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     }
     if (tid < 32 * D) XR[R * D + tid] = 0.0f;  // the dummy rows
     if (tid < 16) prog[tid] = (tid < NCW) ? j_lo : MDE_RING_DONE;
-    if (tid >= 16 && tid < 16 + NPROD) F[tid - 16] = MDE_RING_COOP ? j_lo : j_lo + (tid - 16);
+    if (tid >= 16 && tid < 16 + NPROD) F[tid - 16] = j_lo + (tid - 16);
     if (CB && tid >= 32 && tid < 32 + MDE_RING_CB_VALUES)
       reinterpret_cast<float*>(L + MDE_RING_CTRL_CB)[tid - 32] = a0[tid - 32] * Fn::kParamScale;
   }
@@ -997,116 +1000,6 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
 
   if (wave >= NCW) {
     __builtin_amdgcn_s_setprio(MDE_RING_PRODPRIO);  // the DMA issue ahead of the consumers' instructions (-2.5 %)
-#if MDE_RING_COOP
-    // ---------------- producer p: pieces p, p + NPROD, ... of EVERY chunk.  (Two producers that
-    // alternate whole chunks spend ~650 clocks per chunk on the eight DMA instructions alone once
-    // the consumers are running -- tools/r3_probe.sh: staging then takes 0.21 ms and everything
-    // waits for it.  Striping the pieces over four waves quarters the issue work per wave, lands a
-    // chunk four times sooner and keeps only DEPTH chunks of the ring in flight.)
-    const int p = wave - NCW;
-    constexpr int PPW = PIECES / NPROD;  // pieces per producer and chunk
-    static_assert(PIECES % NPROD == 0 && PPW >= 1 && PPW <= 4, "a producer moves 1..4 pieces of every chunk");
-    const char* Xb = reinterpret_cast<const char*>(X);
-    const char* Xl = Xb + lane * 16 + (size_t)p * PPW * 1024;
-    const size_t nbytes = (size_t)n * D * 4;
-    const size_t last16 = nbytes - 16;
-    int minprog = j_lo, infl = 0;
-    int slot = j_lo % S;
-    int j = j_lo;             // next chunk to issue
-    int oldest = j;           // oldest chunk in flight (valid while infl > 0)
-#if MDE_RING_ABLATE
-    unsigned long long pr_t0 = RING_CLK(), pr_blocked = 0, pr_retire = 0, pr_polls = 0;
-#endif
-    // wait for my pieces of the oldest chunk in flight and publish it (F[p] = first chunk whose
-    // pieces of mine have not landed)
-    auto retire = [&]() __attribute__((always_inline)) {
-#if MDE_RING_ABLATE
-      const unsigned long long tr0 = RING_CLK();
-#endif
-      if (infl == 4)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * 3) : "memory");
-      else if (infl == 3)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW * 2) : "memory");
-      else if (infl == 2)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPW) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      ++oldest;
-      ring_ctrl_store(MDE_RING_CTRL_F + 4u * (uint32_t)p, oldest);
-      --infl;
-#if MDE_RING_ABLATE
-      pr_retire += RING_CLK() - tr0;
-#endif
-    };
-    static_assert(MDE_RING_DEPTH >= 1 && MDE_RING_DEPTH <= 4, "retire() spells out the wait counts of up to four chunks in flight");
-    while (j < j_hi && !(dbg & 128)) {
-      // slot j % S still holds chunk j - S until every consumer is past it
-      if (j - S >= minprog && !(dbg & 8)) {
-#if MDE_RING_ABLATE
-        const unsigned long long tb0 = RING_CLK();
-        ++pr_polls;
-#endif
-        // one LDS read (lane w = consumer w), then a scalar minimum over the consumers' lanes
-        const int v = ring_ctrl_load(MDE_RING_CTRL_PROG + 4u * (uint32_t)(lane & 15));
-        int mn = __builtin_amdgcn_readlane(v, 0);
-#pragma unroll
-        for (int w = 1; w < NCW; ++w) mn = min(mn, __builtin_amdgcn_readlane(v, w));
-        minprog = mn;
-        if (j - S >= minprog) {
-          // blocked: meanwhile publish what has landed (a consumer may be waiting for exactly that)
-          if (infl > 0)
-            retire();
-          else
-            __builtin_amdgcn_s_sleep(1);
-#if MDE_RING_ABLATE
-          pr_blocked += RING_CLK() - tb0;
-#endif
-          continue;
-        }
-#if MDE_RING_ABLATE
-        pr_blocked += RING_CLK() - tb0;
-#endif
-      }
-      const uint32_t dst = (uint32_t)RING_OFF + (uint32_t)slot * (uint32_t)CBYTES + (uint32_t)p * (uint32_t)(PPW * 1024);
-      if (!(dbg & 2)) {
-        if (j != NC - 1) {
-          // my PPW consecutive 1 KiB pieces in one statement: the instruction offset advances the
-          // global and the LDS address together
-          ring_dma_pieces<PPW>(Xl + (size_t)j * CBYTES, dst);
-        } else {
-          // the table's last chunk: lanes whose 16 bytes would cross its end load a clamped address
-          const size_t off0 = (size_t)j * CBYTES + (size_t)p * PPW * 1024 + (size_t)lane * 16;
-#pragma unroll
-          for (int k = 0; k < PPW; ++k) {
-            const size_t off = off0 + (size_t)k * 1024;
-            ring_dma_pieces<1>(Xb + (off < last16 ? off : last16), dst + (uint32_t)k * 1024u);
-          }
-        }
-      }
-      if (infl == 0) oldest = j;
-      ++infl;
-      ++j;
-      ++slot;
-      slot = slot >= S ? slot - S : slot;
-      if (infl == MDE_RING_DEPTH) retire();
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // when the table is not a multiple of 16 bytes its final dwords are put in place by hand, by
-    // the producer whose piece they sit in, before that producer reports the last chunk
-    if ((nbytes & 15) && (NC - 1) >= j_lo && (NC - 1) < j_hi) {
-      const size_t tail0 = nbytes & ~(size_t)15;
-      const int tail_piece = (int)((tail0 - (size_t)(NC - 1) * CBYTES) >> 10);
-      if (tail_piece / PPW == p) {
-        const int nt = (int)((nbytes - tail0) >> 2);
-        if (lane < nt) {
-          const size_t off = tail0 + (size_t)lane * 4 - (size_t)(NC - 1) * CBYTES;
-          *reinterpret_cast<float*>(L + RING_OFF + ((NC - 1) % S) * CBYTES + off) =
-              *reinterpret_cast<const float*>(Xb + tail0 + (size_t)lane * 4);
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      }
-    }
-#else
     // ---------------- producer p: chunks j_lo + p, j_lo + p + NPROD, ...
     const int p = wave - NCW;
     const char* Xb = reinterpret_cast<const char*>(X);
@@ -1214,7 +1107,6 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-#endif
     ring_ctrl_store(MDE_RING_CTRL_F + 4u * (uint32_t)p, MDE_RING_DONE);
 #if MDE_RING_ABLATE
     if ((dbg & 512) && lane == 0 && blockIdx.x < 1024) {

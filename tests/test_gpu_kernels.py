@@ -588,3 +588,29 @@ def test_panel_kernel_against_oracle(mode, bs):
     env = dict(os.environ, MDE_PANEL=mode, MDE_PANEL_BS=bs)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
+
+
+def test_ring_layout_gives_way_on_hub_graphs():
+    """Auto layout choice at a size where the LDS-ring kernel would normally run (n d 4 >= 6 MB): a hub
+    vertex with half a million half-edges would need one wave iteration per entry (rows are distinct
+    inside an iteration), so the layout builder gives the ring up and the CSR kernel runs -- same
+    results, against the oracle."""
+    import pymde_amd
+    rng = np.random.default_rng(11)
+    n, p, hub = 800_000, 8_000_000, 500_000
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    i[:hub] = 12345
+    j[:hub] = rng.choice(n - 1, hub, replace=False)
+    j[:hub][j[:hub] >= 12345] += 1
+    edges = np.stack([np.minimum(i, j), np.maximum(i, j)], 1)
+    w = rng.choice(np.array([1.0, 2.0], dtype=np.float32), size=p)
+    X = rng.standard_normal((n, 2)).astype(np.float32)
+    mde = pymde_amd.MDE(n, 2, torch.tensor(edges, device=DEV), pymde_amd.penalties.Log1p(torch.tensor(w, device=DEV)))
+    Xt = torch.tensor(X, device=DEV, requires_grad=True)
+    E = mde.average_distortion(Xt)
+    E.backward()
+    assert mde._binding().struct(2).layout == 0          # the ring layout was tried and given up
+    wE, wgrad = oracle.average_distortion(edges, X, oracle.func("LOG1P", w, None, (1.5,)))
+    assert float(E) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(Xt.grad.cpu().numpy(), wgrad)
