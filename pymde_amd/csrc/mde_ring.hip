@@ -65,6 +65,9 @@
 #ifndef MDE_RING_NCW
 #define MDE_RING_NCW 10            // consumer waves (config 4, round 3: 8 -> 0.243, 10 -> 0.230, 12 -> 0.238, 14 -> 0.246 ms)
 #endif
+#ifndef MDE_RING_CSLEEP
+#define MDE_RING_CSLEEP 1          // s_sleep argument of a consumer waiting for a chunk (x 64 clocks)
+#endif
 #ifndef MDE_RING_PRODPRIO
 #define MDE_RING_PRODPRIO 3
 #endif
@@ -220,7 +223,11 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
   int out = first, next = beg, nc = 0, cur = 0;
   // counting pass, auto mode: a stream that needs several times the iterations its entries would fill
   // (a hub row: one entry per iteration) makes the caller give the layout up -- stop counting there
-  const int bail = (!FILL && bail_factor > 0) ? bail_factor * ((end - beg + 63) / 64) + 64 : 0x7fffffff;
+  // (an iteration holds at most one entry per row of the wave: a short tail block is not a hub)
+  const int w_ = i % MDE_RING_NCW;
+  const int nrows_w = max(1, bounds[rb * (MDE_RING_NCW + 1) + w_ + 1] - bounds[rb * (MDE_RING_NCW + 1) + w_]);
+  const int per_it = nrows_w < 64 ? nrows_w : 64;
+  const int bail = (!FILL && bail_factor > 0) ? bail_factor * ((end - beg + per_it - 1) / per_it) + 64 : 0x7fffffff;
   int last_chunk = (int)(((int64_t)((i / MDE_RING_NCW) % Q) * NC + Q - 1) / Q);
   while (nc > 0 || next < end) {
     const int m = (int)(keys[nc > 0 ? cq_pos[cur][0] : next] & JM);  // oldest candidate's chunk
@@ -1242,7 +1249,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
             ++cs_trips;
 #endif
             if (need < ready) break;
-            __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_s_sleep(MDE_RING_CSLEEP);
           }
 #if MDE_RING_ABLATE
           cs_poll += RING_CLK() - tp0;
