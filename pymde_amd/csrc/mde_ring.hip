@@ -1285,10 +1285,22 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
               sync_for(hword(un, qn, 0), hword(un, qn, 1));
               const Pre xn = issue_x(wn, (a0_scalar || CB) ? a0s : wq[un][qn]);
               const float p1 = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q] : a1s;
+#if MDE_RING_ABLATE
+              // (probe, wrong results: the next accumulators are read BEFORE this iteration's write --
+              // what the loop would cost without the accumulator chain through LDS)
+              float accn[D];
+              if (HAS_GRAD && (dbg & 2048)) ring_ld<D>(L + GR_OFF + (wn >> 17), accn);
+#endif
               if (!(dbg & 4))
                 finish(pq[u][q], x, acc, p1, hword(u, q, 0), hword(u, q, 2));
               else
                 loss += __uint_as_float(pq[u][q]) * 0.0f + x.xr[0] * 0.0f;
+#if MDE_RING_ABLATE
+              if (HAS_GRAD && (dbg & 2048)) {
+#pragma unroll
+                for (int c = 0; c < D; ++c) acc[c] = accn[c];
+              } else
+#endif
               if (HAS_GRAD) ring_ld<D>(L + GR_OFF + (wn >> 17), acc);
               x = xn;
             }
