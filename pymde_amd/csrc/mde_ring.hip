@@ -628,6 +628,19 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     hipLaunchKernelGGL(k_ring_stats, dim3(256), dim3(MDE_BLOCK), 0, st, (int64_t)total_iters, hdr, dstat);
     RB(hipMemcpyAsync(hstat, dstat, sizeof(hstat), hipMemcpyDeviceToHost, st));
     RB(hipStreamSynchronize(st));
+    {
+      // how even are the consumer waves' streams?  (the slowest wave sets the kernel's duration)
+      std::vector<int32_t> hb((size_t)nseg + 1);
+      RB(hipMemcpy(hb.data(), iter_base, hb.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      int mx = 0, mn = 1 << 30, wg_mx = 0;
+      for (int i = 0; i < nseg; ++i) {
+        mx = std::max(mx, hb[i + 1] - hb[i]);
+        mn = std::min(mn, hb[i + 1] - hb[i]);
+      }
+      for (int g = 0; g + MDE_RING_NCW <= nseg; g += MDE_RING_NCW) wg_mx = std::max(wg_mx, hb[g + MDE_RING_NCW] - hb[g]);
+      fprintf(stderr, "[mde ring] iterations per consumer wave: min %d mean %.1f max %d; per workgroup: mean %.1f max %d\n", mn,
+              (double)total_iters / nseg, mx, (double)total_iters * MDE_RING_NCW / nseg, wg_mx);
+    }
     fprintf(stderr, "[mde ring] d=%d R=%d NRB=%d Q=%d chunks=%d x %d cols, window %d, cap %d, placement %d: %d iterations for %lld half-edges "
             "(%.1f%% padding), %.1f%% with padding lanes; loss terms: %.1f%% of the iterations add all, %.2f%% test per lane\n",
             d, z.R, z.NRB, z.Q, z.NC, z.C, span, cap, place, total_iters, (long long)H,
@@ -1144,6 +1157,19 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       ring_f4 wq[PFB] = {};
       auto load_block = [&](int u, int b) __attribute__((always_inline)) {
         const int bc = min(b, lastb);
+#if MDE_RING_ABLATE
+        if (dbg & 8192) {
+          // (probe: block b of every wave of the grid side by side -- the addresses a [block][wave]
+          // stream layout would touch; the words read are not this wave's, use with 4096 only)
+          const size_t nw = (size_t)gridDim.x * NCW, tb = (size_t)(wave_iter[nw] >> 2);
+          const size_t at = ((size_t)bc * nw + blockIdx.x * NCW + wave) % tb;
+          pq[u] = reinterpret_cast<const ring_u4*>(packed)[at * 64 + lane];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) hq[u][k] = reinterpret_cast<const ring_u4*>(hdr)[at * 4 + k];
+          if (!CB) wq[u] = reinterpret_cast<const ring_f4*>(a0)[at * 64 + lane];
+          return;
+        }
+#endif
         pq[u] = sp[(size_t)((dbg & 1024) ? (bc & 7) : bc) * 64];  // (probe: packed words from L2, real headers)
 #pragma unroll
         for (int k = 0; k < 4; ++k) hq[u][k] = hp[(size_t)bc * 4 + k];
@@ -1279,6 +1305,13 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int un = q < 3 ? u : (u + 1) % PFB, qn = q < 3 ? q + 1 : 0;
+#if MDE_RING_ABLATE
+              if (dbg & 4096) {
+                // (probe: the stream alone -- packed words, parameters and headers are consumed, nothing else happens)
+                loss += __uint_as_float(pq[u][q] ^ hword(u, q, 0) ^ hword(u, q, 1)) * 0.0f + (CB ? 0.0f : wq[u][q] * 0.0f);
+                continue;
+              }
+#endif
               // (past the end of the stream "next" is a copy of the last block: resident chunks,
               // harmless reads, nothing published)
               const uint32_t wn = pq[un][qn];
