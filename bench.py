@@ -548,7 +548,7 @@ def run_embed_config(args, device, which):
                                            max_distances=5e7, device=device)
         label = ("BASELINE configs[2] stand-in: 40k-node scale-free graph (5 links per node), "
                  "preserve_distances(Huber(1.0), max_distances=5e7), d=2")
-        functor = "FnSingle<L_HUBER> on the CSR kernel, FnRuntime on the LDS-ring kernel"
+        functor = "FnSingle<L_HUBER> (compile-time), CSR and LDS-ring kernels"
     torch.cuda.synchronize(device)
     build_s = time.perf_counter() - t0
     iters = 100
@@ -567,6 +567,7 @@ def run_embed_config(args, device, which):
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": label, "n_items": int(mde.n_items), "edges": p, "problem_build_s": build_s,
                    "edges_per_s_per_iter": p * n_it / dt, "kernel_layout": "LDS ring" if layout == 1 else "CSR",
+                   "parameter_stream": "codebook" if mde._binding().codebook else "fp32",
                    "functor": functor, "final_average_distortion": float(mde.value)},
     }
 

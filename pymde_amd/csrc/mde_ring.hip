@@ -160,6 +160,24 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_keys(int nrows, const int32_
   }
 }
 
+__global__ __launch_bounds__(MDE_BLOCK) void k_ring_gather_u32(int64_t H, const uint32_t* __restrict__ idx,
+                                                               const uint32_t* __restrict__ in,
+                                                               uint32_t* __restrict__ out) {
+  for (int64_t h = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; h < H; h += (int64_t)gridDim.x * MDE_BLOCK)
+    out[h] = in[idx[h]];
+}
+
+// hrow[q] = local row of CSR position q
+__global__ __launch_bounds__(MDE_BLOCK) void k_ring_hrow(int nrows, const int32_t* __restrict__ rowptr,
+                                                         int32_t* __restrict__ hrow) {
+  constexpr int G = 16;
+  const int lig = threadIdx.x & (G - 1);
+  const int group = (blockIdx.x * MDE_BLOCK + threadIdx.x) / G;
+  const int ngroups = (gridDim.x * MDE_BLOCK) / G;
+  for (int r = group; r < nrows; r += ngroups)
+    for (int q = rowptr[r] + lig; q < rowptr[r + 1]; q += G) hrow[q] = r;
+}
+
 // seg[t] = first sorted position whose stream id (key >> JB) >= t, t = 0..nseg
 __global__ __launch_bounds__(MDE_BLOCK) void k_ring_seg(int64_t H, uint32_t nseg, int JB,
                                                         const uint32_t* __restrict__ keys,
@@ -478,31 +496,35 @@ static bool choose_sizes(const mde_plan* plan, int d, RingSizes* z) {
   if (d < 1 || d > 4 || nloc <= 0 || plan->H <= 0) return false;
   const int mode = panel_mode();
   if (mode == 0) return false;
-  // rows: about one block per CU (256), multiple of 64, and x_v + the dummy slot must fit below
-  // the control words.  A rank that owns n/N rows keeps the block height of the full plan (the
-  // staging volume is NRB * table bytes) and fills the CUs with Q column groups per row block.
-  int64_t pr = (plan->n + 255) / 256;
+  // Geometry: NRB row blocks x Q column groups ~ one workgroup per CU (256).  Tall blocks first
+  // (many rows per consumer wave keep the distinct-rows iterations full, and the staging volume is
+  // NRB x table bytes), up to what fits below the control words; the CUs left over are filled
+  // with column groups of at least `minch` chunks each (one ring window).  Config 4 (n = 1M, d = 2):
+  // 253 blocks of 3968 rows, Q = 1; an 8-way shard of it: 32 blocks x 8 groups; a dense 40k-node
+  // problem: 32 blocks of 1280 rows x 8 groups of 5 chunks.
+  const int C = ring_chunk_cols(d);
+  const int64_t nc = (plan->n + C - 1) / C;
+  if (nc > 65535 || nc < 2) return false;
+  const int minch = getenv("MDE_RING_MINCH") ? std::max(1, atoi(getenv("MDE_RING_MINCH"))) : 5;
+  const int qmax = (int)std::min<int64_t>(16, std::max<int64_t>(1, nc / minch));
+  int64_t pr = (nloc * qmax + 255) / 256;
+  if (pr < 64 * MDE_RING_NCW) pr = 64 * MDE_RING_NCW;  // >= 64 rows per consumer wave, even if CUs stay empty
+  if (getenv("MDE_RING_ROWS")) pr = atoi(getenv("MDE_RING_ROWS"));
   if (pr > nloc) pr = nloc;
   pr = ((pr + 63) / 64) * 64;
   const int64_t pr_max = (MDE_RING_CTRL_OFF / (4 * d) - 32) / 64 * 64;  // 32 dummy row slots for padding lanes
   if (pr > pr_max) pr = pr_max;
-  const int C = ring_chunk_cols(d);
-  const int64_t nc = (plan->n + C - 1) / C;
   const int64_t nrb = (nloc + pr - 1) / pr;
-  if (nc > 65535 || nc < 2) return false;
-  int Q = 1;
-  if (nrb <= 128) {
-    Q = (int)(256 / nrb);  // one resident round of workgroups
-    if (Q > nc / 16) Q = (int)(nc / 16);
-    if (Q > 16) Q = 16;
-    if (Q < 1) Q = 1;
-  }
+  int Q = (int)std::min<int64_t>(qmax, std::max<int64_t>(1, 256 / nrb));
   if (nrb * Q > MDE_MAX_PARTIALS) return false;
   const int jb = bits_for_u64((uint64_t)nc - 1);
   if (bits_for_u64((uint64_t)(nrb * Q * MDE_RING_NCW)) + jb > 32) return false;
   if (mode != 1) {
-    // auto: only when the table overflows L2 and a 64-entry iteration fits the ring window
-    if ((int64_t)plan->n * d * 4 < (6 << 20)) return false;
+    // auto: a 64-entry iteration must fit the ring window, and the launch must be worth its fixed
+    // costs: either the table overflows L2 (the CSR kernel's gathers go to HBM), or there are enough
+    // half-edges that 64 B of L2 traffic per 8-byte gather is what the CSR kernel spends its time on
+    // (40k nodes, 100M half-edges: 0.60 -> 0.30 ms per evaluation)
+    if ((int64_t)plan->n * d * 4 < (6 << 20) && plan->H < ((int64_t)16 << 20)) return false;
     if ((double)plan->H / ((double)nrb * MDE_RING_NCW * (double)nc) < 64.0 / (0.6 * ring_max_span(d))) return false;
   }
   z->R = (int)pr;
@@ -578,7 +600,30 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   RB(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)H, 0, end_bit, st));
   RB(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, iters, iter_base, nseg + 1, st));
   if (scan_bytes > tmp_bytes) tmp_bytes = scan_bytes;
+  RB(hipcub::DeviceRadixSort::SortPairs(nullptr, scan_bytes, keys, keys2, vals, vals2, (int)H, 0,
+                                        bits_for_u64((uint64_t)plan->n), st));
+  if (scan_bytes > tmp_bytes) tmp_bytes = scan_bytes;
   RB(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+  // Dense graphs (many entries per row and chunk): in CSR order the entries of ONE row follow each
+  // other inside a chunk, and an iteration -- distinct rows -- would find a handful of rows in its
+  // look-ahead.  Order the entries by column first (stable): inside a (stream, chunk) they then come
+  // column by column, and the rows adjacent to one column are distinct.
+  const bool by_column = getenv("MDE_RING_BYCOL") ? atoi(getenv("MDE_RING_BYCOL")) != 0
+                                                  : (double)H > 0.5 * (double)nloc * (double)z.NC;
+  if (by_column) {
+    // keys2 = columns, sorted with vals -> (keys, vals2); then keys2 = stream keys in that order
+    RB(hipMemcpyAsync(keys2, plan->nbr, hb, hipMemcpyDeviceToDevice, st));
+    uint32_t* skey = reinterpret_cast<uint32_t*>(hrow);  // (hrow is rebuilt below)
+    RB(hipMemcpyAsync(skey, keys, hb, hipMemcpyDeviceToDevice, st));
+    RB(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys2, keys, vals, vals2, (int)H, 0,
+                                          bits_for_u64((uint64_t)plan->n), st));
+    hipLaunchKernelGGL(k_ring_gather_u32, dim3(mde_grid(H, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, H, vals2, skey, keys);
+    RB(hipGetLastError());
+    RB(hipMemcpyAsync(vals, vals2, hb, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_ring_hrow, dim3(mde_grid(nloc * 16, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, (int)nloc,
+                       plan->rowptr, hrow);
+    RB(hipGetLastError());
+  }
   RB(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)H, 0, end_bit, st));
   hipLaunchKernelGGL(k_ring_seg, dim3(mde_grid(H + 1, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, H, (uint32_t)nseg,
                      z.JB, keys2, seg);

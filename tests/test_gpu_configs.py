@@ -81,6 +81,38 @@ def test_config3_sparse_graph_distances_huber():
     assert Es[-1] < 0.5 * Es[0] and abs(float(mde.X.mean())) < 1e-4
 
 
+def test_config3_dense_pairs_take_the_ring_kernel():
+    """configs[2] at the density of bench.py --config 3 (40k nodes, tens of millions of sampled pairs):
+    the table fits L2, but with this many half-edges the LDS-ring kernel is chosen anyway -- tall row
+    blocks x column groups, entries ordered by column inside a chunk -- and reproduces the oracle;
+    integer hop counts travel as a codebook when there are few enough of them."""
+    import pymde_amd
+    rng = np.random.default_rng(5)
+    n, p = 40000, 12_000_000
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    key = np.unique(np.minimum(i, j).astype(np.int64) * n + np.maximum(i, j))
+    edges = np.stack([key // n, key % n], 1)
+    X0 = (rng.standard_normal((n, 2)) * 3).astype(np.float32)
+    for ndist in (5, 40):
+        dev = (1.0 + rng.integers(0, ndist, len(edges))).astype(np.float32)
+        f = pymde_amd.losses.Huber(torch.tensor(dev, device=DEV), 1.0)
+        mde = pymde_amd.MDE(n, 2, torch.tensor(edges, device=DEV), f)
+        Xt = torch.tensor(X0, device=DEV, requires_grad=True)
+        E = mde.average_distortion(Xt)
+        E.backward()
+        st = mde._binding().struct(2)
+        assert st.layout == 1, "dense pairs: the ring layout should have been chosen"
+        wE, wgrad = oracle.average_distortion(edges, X0, oracle.func("L_HUBER", dev, None, (1.0,)))
+        assert float(E) == pytest.approx(wE, rel=1e-5)
+        assert_grad_close(Xt.grad.cpu().numpy(), wgrad)
+        mde2 = pymde_amd.MDE(n, 2, torch.tensor(edges, device=DEV), f)
+        Xt2 = torch.tensor(X0, device=DEV, requires_grad=True)
+        E2 = mde2.average_distortion(Xt2)
+        E2.backward()
+        assert torch.equal(Xt2.grad, Xt.grad) and torch.equal(E2.detach(), E.detach())
+
+
 def test_config4_full_size_against_oracle_and_invariants():
     """configs[3], the headline: n = 1M, |E| = 50M, d = 2, Log1p -- the LDS column-panel kernel
     against the OpenMP oracle on the full problem, plus invariants."""

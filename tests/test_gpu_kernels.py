@@ -590,6 +590,42 @@ def test_panel_kernel_against_oracle(mode, bs):
     assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
 
 
+@pytest.mark.parametrize("d,fname", [(2, "huber"), (3, "quadratic"), (1, "log1p"), (4, "absolute")])
+def test_ring_kernel_on_dense_graphs(monkeypatch, d, fname):
+    """Many entries per (row, chunk): the layout orders the entries of a chunk by column (in CSR order
+    an iteration -- distinct rows -- would find a handful of rows in its look-ahead), uses tall row
+    blocks and several column groups of few chunks.  Forced on at a size the oracle checks in seconds."""
+    import pymde_amd
+    monkeypatch.setenv("MDE_PANEL", "1")
+    rng = np.random.default_rng(13 + d)
+    n, p = 12000, 2_500_000
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    key = np.unique(np.minimum(i, j).astype(np.int64) * n + np.maximum(i, j))
+    edges = np.stack([key // n, key % n], 1)
+    p = len(edges)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    a = rng.uniform(0.5, 2.0, p).astype(np.float32)
+    at = torch.tensor(a, device=DEV)
+    f, fd = {
+        "huber": (pymde_amd.losses.Huber(at, 0.7), oracle.func("L_HUBER", a, None, (0.7,))),
+        "quadratic": (pymde_amd.penalties.Quadratic(at), oracle.func("QUADRATIC", a)),
+        "log1p": (pymde_amd.penalties.Log1p(at), oracle.func("LOG1P", a, None, (1.5,))),
+        "absolute": (pymde_amd.losses.Absolute(at), oracle.func("L_ABSOLUTE", a)),
+    }[fname]
+    mde = pymde_amd.MDE(n, d, torch.tensor(edges, device=DEV), f)
+    Xt = torch.tensor(X, device=DEV, requires_grad=True)
+    E = mde.average_distortion(Xt)
+    E.backward()
+    assert mde._binding().struct(d).layout == 1
+    from pymde_amd import _lib
+    padded = int(_lib.load().mde_plan_layout_half_edges(mde._binding().plan.handle, 1))
+    assert padded <= 1.35 * 2 * p   # the iterations are (nearly) full
+    wE, wgrad = oracle.average_distortion(edges, X, fd)
+    assert float(E) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(Xt.grad.cpu().numpy(), wgrad)
+
+
 def test_ring_layout_gives_way_on_hub_graphs():
     """Auto layout choice at a size where the LDS-ring kernel would normally run (n d 4 >= 6 MB): a hub
     vertex with half a million half-edges would need one wave iteration per entry (rows are distinct
