@@ -8,6 +8,7 @@
 #include "mde_common.h"
 
 #include <algorithm>
+#include <atomic>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -1092,6 +1093,7 @@ extern "C" int mde_std_retract(int64_t n, int32_t d, float* Z, int32_t demean, d
 
 // ---------------------------------------------------------------- L-BFGS memory
 #define MDE_LB_GROUP 8
+#define MDE_LB_NVAL (4 + 5 * MDE_LB_GROUP)
 struct LbPtrs {
   const float* s[MDE_LB_GROUP];
   const float* y[MDE_LB_GROUP];
@@ -1314,129 +1316,41 @@ __global__ void k_lbfgs_dev_reset(LbDev* __restrict__ dv, int history) {
   }
 }
 
-// One wave.  Lane j owns column j of everything; the Gram matrices sit in LDS while they are edited.
-__global__ __launch_bounds__(64) void k_lbfgs_direction(LbDev* __restrict__ dv, const double* __restrict__ dots,
-                                                        int history) {
-  __shared__ double SY[MDE_LB_LD * MDE_LB_LD];
-  __shared__ double YY[MDE_LB_LD * MDE_LB_LD];
-  const int j = threadIdx.x;
-  const int c = dv->count;
-  for (int i = 0; i < c; ++i) {
-    SY[i * MDE_LB_LD + j] = (j < c) ? dv->SY[i * MDE_LB_LD + j] : 0.0;
-    YY[i * MDE_LB_LD + j] = (j < c) ? dv->YY[i * MDE_LB_LD + j] : 0.0;
-  }
-  const double ys = dots[0], yy = dots[1], sg_new = dots[2], yg_new = dots[3];
-  // per stored pair j: s_j.y*, y_j.y*, s*.y_j, s_j.g, y_j.g
-  double s_old_ynew = 0, y_old_ynew = 0, snew_y_old = 0, Sg = 0, Yg = 0;
-  if (j < c) {
-    s_old_ynew = dots[4 + 5 * j + 0];
-    y_old_ynew = dots[4 + 5 * j + 1];
-    snew_y_old = dots[4 + 5 * j + 2];
-    Sg = dots[4 + 5 * j + 3];
-    Yg = dots[4 + 5 * j + 4];
-  }
-  const bool accepted = ys > 1e-10;  // lbfgs.py:472
-  int m = c;
-  double H = dv->H;
-  __syncthreads();
-  if (accepted) {
-    // append row / column c
-    if (j < c) {
-      SY[j * MDE_LB_LD + c] = s_old_ynew;
-      SY[c * MDE_LB_LD + j] = snew_y_old;
-      YY[j * MDE_LB_LD + c] = y_old_ynew;
-      YY[c * MDE_LB_LD + j] = y_old_ynew;
-    }
-    if (j == c) {
-      SY[c * MDE_LB_LD + c] = ys;
-      YY[c * MDE_LB_LD + c] = yy;
-      Sg = sg_new;
-      Yg = yg_new;
-    }
-    __syncthreads();
-    m = c + 1;
-    H = ys / yy;  // lbfgs.py:486
-    if (c == history) {
-      // drop the oldest pair (lbfgs.py:474-478): shift everything up / left by one
-      double rowS[MDE_LB_MAX + 1], rowY[MDE_LB_MAX + 1];
-      for (int i = 1; i < m; ++i) {
-        rowS[i] = (j + 1 < m) ? SY[i * MDE_LB_LD + j + 1] : 0.0;
-        rowY[i] = (j + 1 < m) ? YY[i * MDE_LB_LD + j + 1] : 0.0;
-      }
-      __syncthreads();
-      for (int i = 1; i < m; ++i) {
-        SY[(i - 1) * MDE_LB_LD + j] = rowS[i];
-        YY[(i - 1) * MDE_LB_LD + j] = rowY[i];
-      }
-      Sg = __shfl_down(Sg, 1, 64);
-      Yg = __shfl_down(Yg, 1, 64);
-      m = history;
-      __syncthreads();
+// Sums over the 64 lanes of NV values at once: lane q < NV returns the total of val[q].  A butterfly
+// in which every lane keeps half of its values per step (63 shuffles for up to 64 values; NV
+// separate wave sums are 6 NV of them, and behind a run-time `q < nval` each is a serial chain of six
+// cross-lane latencies -- 15 us of the 28 the staging kernel took at N = 140k).
+template <int NV>
+__device__ __forceinline__ double lb_transpose_sum(const double (&val)[NV]) {
+  static_assert(NV <= 64, "one value per lane at most");
+  double a[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) a[k] = k < NV ? val[k] : 0.0;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const bool hi = (lane & o) != 0;
+#pragma unroll
+    for (int k = 0; k < o; ++k) {
+      if (k >= NV) continue;  // both halves are zero in every lane
+      const double keep = hi ? a[k + o] : a[k];
+      const double send = hi ? a[k] : a[k + o];
+      a[k] = keep + __shfl_xor(send, o, 64);
     }
   }
-  // two-loop recursion in coefficient form: q = -g + sum cq_j y_j ; r = H q + sum cr_j s_j
-  const double rho = (j < m) ? 1.0 / SY[j * MDE_LB_LD + j] : 0.0;
-  double cq = 0.0, al = 0.0, cr = 0.0;
-  for (int i = m - 1; i >= 0; --i) {
-    const double part = (j < m) ? cq * SY[i * MDE_LB_LD + j] : 0.0;
-    const double sq = -__shfl(Sg, i, 64) + mde_wave_sum(part);
-    const double a = __shfl(rho, i, 64) * sq;
-    if (j == i) {
-      al = a;
-      cq = -a;
-    }
-  }
-  for (int i = 0; i < m; ++i) {
-    const double p1 = (j < m) ? cq * YY[i * MDE_LB_LD + j] : 0.0;
-    const double p2 = (j < m) ? cr * SY[j * MDE_LB_LD + i] : 0.0;
-    const double yq = -__shfl(Yg, i, 64) + mde_wave_sum(p1);
-    const double yr = H * yq + mde_wave_sum(p2);
-    if (j == i) cr = al - rho * yr;
-  }
-  // write back
-  if (j < m) {
-    dv->cs[j] = (float)cr;
-    dv->cy[j] = (float)(H * cq);
-  }
-  if (accepted) {
-    for (int i = 0; i < m; ++i) {
-      if (j < m) {
-        dv->SY[i * MDE_LB_LD + j] = SY[i * MDE_LB_LD + j];
-        dv->YY[i * MDE_LB_LD + j] = YY[i * MDE_LB_LD + j];
-      }
-    }
-    // slot permutation: the spare becomes the newest pair; when full, the oldest slot is the new spare
-    int ord = (j <= history) ? dv->order[j] : 0;
-    if (c == history) {
-      const int first = __shfl(ord, 0, 64);
-      const int next = __shfl_down(ord, 1, 64);
-      ord = (j < history) ? next : first;
-    }
-    __syncthreads();
-    if (j <= history) dv->order[j] = ord;
-  }
-  if (j == 0) {
-    dv->count = m;
-    dv->accepted = accepted ? 1 : 0;
-    dv->H = H;
-    dv->c_g = (float)(-H);
-  }
+  return a[0];
 }
 
-// ---- the device-driven step in four launches
-// (1) k_lb_stage_all: stage the new pair and form every dot product against the stored pairs, eight
-//     pairs per pass over the vectors; (2) k_lb_reduce adds the workgroups' partials to `dots`.
-// (3) k_lbfgs_direction (above).
-// (4) k_lb_combine_all: d_out from all pairs, its statistics against g in the same pass, reduced by
-//     the last workgroup (what mde_vec_stats(g, d_out, NULL) writes).
-#define MDE_LB_NVAL (4 + 5 * MDE_LB_GROUP)
-__global__ __launch_bounds__(MDE_BLOCK) void k_lb_stage_all(int64_t N, const float* __restrict__ g,
-                                                            float* __restrict__ g_prev,
-                                                            const float* __restrict__ d, float t,
-                                                            float* __restrict__ buf,
-                                                            const LbDev* __restrict__ dv,
-                                                            double* __restrict__ partial) {
-  __shared__ double sm[MDE_BLOCK / 64][MDE_LB_NVAL];
+// The staging pass of the device-driven step over the elements i = b * MDE_BLOCK + thread (+ k nb
+// MDE_BLOCK): the new pair y = g - g_prev, s = t d is written to the spare slot, g_prev <- g, and the
+// workgroup's share of every dot product the history update needs goes to partial[row * nb + b]
+// (rows 0..3: y*.s*, y*.y*, s*.g, y*.g; 4 + 5 j + k: pair j: s_j.y*, y_j.y*, s*.y_j, s_j.g, y_j.g),
+// eight stored pairs per pass.  PUBLISH: relaxed device-scope stores (read again inside the launch).
+template <bool PUBLISH>
+__device__ __forceinline__ void lb_stage_phase(int64_t N, const float* __restrict__ g, float* __restrict__ g_prev,
+                                               const float* __restrict__ d, float t, float* __restrict__ buf,
+                                               const LbDev* __restrict__ dv, double* __restrict__ partial,
+                                               double (*sm)[MDE_LB_NVAL]) {
   const int count = dv->count;
   const int spare = dv->order[count];
   float* s_new = buf + (int64_t)(2 * spare) * N;
@@ -1455,7 +1369,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_stage_all(int64_t N, const flo
       ps[j] = buf + (int64_t)(2 * slot) * N;
       py[j] = buf + (int64_t)(2 * slot + 1) * N;
     }
-    double val[MDE_LB_NVAL];  // 0..3: y*.s*, y*.y*, s*.g, y*.g; 4 + 5 j + k: pair j
+    double val[MDE_LB_NVAL];
 #pragma unroll
     for (int q = 0; q < MDE_LB_NVAL; ++q) val[q] = 0.0;
     for (int64_t i = (int64_t)b * MDE_BLOCK + threadIdx.x; i < N; i += (int64_t)nb * MDE_BLOCK) {
@@ -1485,23 +1399,18 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_stage_all(int64_t N, const flo
       }
 #pragma unroll
       for (int j = 0; j < MDE_LB_GROUP; ++j) {
-        const double s = sj[j], y = yj[j];
-        val[4 + 5 * j + 0] = fma(s, (double)yv, val[4 + 5 * j + 0]);  // s_j . y*
-        val[4 + 5 * j + 1] = fma(y, (double)yv, val[4 + 5 * j + 1]);  // y_j . y*
-        val[4 + 5 * j + 2] = fma((double)sv, y, val[4 + 5 * j + 2]);  // s* . y_j
-        val[4 + 5 * j + 3] = fma(s, (double)gv, val[4 + 5 * j + 3]);  // s_j . g
-        val[4 + 5 * j + 4] = fma(y, (double)gv, val[4 + 5 * j + 4]);  // y_j . g
+        const double sd = sj[j], yd = yj[j];
+        val[4 + 5 * j + 0] = fma(sd, (double)yv, val[4 + 5 * j + 0]);  // s_j . y*
+        val[4 + 5 * j + 1] = fma(yd, (double)yv, val[4 + 5 * j + 1]);  // y_j . y*
+        val[4 + 5 * j + 2] = fma((double)sv, yd, val[4 + 5 * j + 2]);  // s* . y_j
+        val[4 + 5 * j + 3] = fma(sd, (double)gv, val[4 + 5 * j + 3]);  // s_j . g
+        val[4 + 5 * j + 4] = fma(yd, (double)gv, val[4 + 5 * j + 4]);  // y_j . g
       }
     }
-    // wave sums -> LDS -> one thread per value adds the four waves (two barriers per pass)
+    // lane q holds the wave's total of value q -> LDS -> thread q adds the four waves
     const int nval = 4 + 5 * pc;
-#pragma unroll
-    for (int q = 0; q < MDE_LB_NVAL; ++q) {
-      if (q < nval) {
-        const double r = mde_wave_sum(val[q]);
-        if (lane == 0) sm[wave][q] = r;
-      }
-    }
+    const double tot = lb_transpose_sum<MDE_LB_NVAL>(val);
+    if (lane < MDE_LB_NVAL) sm[wave][lane] = tot;
     __syncthreads();
     if ((int)threadIdx.x < nval && (first || threadIdx.x >= 4)) {
       const int q = threadIdx.x;
@@ -1509,10 +1418,400 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_stage_all(int64_t N, const flo
 #pragma unroll
       for (int w = 0; w < MDE_BLOCK / 64; ++w) r += sm[w][q];
       const int row = q < 4 ? q : 4 + 5 * done + (q - 4);
-      partial[(int64_t)row * nb + b] = r;
+      if (PUBLISH)
+        mde_st_partial(partial + (int64_t)row * nb + b, r);
+      else
+        partial[(int64_t)row * nb + b] = r;
     }
     __syncthreads();
   }
+}
+
+// Results of the direction step, kept in LDS until they are written back to LbDev.
+struct LbOut {
+  int m, accepted;
+  double H;
+  float c_g;
+  float cs[MDE_LB_LD], cy[MDE_LB_LD];
+  int order[MDE_LB_LD];
+  double Sg[MDE_LB_LD], Yg[MDE_LB_LD], cq[MDE_LB_LD], al[MDE_LB_LD], cr[MDE_LB_LD];  // scratch of the recursion
+};
+
+// LDS written by some lanes of ONE wave and read by others: the hardware executes a wave's LDS
+// accesses in order, the compiler must not move them across this point (no workgroup barrier: in the
+// fused kernel the other waves of the block do not take part).
+__device__ __forceinline__ void lb_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// One wave.  Lane j owns column j of everything; the Gram matrices (SY, YY: LD x LD doubles of LDS,
+// LD > history) are edited in place, the coefficients of the new direction go to *o.  `dots` as
+// k_lb_reduce leaves them.  Nothing of LbDev is written.
+template <int LD>
+__device__ void lb_direction_core(const LbDev* __restrict__ dv, const double* dots, int history, double* SY,
+                                  double* YY, LbOut* o) {
+  const int j = threadIdx.x & 63;
+  const int c = dv->count;
+  {
+    // the stored Gram matrices -> LDS, eight row groups per batch with all their loads in flight
+    // together (a loop of one row per trip pays one memory latency per row: 10 us at ten pairs)
+    constexpr int RP = 64 / (LD < 64 ? LD : 64);  // rows per pass of the 64 lanes
+    const int col = j % LD, rsub = j / LD;
+    for (int i0 = 0; i0 < c; i0 += 8 * RP) {
+      double vs[8], vy[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * RP + rsub;
+        const bool in = i < c && col < c;
+        vs[u] = in ? dv->SY[i * MDE_LB_LD + col] : 0.0;
+        vy[u] = in ? dv->YY[i * MDE_LB_LD + col] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * RP + rsub;
+        if (i < c) {
+          SY[i * LD + col] = vs[u];
+          YY[i * LD + col] = vy[u];
+        }
+      }
+    }
+  }
+  const double ys = dots[0], yy = dots[1], sg_new = dots[2], yg_new = dots[3];
+  // per stored pair j: s_j.y*, y_j.y*, s*.y_j, s_j.g, y_j.g
+  double s_old_ynew = 0, y_old_ynew = 0, snew_y_old = 0, Sg = 0, Yg = 0;
+  if (j < c) {
+    s_old_ynew = dots[4 + 5 * j + 0];
+    y_old_ynew = dots[4 + 5 * j + 1];
+    snew_y_old = dots[4 + 5 * j + 2];
+    Sg = dots[4 + 5 * j + 3];
+    Yg = dots[4 + 5 * j + 4];
+  }
+  const bool accepted = ys > 1e-10;  // lbfgs.py:472
+  int m = c;
+  double H = dv->H;
+  int ord = (j <= history) ? dv->order[j] : 0;
+  lb_wave_sync();
+  if (accepted) {
+    // append row / column c
+    if (j < c) {
+      SY[j * LD + c] = s_old_ynew;
+      SY[c * LD + j] = snew_y_old;
+      YY[j * LD + c] = y_old_ynew;
+      YY[c * LD + j] = y_old_ynew;
+    }
+    if (j == c) {
+      SY[c * LD + c] = ys;
+      YY[c * LD + c] = yy;
+      Sg = sg_new;
+      Yg = yg_new;
+    }
+    lb_wave_sync();
+    m = c + 1;
+    H = ys / yy;  // lbfgs.py:486
+    if (c == history) {
+      // drop the oldest pair (lbfgs.py:474-478): shift everything up / left by one
+      // (in place, rows ascending: row i is read before row i - 1 is written, and a wave's LDS
+      // accesses execute in program order; per-lane row buffers would live in scratch memory --
+      // twenty dependent memory round trips, most of this kernel's 12 us)
+      for (int i = 1; i < m; ++i) {
+        const double a = (j + 1 < m && j + 1 < LD) ? SY[i * LD + j + 1] : 0.0;
+        const double y = (j + 1 < m && j + 1 < LD) ? YY[i * LD + j + 1] : 0.0;
+        if (j < LD) {
+          SY[(i - 1) * LD + j] = a;
+          YY[(i - 1) * LD + j] = y;
+        }
+      }
+      Sg = __shfl_down(Sg, 1, 64);
+      Yg = __shfl_down(Yg, 1, 64);
+      m = history;
+      lb_wave_sync();
+    }
+    // slot permutation: the spare becomes the newest pair; when full, the oldest slot is the new spare
+    if (c == history) {
+      const int first = __shfl(ord, 0, 64);
+      const int next = __shfl_down(ord, 1, 64);
+      ord = (j < history) ? next : first;
+    }
+  }
+  double my_cq = 0.0, my_cr = 0.0;
+  if constexpr (LD <= 16) {
+    // Short histories (the default memory is 10): lane i keeps row i and column i of SY and row i of
+    // YY in registers; both loops are substitutions in which lane k finishes its coefficient, hands it
+    // to the others with v_readlane and every later lane folds it into its own running sum -- LD
+    // fully unrolled steps of a readlane and one FMA, no LDS and no cross-lane sums (the two loops
+    // take 1 us; one wave sum per step took 9, the same recursion serially from LDS 9 as well).
+    auto bcast = [](double v, int k) {
+      const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+      return __hiloint2double(hi, lo);
+    };
+    const int li = j < LD ? j : 0;
+    double rS[LD], cS[LD], rY[LD];
+#pragma unroll
+    for (int k = 0; k < LD; ++k) {
+      rS[k] = SY[li * LD + k];
+      cS[k] = SY[k * LD + li];
+      rY[k] = YY[li * LD + k];
+    }
+    const double rho = (j < m) ? 1.0 / SY[li * LD + li] : 0.0;
+    double acc = -Sg, al = 0.0, cq = 0.0;
+#pragma unroll
+    for (int k = LD - 1; k >= 0; --k) {
+      const double a_k = bcast(rho * acc, k);
+      if (k < m) {
+        if (j == k) {
+          al = a_k;
+          cq = -a_k;
+        }
+        if (j < k) acc = fma(-a_k, rS[k], acc);
+      }
+    }
+    double yq = -Yg;
+#pragma unroll
+    for (int k = 0; k < LD; ++k) {
+      const double cqk = bcast(cq, k);
+      if (k < m) yq = fma(cqk, rY[k], yq);
+    }
+    double acc2 = H * yq, cr = 0.0;
+#pragma unroll
+    for (int k = 0; k < LD; ++k) {
+      const double c_k = bcast(al - rho * acc2, k);
+      if (k < m) {
+        if (j == k) cr = c_k;
+        if (j > k) acc2 = fma(c_k, cS[k], acc2);
+      }
+    }
+    my_cq = cq;
+    my_cr = cr;
+  } else {
+    // two-loop recursion in coefficient form: q = -g + sum cq_j y_j ; r = H q + sum cr_j s_j.  m is a
+    // dozen: every lane runs the SAME serial recursion on the LDS copies (uniform addresses: broadcast
+    // reads) -- ~m^2 dependent fp64 FMAs, 2 us; one cross-lane sum per step was 20 serial round trips
+    // of six shuffles each, 9 of the kernel's 12 us.
+    if (j < LD) {
+      o->Sg[j] = Sg;
+      o->Yg[j] = Yg;
+    }
+    lb_wave_sync();
+    for (int i = m - 1; i >= 0; --i) {
+      double a0 = -o->Sg[i], a1 = 0.0;
+      int k = i + 1;
+      for (; k + 1 < m; k += 2) {
+        a0 = fma(o->cq[k], SY[i * LD + k], a0);
+        a1 = fma(o->cq[k + 1], SY[i * LD + k + 1], a1);
+      }
+      if (k < m) a0 = fma(o->cq[k], SY[i * LD + k], a0);
+      const double a = (a0 + a1) / SY[i * LD + i];
+      lb_wave_sync();
+      if (j == 0) {
+        o->al[i] = a;
+        o->cq[i] = -a;
+      }
+      lb_wave_sync();
+    }
+    for (int i = 0; i < m; ++i) {
+      double q0 = -o->Yg[i], q1 = 0.0;
+      int k = 0;
+      for (; k + 1 < m; k += 2) {
+        q0 = fma(o->cq[k], YY[i * LD + k], q0);
+        q1 = fma(o->cq[k + 1], YY[i * LD + k + 1], q1);
+      }
+      if (k < m) q0 = fma(o->cq[k], YY[i * LD + k], q0);
+      double r0 = H * (q0 + q1), r1 = 0.0;
+      k = 0;
+      for (; k + 1 < i; k += 2) {
+        r0 = fma(o->cr[k], SY[k * LD + i], r0);
+        r1 = fma(o->cr[k + 1], SY[(k + 1) * LD + i], r1);
+      }
+      if (k < i) r0 = fma(o->cr[k], SY[k * LD + i], r0);
+      const double c = o->al[i] - (r0 + r1) / SY[i * LD + i];
+      lb_wave_sync();
+      if (j == 0) o->cr[i] = c;
+      lb_wave_sync();
+      if (j == i) {
+        my_cr = c;
+        my_cq = o->cq[i];
+      }
+    }
+  }
+  o->cs[j] = (j < m) ? (float)my_cr : 0.0f;
+  o->cy[j] = (j < m) ? (float)(H * my_cq) : 0.0f;
+  o->order[j] = ord;
+  if (j == 0) {
+    o->m = m;
+    o->accepted = accepted ? 1 : 0;
+    o->H = H;
+    o->c_g = (float)(-H);
+  }
+  lb_wave_sync();
+}
+
+// One wave: *o and the edited Gram matrices -> LbDev.
+template <int LD>
+__device__ void lb_write_back(LbDev* __restrict__ dv, int history, const double* SY, const double* YY,
+                              const LbOut* o) {
+  const int j = threadIdx.x & 63;
+  const int m = o->m;
+  if (j < m) {
+    dv->cs[j] = o->cs[j];
+    dv->cy[j] = o->cy[j];
+  }
+  if (o->accepted) {
+    for (int i = 0; i < m; ++i) {
+      if (j < m) {
+        dv->SY[i * MDE_LB_LD + j] = SY[i * LD + j];
+        dv->YY[i * MDE_LB_LD + j] = YY[i * LD + j];
+      }
+    }
+    if (j <= history) dv->order[j] = o->order[j];
+  }
+  if (j == 0) {
+    dv->count = m;
+    dv->accepted = o->accepted;
+    dv->H = o->H;
+    dv->c_g = o->c_g;
+  }
+}
+
+#define MDE_LB_DIR_LDS(LD) (2 * (LD) * (LD) * sizeof(double) + sizeof(LbOut))
+template <int LD>
+__global__ __launch_bounds__(64) void k_lbfgs_direction(LbDev* __restrict__ dv, const double* __restrict__ dots,
+                                                        int history) {
+  extern __shared__ __attribute__((aligned(16))) char lb_lds[];
+  double* SY = reinterpret_cast<double*>(lb_lds);
+  double* YY = SY + LD * LD;
+  LbOut* out = reinterpret_cast<LbOut*>(YY + LD * LD);
+  lb_direction_core<LD>(dv, dots, history, SY, YY, out);
+  lb_write_back<LD>(dv, history, SY, YY, out);
+}
+
+// ---- the same step in ONE launch, for vectors small enough that launches, not bytes, are what an
+// iteration costs (configs 2 and 3: N = 140k / 80k floats; every kernel boundary is ~5 us on this
+// stack and the four launches below took 60 us of a 150 us iteration).  At most 512 workgroups, all
+// resident at once, in phases separated by a grid-wide arrival counter:
+//   1. stage the new pair and form the partial dot products of the workgroup's own elements;
+//   -- every workgroup has published its partials (relaxed device-scope stores, as mde_last_block) --
+//   2. workgroup q adds row q of the partials and publishes the dot product; -- arrival counter --
+//      EVERY workgroup then runs the direction step on the same numbers in its own LDS: identical
+//      coefficients everywhere, nothing to broadcast;
+//   3. combine the new direction over the workgroup's own elements (it re-reads only what it wrote
+//      itself in phase 1), publish the statistics partials; the last workgroup to arrive reduces
+//      them and writes the bookkeeping back to LbDev (everyone has finished reading it by then).
+#define MDE_LB_FUSED_LD 16       // history <= 15
+#define MDE_LB_FUSED_MAXN (1 << 18)  // <= 512 workgroups of 4 waves: resident together with room to spare
+#define MDE_LB_FUSED_MAXBLOCKS 512
+// the flag words of the fused kernel: doubles [2304, 3072) of the work buffer's small area (nothing
+// else is kept there; zero or an older epoch between launches)
+static inline unsigned int* work_lb_flags(double* work) { return reinterpret_cast<unsigned int*>(work + 2304); }
+__global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* __restrict__ g, float* __restrict__ g_prev,
+                                                        const float* d, float t, float* __restrict__ buf,
+                                                        LbDev* __restrict__ dv, int history, float* out,  // (out may be d)
+                                                        double* __restrict__ partial, double* __restrict__ stats,
+                                                        unsigned int* __restrict__ flags, unsigned int epoch) {
+  constexpr int LD = MDE_LB_FUSED_LD;
+  __shared__ double sm[MDE_BLOCK / 64][MDE_LB_NVAL];
+  __shared__ double s_dots[4 + 5 * LD];
+  __shared__ double s_SY[LD * LD], s_YY[LD * LD];
+  __shared__ LbOut s_out;
+  const int count = dv->count;
+  const int wave = threadIdx.x >> 6;
+  const int nb = gridDim.x, b = blockIdx.x;
+  // ---- phase 1
+  lb_stage_phase<true>(N, g, g_prev, d, t, buf, dv, partial, sm);
+  // Arrival point `which`: every workgroup raises its own flag word to this launch's epoch (plain
+  // device-scope stores to distinct addresses; an arrival COUNTER costs ~20 ns per workgroup because
+  // same-address atomics are executed one after the other at the memory side -- 5.6 us for 274
+  // workgroups, three times per launch), the waiting workgroups read all flags, one per thread.
+  auto grid_arrive = [&](int which, bool wait) {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this thread's published values have completed
+    __syncthreads();
+    unsigned int* f = flags + which * MDE_LB_FUSED_MAXBLOCKS;
+    if (threadIdx.x == 0) __hip_atomic_store(f + b, epoch + (unsigned int)which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!wait) return;
+    // (a workgroup that never sees the others arrive gives up after ~1 s and lets the result be wrong
+    // rather than hanging the queue)
+    for (unsigned int spins = 0; spins < (1u << 22); ++spins) {
+      bool ok = true;
+      for (int k = threadIdx.x; k < nb; k += MDE_BLOCK)
+        ok = ok && __hip_atomic_load(f + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch + (unsigned int)which;
+      if (__syncthreads_and(ok ? 1 : 0)) break;
+      __builtin_amdgcn_s_sleep(1);
+    }
+  };
+  grid_arrive(0, true);
+  // ---- phase 2a: workgroup q adds row q of the partials (k_lb_reduce: same order of additions)
+  const int nrows = 4 + 5 * count;
+  double* dots_g = partial + (int64_t)(4 + 5 * LD + 8) * nb;  // behind the dot-product and statistics rows
+  for (int q = b; q < nrows; q += nb) {
+    double r = 0.0;
+    for (int k = threadIdx.x; k < nb; k += MDE_BLOCK) r += mde_ld_partial(partial + (int64_t)q * nb + k);
+    const double tot = mde_block_sum(r, &sm[0][0]);
+    if (threadIdx.x == 0) mde_st_partial(dots_g + q, tot);
+    __syncthreads();
+  }
+  grid_arrive(1, true);
+  // ---- phase 2b: every workgroup runs the direction step on the same numbers
+  for (int q = threadIdx.x; q < nrows; q += MDE_BLOCK) s_dots[q] = mde_ld_partial(dots_g + q);
+  __syncthreads();
+  if (wave == 0) lb_direction_core<LD>(dv, s_dots, history, s_SY, s_YY, &s_out);
+  __syncthreads();
+  // ---- phase 3 (k_lb_combine_all), with the coefficients and the slot order of s_out
+  const int m = s_out.m;
+  const float c_g = s_out.c_g;
+  double gd = 0, gg = 0, g1 = 0, gm = 0, nf = 0, dd = 0, dm = 0;
+  for (int64_t i = (int64_t)b * MDE_BLOCK + threadIdx.x; i < N; i += (int64_t)nb * MDE_BLOCK) {
+    const float gv = g[i];
+    float v = c_g * gv;
+    for (int j0 = 0; j0 < m; j0 += MDE_LB_GROUP) {
+      float sv[MDE_LB_GROUP], yv[MDE_LB_GROUP];
+#pragma unroll
+      for (int j = 0; j < MDE_LB_GROUP; ++j) {
+        const int jj = (j0 + j < m) ? j0 + j : 0;
+        const float* sp = buf + (int64_t)(2 * s_out.order[jj]) * N;
+        sv[j] = sp[i];
+        yv[j] = sp[N + i];
+      }
+#pragma unroll
+      for (int j = 0; j < MDE_LB_GROUP; ++j)
+        if (j0 + j < m) v = fmaf(s_out.cy[j0 + j], yv[j], fmaf(s_out.cs[j0 + j], sv[j], v));
+    }
+    out[i] = v;
+    const double gvd = gv, dv2 = v;
+    gg += gvd * gvd;
+    const double ag = fabs(gvd);
+    g1 += ag;
+    gm = ag > gm ? ag : gm;
+    nf += (fabsf(gv) <= 3.402823466e+38f) ? 0.0 : 1.0;
+    gd += gvd * dv2;
+    dd += dv2 * dv2;
+    const double ad = fabs(dv2);
+    dm = ad > dm ? ad : dm;
+  }
+  const double v8[8] = {gd, gg, g1, gm, nf, dd, dm, 0.0};
+  double* spart = partial + (int64_t)(4 + 5 * LD) * nb;  // behind the dot-product rows
+  mde_publish8(v8, (1u << 3) | (1u << 6), spart, nb, b);
+  // workgroup 0 finishes: the statistics rows, and the bookkeeping back to LbDev (everyone has
+  // finished reading it when the third flag is up)
+  grid_arrive(2, b == 0);
+  if (b != 0) return;
+  mde_final_rows(8, nb, spart, stats, (1ull << 3) | (1ull << 6));
+  if (wave == 0) lb_write_back<LD>(dv, history, s_SY, s_YY, &s_out);
+}
+
+// ---- the device-driven step in four launches
+// (1) k_lb_stage_all: stage the new pair and form every dot product against the stored pairs, eight
+//     pairs per pass over the vectors; (2) k_lb_reduce adds the workgroups' partials to `dots`.
+// (3) k_lbfgs_direction (above).
+// (4) k_lb_combine_all: d_out from all pairs, its statistics against g in the same pass, reduced by
+//     the last workgroup (what mde_vec_stats(g, d_out, NULL) writes).
+__global__ __launch_bounds__(MDE_BLOCK) void k_lb_stage_all(int64_t N, const float* __restrict__ g,
+                                                            float* __restrict__ g_prev,
+                                                            const float* __restrict__ d, float t,
+                                                            float* __restrict__ buf,
+                                                            const LbDev* __restrict__ dv,
+                                                            double* __restrict__ partial) {
+  __shared__ double sm[MDE_BLOCK / 64][MDE_LB_NVAL];
+  lb_stage_phase<false>(N, g, g_prev, d, t, buf, dv, partial, sm);
 }
 
 // dots[q] = sum_b partial[q * nb + b] for the 4 + 5 count rows that were written (one workgroup per
@@ -1601,15 +1900,35 @@ extern "C" int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, c
   if (!o || !o->dev || !g || !g_prev || !d || !d_out || !stats || !work) return MDE_E_INVALID;
   hipStream_t st = mde_stream(stream);
   const int64_t N = o->N;
-  const int nb = mde_grid(N, MDE_BLOCK * 2, 1024);
   double* partial = work + MDE_SMALL_DOUBLES;
+  if (N <= MDE_LB_FUSED_MAXN && o->history < MDE_LB_FUSED_LD && !getenv("MDE_LB_UNFUSED")) {
+    const int nbf = mde_grid(N, MDE_BLOCK * 2, 1024);  // (the grid of the four-launch form: same partials, same sums)
+    static std::atomic<unsigned int> launches{0};  // one epoch per launch, shared by every solver object
+    const unsigned int epoch = 4u * (launches.fetch_add(1u) + 1u);
+    hipLaunchKernelGGL(k_lb_fused, dim3(nbf), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t, o->buf, o->dev, o->history,
+                       d_out, partial, stats, work_lb_flags(work), epoch);
+    MDE_LAUNCH_CHECK();
+    return MDE_OK;
+  }
+  const int nb = mde_grid(N, MDE_BLOCK * 2, 1024);
   double* dots = work;  // the small area: 4 + 5 * 63 doubles at most
   hipLaunchKernelGGL(k_lb_stage_all, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t, o->buf, o->dev,
                      partial);
   MDE_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_lb_reduce, dim3(4 + 5 * o->history), dim3(MDE_BLOCK), 0, st, nb, partial, o->dev, dots);
   MDE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_lbfgs_direction, dim3(1), dim3(64), 0, st, o->dev, dots, o->history);
+  if (o->history < 16) {
+    hipLaunchKernelGGL(k_lbfgs_direction<16>, dim3(1), dim3(64), MDE_LB_DIR_LDS(16), st, o->dev, dots, o->history);
+  } else {
+    static bool dir_attr = false;
+    if (!dir_attr) {
+      MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lbfgs_direction<MDE_LB_LD>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)MDE_LB_DIR_LDS(MDE_LB_LD)));
+      dir_attr = true;
+    }
+    hipLaunchKernelGGL(k_lbfgs_direction<MDE_LB_LD>, dim3(1), dim3(64), MDE_LB_DIR_LDS(MDE_LB_LD), st, o->dev, dots,
+                       o->history);
+  }
   MDE_LAUNCH_CHECK();
   const int nbc = mde_grid(N, MDE_BLOCK * 2, MDE_RED_BLOCKS);  // (its last workgroup adds nbc partials per row)
   hipLaunchKernelGGL(k_lb_combine_all, dim3(nbc), dim3(MDE_BLOCK), 0, st, N, g, o->buf, o->dev, d_out, partial,

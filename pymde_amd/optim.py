@@ -142,7 +142,7 @@ class _Engine(object):
                                              self.stream()))
 
     def finish_read(self, count):
-        self._stream_obj.synchronize()
+        self._stream_obj.synchronize()  # (polling hipStreamQuery from C instead measured the same)
         vals = self.host[:count].numpy().copy()
         return vals, float(self.host_loss[0])
 

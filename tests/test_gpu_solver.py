@@ -267,22 +267,26 @@ def test_spectral_initialiser(golden_spectral):
     assert float(mde.average_distortion(emb)) == pytest.approx(float(g["mid_value"]), rel=1e-3)
 
 
-def test_device_driven_lbfgs_step_matches_explicit_two_loop():
+@pytest.mark.parametrize("N,unfused", [(3001, False), (3001, True), (70001, False), (70001, True)])
+def test_device_driven_lbfgs_step_matches_explicit_two_loop(monkeypatch, N, unfused):
     """mde_lbfgs_dev_step (history update, acceptance test and two-loop recursion all on the
     device) against the explicit recursion of lbfgs.py:468-507 in float64, incl. the history
-    wrap-around (more than 8 pairs: two kernel groups) and a rejected pair (y.s <= 1e-10)."""
+    wrap-around (more than 8 pairs: two kernel groups) and a rejected pair (y.s <= 1e-10).  Both
+    forms: the single launch with a grid-wide arrival counter that small vectors take (one / many
+    workgroups), and the four launches of large vectors (forced with MDE_LB_UNFUSED)."""
     import ctypes
     from pymde_amd import _lib, util
     lib = _lib.load()
+    if unfused:
+        monkeypatch.setenv("MDE_LB_UNFUSED", "1")
     rng = np.random.default_rng(0)
-    N = 3001
     A = rng.standard_normal((60, N))
     diag = rng.uniform(0.5, 2.0, N)
 
     def grad(x):  # SPD quadratic: y.s > 0
         return diag * x + A.T @ (A @ x) / 60.0
 
-    for hist in (3, 10):
+    for hist in (3, 10, 20):   # 20: the general (64-column) form of the direction step, always four launches
         h = ctypes.c_void_p()
         _lib.check(lib.mde_lbfgs_create(N, hist, ctypes.byref(h)))
         st = _lib.stream_ptr(torch.device(DEV))
@@ -296,7 +300,7 @@ def test_device_driven_lbfgs_step_matches_explicit_two_loop():
         d = torch.tensor(d_np, dtype=torch.float32, device=DEV)
         S, Y = [], []
         Hd = 1.0
-        for step in range(14):
+        for step in range(14 if hist < 20 else 25):
             t = 0.3
             s32 = np.float32(t) * d.cpu().numpy()
             reject = step == 11
