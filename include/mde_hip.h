@@ -291,6 +291,20 @@ int mde_std_tangent(int64_t n, int32_t d, const float* X, float* Z, double* work
  * read back after every batch of steps (one stream synchronisation per 6 steps, usually one). */
 int mde_std_retract(int64_t n, int32_t d, float* Z, int32_t demean, double* work,
                     int32_t* status_dev, void* stream);
+/* The line search's trial point in one call: Z <- retraction(X + t dir) for the Centered and the
+ * Standardized constraint [ref: optim.py:135-136 after lbfgs.py:551: `X += t d` then
+ * `constraint.project_onto_constraint(X)`].  At small d the step is folded into the first pass of the
+ * retraction (one launch less per trial); results are those of mde_axpy followed by mde_center /
+ * mde_std_retract, bit for bit. */
+int mde_center_step(int64_t n, int32_t d, const float* X, const float* dir, float t, float* Z, double* work,
+                    void* stream);
+int mde_std_retract_step(int64_t n, int32_t d, const float* X, const float* dir, float t, float* Z,
+                         int32_t demean, double* work, int32_t* status_dev, void* stream);
+/* mde_std_tangent(X, Z) followed by mde_vec_stats(Z, dir, X) (dir may be NULL): the projected gradient
+ * and the statistics the line search reads, with the statistics folded into the projection's second
+ * pass at d <= 4.  ASYNC. */
+int mde_std_tangent_stats(int64_t n, int32_t d, const float* X, float* Z, const float* dir, double* stats,
+                          double* work, void* stream);
 /* Gram matrix out[d_a, d_b] (double, device) = A^T B for A [n,d_a], B [n,d_b]; uses the
  * f32 MFMA path when both widths are multiples of 32. */
 int mde_gram(int64_t n, int32_t da, int32_t db, const float* A, const float* B, double* out,

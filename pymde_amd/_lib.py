@@ -70,6 +70,9 @@ SYMBOLS = {
     "mde_anchor_rows": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "mde_std_tangent": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "mde_std_retract": (c_i32, [c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "mde_center_step": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp]),
+    "mde_std_retract_step": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "mde_std_tangent_stats": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mde_gram": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "mde_right_multiply": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "mde_right_multiply_add": (c_i32, [c_i64, c_i32, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp]),

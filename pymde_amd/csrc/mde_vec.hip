@@ -92,14 +92,16 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_axpy(int64_t N, float alpha,
   }
 }
 
+static int axpy_impl(int64_t N, float alpha, const float* x, const float* y, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_axpy, dim3(mde_grid((N + 3) / 4, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, N, alpha, x, y, out);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
 extern "C" int mde_axpy(int64_t N, float alpha, const float* x, const float* y, float* out,
                         void* stream) {
   if (N < 0 || (N > 0 && (!x || !y || !out))) return MDE_E_INVALID;
   if (N == 0) return MDE_OK;
-  hipLaunchKernelGGL(k_axpy, dim3(mde_grid((N + 3) / 4, MDE_BLOCK)), dim3(MDE_BLOCK), 0,
-                     mde_stream(stream), N, alpha, x, y, out);
-  MDE_LAUNCH_CHECK();
-  return MDE_OK;
+  return axpy_impl(N, alpha, x, y, out, mde_stream(stream));
 }
 
 // eight block-wide reductions with two barriers: wave results to LDS, thread q < 8 combines the waves
@@ -199,8 +201,11 @@ extern "C" int mde_vec_stats(int64_t N, const float* g, const float* d, const fl
 
 // ---------------------------------------------------------------- column sums / centring
 // threads are laid out (rows_per_pass x dp), dp = pow2 >= min(d,256); coalesced over columns
-__global__ __launch_bounds__(MDE_BLOCK) void k_colsum(int64_t n, int d, int dp,
-                                                      const float* __restrict__ Z,
+// STEP: Z <- X0 + t DIR first (the line-search trial point: one launch less than axpy + centring; the
+// sums are those of the rounded floats, exactly what the two launches produce)
+template <bool STEP>
+__global__ __launch_bounds__(MDE_BLOCK) void k_colsum(int64_t n, int d, int dp, float* Z, const float* X0,
+                                                      const float* DIR, float t,
                                                       double* __restrict__ partial /* [nb][d] */,
                                                       double* __restrict__ mean, unsigned int* ticket) {
   __shared__ double sm[MDE_BLOCK];
@@ -211,8 +216,16 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_colsum(int64_t n, int d, int dp,
     const int c = c0 + tc;
     double s = 0.0;
     if (c < d)
-      for (int64_t r = (int64_t)blockIdx.x * rpp + tr; r < n; r += (int64_t)gridDim.x * rpp)
-        s += (double)Z[r * d + c];
+      for (int64_t r = (int64_t)blockIdx.x * rpp + tr; r < n; r += (int64_t)gridDim.x * rpp) {
+        float z;
+        if (STEP) {
+          z = fmaf(t, DIR[r * d + c], X0[r * d + c]);
+          Z[r * d + c] = z;
+        } else {
+          z = Z[r * d + c];
+        }
+        s += (double)z;
+      }
     __syncthreads();
     sm[threadIdx.x] = s;
     __syncthreads();
@@ -256,7 +269,8 @@ static int pow2_ge(int x) {
   return p;
 }
 
-static int center_impl(int64_t n, int d, float* Z, double* work, hipStream_t st) {
+static int center_impl(int64_t n, int d, float* Z, double* work, hipStream_t st, const float* X0 = nullptr,
+                       const float* DIR = nullptr, float t = 0.0f) {
   double* mean = work;  // d doubles (d <= 2048 fits the small area)
   double* partial = work_partials(work, d);
   int dp = pow2_ge(d);
@@ -265,8 +279,12 @@ static int center_impl(int64_t n, int d, float* Z, double* work, hipStream_t st)
   int nb = mde_grid(n, rpp * 8, MDE_RED_BLOCKS);
   // (a last workgroup adding d columns of nb partials one after the other only pays for a few columns)
   const bool fused_final = d <= 16;
-  hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(MDE_BLOCK), 0, st, n, d, dp, Z, partial, mean,
-                     fused_final ? work_ticket(work, TK_CENTER) : (unsigned int*)nullptr);
+  if (DIR)
+    hipLaunchKernelGGL(k_colsum<true>, dim3(nb), dim3(MDE_BLOCK), 0, st, n, d, dp, Z, X0, DIR, t, partial, mean,
+                       fused_final ? work_ticket(work, TK_CENTER) : (unsigned int*)nullptr);
+  else
+    hipLaunchKernelGGL(k_colsum<false>, dim3(nb), dim3(MDE_BLOCK), 0, st, n, d, dp, Z, X0, DIR, t, partial, mean,
+                       fused_final ? work_ticket(work, TK_CENTER) : (unsigned int*)nullptr);
   MDE_LAUNCH_CHECK();
   if (!fused_final) {
     hipLaunchKernelGGL(k_colsum_final, dim3(d), dim3(64), 0, st, nb, d, n, partial, mean);
@@ -281,6 +299,13 @@ static int center_impl(int64_t n, int d, float* Z, double* work, hipStream_t st)
 extern "C" int mde_center(int64_t n, int32_t d, float* Z, double* work, void* stream) {
   if (n <= 0 || d <= 0 || d > 2048 || !Z || !work) return MDE_E_INVALID;
   return center_impl(n, d, Z, work, mde_stream(stream));
+}
+
+// Z <- centre(X + t DIR): the trial point of the line search under the Centered constraint
+extern "C" int mde_center_step(int64_t n, int32_t d, const float* X, const float* dir, float t, float* Z,
+                               double* work, void* stream) {
+  if (n <= 0 || d <= 0 || d > 2048 || !X || !dir || !Z || !work) return MDE_E_INVALID;
+  return center_impl(n, d, Z, work, mde_stream(stream), X, dir, t);
 }
 
 // ---------------------------------------------------------------- anchors
@@ -661,6 +686,77 @@ extern "C" int mde_std_tangent(int64_t n, int32_t d, const float* X, float* Z, d
   return rmul_impl(n, d, d, X, G, (float)(-1.0 / (double)n), Z, Z, st);
 }
 
+// The same with the statistics of the result folded in (d <= 4: one launch less per evaluation): what
+// mde_std_tangent(X, Z) followed by mde_vec_stats(Z, dir, X) leaves in `stats`.
+template <int D>
+__global__ __launch_bounds__(MDE_BLOCK) void k_rmul_tiny_stats(int64_t n, const float* __restrict__ X,
+                                                               const double* __restrict__ G, float alpha, float* Z,
+                                                               const float* __restrict__ dir, double* __restrict__ partial,
+                                                               double* __restrict__ stats, unsigned int* __restrict__ ticket) {
+  float m[D * D];
+#pragma unroll
+  for (int i = 0; i < D * D; ++i) m[i] = (float)(G[i] * (double)alpha);
+  double gd = 0, gg = 0, g1 = 0, gm = 0, nf = 0, dd = 0, dm = 0, xx = 0;
+  for (int64_t r = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * MDE_BLOCK) {
+    float a[D], o[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) a[c] = X[r * D + c];
+#pragma unroll
+    for (int j = 0; j < D; ++j) o[j] = Z[r * D + j];
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+#pragma unroll
+      for (int j = 0; j < D; ++j) o[j] = fmaf(a[c], m[c * D + j], o[j]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+      Z[r * D + j] = o[j];
+      const double gv = o[j], xv = a[j];
+      gg += gv * gv;
+      const double ag = fabs(gv);
+      g1 += ag;
+      gm = ag > gm ? ag : gm;
+      nf += (fabsf(o[j]) <= 3.402823466e+38f) ? 0.0 : 1.0;
+      xx += xv * xv;
+      if (dir) {
+        const double dv = dir[r * D + j];
+        gd += gv * dv;
+        dd += dv * dv;
+        const double ad = fabs(dv);
+        dm = ad > dm ? ad : dm;
+      }
+    }
+  }
+  const double v[8] = {gd, gg, g1, gm, nf, dd, dm, xx};
+  mde_publish8(v, (1u << 3) | (1u << 6), partial, gridDim.x, blockIdx.x);
+  if (!mde_last_block(ticket)) return;
+  mde_final_rows(8, gridDim.x, partial, stats, (1ull << 3) | (1ull << 6));
+}
+
+extern "C" int mde_std_tangent_stats(int64_t n, int32_t d, const float* X, float* Z, const float* dir, double* stats,
+                                     double* work, void* stream) {
+  if (n <= 0 || d <= 0 || d > 2048 || !X || !Z || !stats || !work) return MDE_E_INVALID;
+  hipStream_t st = mde_stream(stream);
+  if (d > 4) {
+    const int rc = mde_std_tangent(n, d, X, Z, work, stream);
+    if (rc != MDE_OK) return rc;
+    return vec_stats_impl(n * (int64_t)d, Z, dir, X, stats, work, st);
+  }
+  double* G = work_mats(work);
+  const int rc = gram_impl(n, d, d, Z, X, G, work_partials(work, d), work_ticket(work, TK_GRAM), st);
+  if (rc != MDE_OK) return rc;
+  const int nb = mde_grid(n, MDE_BLOCK * 2, MDE_RED_BLOCKS);
+  const float alpha = (float)(-1.0 / (double)n);
+#define TINY(D_)                                                                                                  \
+  if (d == D_)                                                                                                    \
+    hipLaunchKernelGGL(k_rmul_tiny_stats<D_>, dim3(nb), dim3(MDE_BLOCK), 0, st, n, X, G, alpha, Z, dir,           \
+                       work_partials(work, d), stats, work_ticket(work, TK_STATS));
+  // (the partials go behind the matrices: G itself is still being read by workgroups that start late)
+  TINY(1) TINY(2) TINY(3) TINY(4)
+#undef TINY
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
 // ---------------------------------------------------------------- C^{-1/2} of a small SPD matrix
 // One workgroup.  d = 1, 2: closed form.  d >= 3: coupled Newton-Schulz iteration in double
 //   Y0 = C/s, Z0 = I;  T = (3I - Z Y)/2;  Y <- Y T;  Z <- T Z;   Z -> (C/s)^{-1/2}
@@ -777,8 +873,10 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_invsqrt(int d, const double* C, d
 // (the Gram matrix of the centred rows) and out_scale C^{-1/2}; k_center_rmul_tiny then applies
 // both.  (Seven launches -- column sums, their reduction, the subtraction, Gram, its reduction,
 // the inverse square root, the multiply -- when composed from the general-d pieces.)
+// X0 / DIR given: Z <- X0 + t DIR first (the trial point of the line search: one launch less).
 template <int D>
-__global__ __launch_bounds__(MDE_BLOCK) void k_retract_stats_tiny(int64_t n, const float* __restrict__ Z,
+__global__ __launch_bounds__(MDE_BLOCK) void k_retract_stats_tiny(int64_t n, float* Z, const float* X0,
+                                                                  const float* DIR, float t,
                                                                   int demean, double out_scale,
                                                                   double* partial /* [D*D + D][nb] */,
                                                                   double* mean /* D */, double* C, double* M,
@@ -791,8 +889,17 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_retract_stats_tiny(int64_t n, con
   for (int q = 0; q < NQ; ++q) acc[q] = 0.0;
   for (int64_t r = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * MDE_BLOCK) {
     double a[D];
+    if (DIR) {
 #pragma unroll
-    for (int i = 0; i < D; ++i) a[i] = Z[r * D + i];
+      for (int i = 0; i < D; ++i) {
+        const float z = fmaf(t, DIR[r * D + i], X0[r * D + i]);
+        Z[r * D + i] = z;
+        a[i] = z;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < D; ++i) a[i] = Z[r * D + i];
+    }
 #pragma unroll
     for (int i = 0; i < D; ++i) {
       acc[D * D + i] += a[i];
@@ -1039,11 +1146,14 @@ static int invsqrt_impl(int d, const double* C, double out_scale, double* M, dou
 
 // Z <- sqrt(n) (Z - mean) C^{-1/2},  C = (Z-mean)^T (Z-mean)          [ref: util.py:129-161]
 // (= sqrt(n) U V^T of the thin SVD Z - mean = U S V^T, the reference's formula.)
-extern "C" int mde_std_retract(int64_t n, int32_t d, float* Z, int32_t demean, double* work,
-                               int32_t* status_dev, void* stream) {
-  if (n <= 0 || d <= 0 || d > 2048 || !Z || !work) return MDE_E_INVALID;
-  hipStream_t st = mde_stream(stream);
+// (X0, DIR, t given: Z <- X0 + t DIR first -- folded into the statistics pass at d <= 4)
+static int std_retract_impl(int64_t n, int32_t d, float* Z, int32_t demean, double* work, int32_t* status_dev,
+                            hipStream_t st, const float* X0 = nullptr, const float* DIR = nullptr, float t = 0.0f) {
   int rc = MDE_OK;
+  if (DIR && d > 4) {
+    rc = axpy_impl(n * (int64_t)d, t, DIR, X0, Z, st);
+    if (rc != MDE_OK) return rc;
+  }
   double* mats = work_mats(work);
   const int64_t m = (int64_t)d * d;
   double* C = mats;
@@ -1055,8 +1165,8 @@ extern "C" int mde_std_retract(int64_t n, int32_t d, float* Z, int32_t demean, d
     double* mean = work;  // small area
 #define TINY(D_)                                                                                             \
   if (d == D_) {                                                                                             \
-    hipLaunchKernelGGL(k_retract_stats_tiny<D_>, dim3(nb), dim3(MDE_BLOCK), 0, st, n, Z, (int)demean,        \
-                       sqrt((double)n), work_partials(work, d), mean, C, M, scratch, status_dev,             \
+    hipLaunchKernelGGL(k_retract_stats_tiny<D_>, dim3(nb), dim3(MDE_BLOCK), 0, st, n, Z, X0, DIR, t,         \
+                       (int)demean, sqrt((double)n), work_partials(work, d), mean, C, M, scratch, status_dev, \
                        work_ticket(work, TK_RETRACT));                                                       \
     MDE_LAUNCH_CHECK();                                                                                      \
     hipLaunchKernelGGL(k_center_rmul_tiny<D_>, dim3(nb2), dim3(MDE_BLOCK), 0, st, n, mean, M, Z);             \
@@ -1089,6 +1199,19 @@ extern "C" int mde_std_retract(int64_t n, int32_t d, float* Z, int32_t demean, d
   rc = invsqrt_impl(d, C, sqrt((double)n), M, scratch, status_dev, st);
   if (rc != MDE_OK) return rc;
   return rmul_impl(n, d, d, Z, M, 1.0f, nullptr, Z, st);
+}
+
+extern "C" int mde_std_retract(int64_t n, int32_t d, float* Z, int32_t demean, double* work,
+                               int32_t* status_dev, void* stream) {
+  if (n <= 0 || d <= 0 || d > 2048 || !Z || !work) return MDE_E_INVALID;
+  return std_retract_impl(n, d, Z, demean, work, status_dev, mde_stream(stream));
+}
+
+// Z <- retract(X + t dir): the trial point of the line search under the Standardized constraint
+extern "C" int mde_std_retract_step(int64_t n, int32_t d, const float* X, const float* dir, float t, float* Z,
+                                    int32_t demean, double* work, int32_t* status_dev, void* stream) {
+  if (n <= 0 || d <= 0 || d > 2048 || !X || !dir || !Z || !work) return MDE_E_INVALID;
+  return std_retract_impl(n, d, Z, demean, work, status_dev, mde_stream(stream), X, dir, t);
 }
 
 // ---------------------------------------------------------------- L-BFGS memory

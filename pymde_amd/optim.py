@@ -200,7 +200,32 @@ class _NativeProblem(object):
             _lib.check(lib.mde_anchor_rows(self.anchors.numel(), e.d, _lib.ptr(self.anchors),
                                            _lib.ptr(self.values), _lib.ptr(X), e.stream()))
 
-    def value_and_grad(self, X):
+    def retract_step(self, t, out):
+        """out <- retraction(X + t dir): the line search's trial point, the step folded into the
+        retraction's first pass where the library can."""
+        e, lib = self.e, self.e.lib
+        if self.kind == "centered":
+            _lib.check(lib.mde_center_step(e.n, e.d, _lib.ptr(e.X), _lib.ptr(e.dir), float(t), _lib.ptr(out),
+                                           _lib.ptr(e.work), e.stream()))
+        elif self.kind == "standardized":
+            _lib.check(lib.mde_std_retract_step(e.n, e.d, _lib.ptr(e.X), _lib.ptr(e.dir), float(t), _lib.ptr(out), 1,
+                                                _lib.ptr(e.work), _lib.ptr(e.status), e.stream()))
+        else:
+            e.axpy(t, e.dir, e.X, out)
+            self.retract(out)
+
+    def value_grad_stats(self, X):
+        """value_and_grad(X) followed by the statistics of (g, dir, X) on the board."""
+        e, lib = self.e, self.e.lib
+        if self.kind == "standardized":
+            self.value_and_grad(X, project=False)
+            _lib.check(lib.mde_std_tangent_stats(e.n, e.d, _lib.ptr(X), _lib.ptr(e.g), _lib.ptr(e.dir),
+                                                 _lib.ptr(e.board), _lib.ptr(e.work), e.stream()))
+        else:
+            self.value_and_grad(X)
+            e.stats(e.g, e.dir, X)
+
+    def value_and_grad(self, X, project=True):
         from pymde_amd import average_distortion as ad
         e, lib = self.e, self.e.lib
         if self.reducer is not None and getattr(self.reducer, "needs_zero", lambda: True)():
@@ -216,8 +241,9 @@ class _NativeProblem(object):
         if self.reducer is not None:
             self.reducer(e.gbuf)
         if self.kind == "standardized":
-            _lib.check(lib.mde_std_tangent(e.n, e.d, _lib.ptr(X), _lib.ptr(e.g), _lib.ptr(e.work),
-                                           e.stream()))
+            if project:
+                _lib.check(lib.mde_std_tangent(e.n, e.d, _lib.ptr(X), _lib.ptr(e.g), _lib.ptr(e.work),
+                                               e.stream()))
         elif self.kind == "anchored":
             _lib.check(lib.mde_anchor_rows(self.anchors.numel(), e.d, _lib.ptr(self.anchors), None,
                                            _lib.ptr(e.g), e.stream()))
@@ -241,6 +267,14 @@ class _GenericProblem(object):
     def retract(self, X):
         with torch.no_grad():
             self.constraint.project_onto_constraint(X, inplace=True)
+
+    def retract_step(self, t, out):
+        self.e.axpy(t, self.e.dir, self.e.X, out)
+        self.retract(out)
+
+    def value_grad_stats(self, X):
+        self.value_and_grad(X)
+        self.e.stats(self.e.g, self.e.dir, X)
 
     def value_and_grad(self, X):
         e = self.e
@@ -341,6 +375,29 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
         vals, loss = e.read_board(8)
         return loss, vals
 
+    last_eval = {"t": None}
+
+    def enqueue_trial(tt):
+        problem.retract_step(tt, e.X_trial)
+        problem.value_grad_stats(e.X_trial)
+
+    def finish_trial(tt, extra=0):
+        v, f = e.finish_read(8 + extra)
+        last_eval["t"] = tt
+        last_eval["gg"] = v[_GG]
+        last_eval["xx"] = v[_XX]
+        return (f, v[_GD], v[_NONFINITE] == 0), v
+
+    def phi(tt, extra=0):
+        enqueue_trial(tt)
+        e.enqueue_read(8 + extra)
+        return finish_trial(tt, extra)
+
+    # The next iteration's direction update and first trial (t = 1) are enqueued as soon as the line
+    # search has accepted a point -- before this iteration's bookkeeping, which then runs while the GPU
+    # works (the iteration is a chain of ~10 short kernels behind ~40 us of Python).
+    ahead = False
+
     for iteration in range(max_iter):
         if snapshot_every is not None and iteration % snapshot_every == 0:
             snapshots.append(e.X.detach().cpu().clone())
@@ -370,36 +427,22 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
             gtd, d_norm2, d_max = vals[_GD], math.sqrt(vals[_DD]), vals[_DMAX]
             g1 = vals[_G1]
             t = min(1.0, 1.0 / g1) if g1 > 0 else 1.0   # initial step (lbfgs.py:521-524), lr = 1
-        last_eval = {"t": None}
-
-        def enqueue_trial(tt):
-            e.axpy(tt, e.dir, e.X, e.X_trial)
-            problem.retract(e.X_trial)
-            problem.value_and_grad(e.X_trial)
-            e.stats(e.g, e.dir, e.X_trial)
-
-        def finish_trial(tt, extra=0):
-            v, f = e.finish_read(8 + extra)
-            last_eval["t"] = tt
-            last_eval["gg"] = v[_GG]
-            last_eval["xx"] = v[_XX]
-            return (f, v[_GD], v[_NONFINITE] == 0), v
-
-        def phi(tt, extra=0):
-            enqueue_trial(tt)
-            e.enqueue_read(8 + extra)
-            return finish_trial(tt, extra)
+        last_eval["t"] = None
 
         if n_iter > 1:
             # the first trial point is enqueued before the direction statistics are known; both
             # come back in one read
             t_prev, t = t, 1.0
-            e.update_direction(t_prev)
-            if use_line_search:
-                first, v = phi(t, extra=_DIR)
+            if ahead:
+                first, v = finish_trial(t, extra=_DIR)   # (enqueued at the end of the last iteration)
             else:
-                first = None
-                v, _ = e.read_board(_DIR + 8)
+                e.update_direction(t_prev)
+                if use_line_search:
+                    first, v = phi(t, extra=_DIR)
+                else:
+                    first = None
+                    v, _ = e.read_board(_DIR + 8)
+            ahead = False
             dv = v[_DIR:_DIR + 8]
             gtd, d_norm2, d_max = dv[_GD], math.sqrt(dv[_DD]), dv[_DMAX]
         else:
@@ -427,11 +470,17 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
             e.X, e.X_trial = e.X_trial, e.X
             new_xx = last_eval["xx"]
         else:
-            e.axpy(t, e.dir, e.X, e.X_trial)
-            problem.retract(e.X_trial)
+            problem.retract_step(t, e.X_trial)
             e.X, e.X_trial = e.X_trial, e.X
             new_xx = None
         problem.check_status()
+        norm_grad = grad_norms[-1]
+        if (use_line_search and use_cached_loss and t != 0 and norm_grad > eps and iteration + 1 < max_iter
+                and not (snapshot_every is not None and (iteration + 1) % snapshot_every == 0)):
+            e.update_direction(t)
+            enqueue_trial(1.0)
+            e.enqueue_read(8 + _DIR)
+            ahead = True
 
         times.append(time.time() - start)
         h = t
@@ -439,7 +488,6 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
         step_size_percents.append(float(percent_change))
         norm_X = math.sqrt(new_xx) if new_xx is not None else None
 
-        norm_grad = grad_norms[-1]
         if verbose and ((iteration % print_every == 0) or (iteration == max_iter - 1)):
             logger.info(
                 "iteration %0*d | distortion %6f | residual norm %g | "

@@ -379,3 +379,54 @@ def test_solve_is_bitwise_reproducible(cname):
     assert se.residual_norms == sg.residual_norms
     assert se.step_size_percents == sg.step_size_percents
     assert all(torch.equal(a, b) for a, b in zip(se.snapshots, sg.snapshots))
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 8])
+def test_fused_trial_point_and_projection_entry_points(d):
+    """mde_center_step / mde_std_retract_step (the step X + t dir folded into the retraction) and
+    mde_std_tangent_stats (statistics folded into the tangent projection) against the calls they
+    replace: mde_axpy + mde_center / mde_std_retract bit for bit, mde_std_tangent bit for bit and
+    mde_vec_stats to rounding (same doubles, another order of additions)."""
+    from pymde_amd import _lib, util
+    lib = _lib.load()
+    dev = torch.device(DEV)
+    st = _lib.stream_ptr(dev)
+    torch.manual_seed(d)
+    n = 30011
+    X = torch.randn(n, d, device=dev)
+    dirv = torch.randn(n, d, device=dev) * 0.1
+    t = 0.37
+    work = util.work_buffer(dev, d)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    # Centered
+    want = torch.empty_like(X)
+    _lib.check(lib.mde_axpy(n * d, t, _lib.ptr(dirv), _lib.ptr(X), _lib.ptr(want), st))
+    _lib.check(lib.mde_center(n, d, _lib.ptr(want), _lib.ptr(work), st))
+    got = torch.empty_like(X)
+    _lib.check(lib.mde_center_step(n, d, _lib.ptr(X), _lib.ptr(dirv), t, _lib.ptr(got), _lib.ptr(work), st))
+    assert torch.equal(got, want)
+    # Standardized retraction
+    want = torch.empty_like(X)
+    _lib.check(lib.mde_axpy(n * d, t, _lib.ptr(dirv), _lib.ptr(X), _lib.ptr(want), st))
+    _lib.check(lib.mde_std_retract(n, d, _lib.ptr(want), 1, _lib.ptr(work), _lib.ptr(status), st))
+    got = torch.empty_like(X)
+    _lib.check(lib.mde_std_retract_step(n, d, _lib.ptr(X), _lib.ptr(dirv), t, _lib.ptr(got), 1, _lib.ptr(work),
+                                        _lib.ptr(status), st))
+    assert torch.equal(got, want) and int(status[0]) == 0
+    # tangent projection + statistics
+    Xs = want                                   # a point on the constraint set
+    G = torch.randn(n, d, device=dev)
+    g_want = G.clone()
+    b_want = torch.zeros(64, dtype=torch.float64, device=dev)
+    _lib.check(lib.mde_std_tangent(n, d, _lib.ptr(Xs), _lib.ptr(g_want), _lib.ptr(work), st))
+    _lib.check(lib.mde_vec_stats(n * d, _lib.ptr(g_want), _lib.ptr(dirv), _lib.ptr(Xs), _lib.ptr(b_want),
+                                 _lib.ptr(work), st))
+    for with_dir in (True, False):
+        g_got = G.clone()
+        b_got = torch.zeros(64, dtype=torch.float64, device=dev)
+        _lib.check(lib.mde_std_tangent_stats(n, d, _lib.ptr(Xs), _lib.ptr(g_got), _lib.ptr(dirv) if with_dir else None,
+                                             _lib.ptr(b_got), _lib.ptr(work), st))
+        assert torch.equal(g_got, g_want)
+        rows = range(8) if with_dir else (1, 2, 3, 4, 7)
+        for q in rows:
+            assert float(b_got[q]) == pytest.approx(float(b_want[q]), rel=1e-12, abs=1e-300), q
