@@ -1810,7 +1810,7 @@ __global__ __launch_bounds__(64) void k_lbfgs_direction(LbDev* __restrict__ dv, 
 
 // ---- the same step in ONE launch, for vectors small enough that launches, not bytes, are what an
 // iteration costs (configs 2 and 3: N = 140k / 80k floats; every kernel boundary is ~5 us on this
-// stack and the four launches below took 60 us of a 150 us iteration).  At most 512 workgroups, all
+// stack and the four launches below took 60 us of a 150 us iteration).  At most 128 workgroups, all
 // resident at once, in phases separated by a grid-wide arrival counter:
 //   1. stage the new pair and form the partial dot products of the workgroup's own elements;
 //   -- every workgroup has published its partials (relaxed device-scope stores, as mde_last_block) --
@@ -1821,7 +1821,7 @@ __global__ __launch_bounds__(64) void k_lbfgs_direction(LbDev* __restrict__ dv, 
 //      itself in phase 1), publish the statistics partials; the last workgroup to arrive reduces
 //      them and writes the bookkeeping back to LbDev (everyone has finished reading it by then).
 #define MDE_LB_FUSED_LD 16       // history <= 15
-#define MDE_LB_FUSED_MAXN (1 << 18)  // <= 512 workgroups of 4 waves: resident together with room to spare
+#define MDE_LB_FUSED_MAXN (1 << 18)
 #define MDE_LB_FUSED_MAXBLOCKS 512
 // the flag words of the fused kernel: doubles [2304, 3072) of the work buffer's small area (nothing
 // else is kept there; zero or an older epoch between launches)
@@ -2025,7 +2025,11 @@ extern "C" int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, c
   const int64_t N = o->N;
   double* partial = work + MDE_SMALL_DOUBLES;
   if (N <= MDE_LB_FUSED_MAXN && o->history < MDE_LB_FUSED_LD && !getenv("MDE_LB_UNFUSED")) {
-    const int nbf = mde_grid(N, MDE_BLOCK * 2, 1024);  // (the grid of the four-launch form: same partials, same sums)
+    // At most 128 workgroups: the arrival points need every workgroup of the launch resident at once.
+    // The kernel fits two workgroups per CU (198 VGPRs), i.e. 512 on the chip -- 128 leaves room for
+    // whatever else is resident, e.g. the same kernel of other processes sharing the GPU (two ranks of
+    // a test on one device: 469 workgroups each deadlocked until the spin limit).
+    const int nbf = mde_grid(N, MDE_BLOCK * 2, 128);
     static std::atomic<unsigned int> launches{0};  // one epoch per launch, shared by every solver object
     const unsigned int epoch = 4u * (launches.fetch_add(1u) + 1u);
     hipLaunchKernelGGL(k_lb_fused, dim3(nbf), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t, o->buf, o->dev, o->history,

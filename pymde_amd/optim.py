@@ -93,6 +93,8 @@ class _Engine(object):
         self.work = util.work_buffer(dev, self.d)
         util.reset_work_tickets(self.work)
         self.board = self.gtail[self._board_off:].view(torch.float64)
+        self._ptrs = {}
+        self._dir_board = None
         self.status = self.gtail[self.N + 1:self.N + 2].view(torch.int32)
         # pinned mirror of [loss | status | pad | board]
         head = self._board_off - self.N                        # floats before the board (2 or 3)
@@ -102,6 +104,11 @@ class _Engine(object):
         self.host = self.host_raw[b0 + head:].view(torch.float64)
         self.host_loss = self.host_raw[b0:b0 + 1]
         self.host_status = self.host_raw[b0 + 1:b0 + 2].view(torch.int32)
+        # numpy views of the pinned mirror (a tensor index costs microseconds, and the read-back sits
+        # on the critical path of every iteration)
+        self._host_np = self.host.numpy()
+        self._host_loss_np = self.host_loss.numpy()
+        self._host_status_np = self.host_status.numpy()
         self._host_ptr = ctypes.c_void_p(self.host_raw.data_ptr() + 4 * b0)
         self._tail_ptr = ctypes.c_void_p(self.gtail.data_ptr() + 4 * self.N)
         # the solve runs on the stream that is current now; its handle is looked up once
@@ -126,14 +133,24 @@ class _Engine(object):
     def stream(self):
         return self._stream
 
+    def p(self, t):
+        """Device pointer of one of the engine's long-lived tensors (cached per tensor object)."""
+        key = id(t)
+        hit = self._ptrs.get(key)
+        if hit is None or hit[0] is not t:
+            hit = (t, ctypes.c_void_p(t.data_ptr()))
+            self._ptrs[key] = hit
+        return hit[1]
+
     # ---- vector kernels
     def axpy(self, alpha, x, y, out):
         _lib.check(self.lib.mde_axpy(self.N, float(alpha), _lib.ptr(x), _lib.ptr(y), _lib.ptr(out),
                                      self.stream()))
 
     def stats(self, g, d, x):
-        _lib.check(self.lib.mde_vec_stats(self.N, _lib.ptr(g), _lib.ptr(d), _lib.ptr(x),
-                                          _lib.ptr(self.board), _lib.ptr(self.work), self.stream()))
+        _lib.check(self.lib.mde_vec_stats(self.N, self.p(g), None if d is None else self.p(d),
+                                          None if x is None else self.p(x), self.p(self.board), self.p(self.work),
+                                          self._stream))
 
     def enqueue_read(self, count):
         """Enqueue the device->host copy of [loss | status | first ``count`` doubles of the board]
@@ -143,8 +160,8 @@ class _Engine(object):
 
     def finish_read(self, count):
         self._stream_obj.synchronize()  # (polling hipStreamQuery from C instead measured the same)
-        vals = self.host[:count].numpy().copy()
-        return vals, float(self.host_loss[0])
+        vals = self._host_np[:count].copy()
+        return vals, float(self._host_loss_np[0])
 
     def read_board(self, count):
         """One device->host read-back of the first ``count`` doubles plus the loss."""
@@ -161,10 +178,11 @@ class _Engine(object):
         (g, d) are left in the second half of the board (``_DIR`` doubles in): they are not needed
         before the first trial evaluation of the line search has been enqueued, so they travel
         with its read-back."""
-        dir_board = ctypes.c_void_p(self.board.data_ptr() + 8 * _DIR)
-        _lib.check(self.lib.mde_lbfgs_dev_step(self.lbfgs, _lib.ptr(self.g), _lib.ptr(self.g_prev),
-                                               _lib.ptr(self.dir), float(t_prev), _lib.ptr(self.dir),
-                                               dir_board, _lib.ptr(self.work), self.stream()))
+        if self._dir_board is None:
+            self._dir_board = ctypes.c_void_p(self.board.data_ptr() + 8 * _DIR)
+        _lib.check(self.lib.mde_lbfgs_dev_step(self.lbfgs, self.p(self.g), self.p(self.g_prev),
+                                               self.p(self.dir), float(t_prev), self.p(self.dir),
+                                               self._dir_board, self.p(self.work), self._stream))
 
 
 class _NativeProblem(object):
@@ -179,6 +197,8 @@ class _NativeProblem(object):
         self.reducer = reducer  # multi-GPU: all-reduce of [grad | loss]
         # the function's parameters are fixed for the duration of a solve: bind them once
         self.fstruct = binding.struct(engine.d) if binding.fused else None
+        self._fref = ctypes.byref(self.fstruct) if binding.fused else None
+        self._plan_handle = binding.plan.handle if binding.fused else None
         if isinstance(constraint, _constraints._Standardized):
             self.kind = "standardized"
         elif isinstance(constraint, _constraints._Centered):
@@ -205,11 +225,10 @@ class _NativeProblem(object):
         retraction's first pass where the library can."""
         e, lib = self.e, self.e.lib
         if self.kind == "centered":
-            _lib.check(lib.mde_center_step(e.n, e.d, _lib.ptr(e.X), _lib.ptr(e.dir), float(t), _lib.ptr(out),
-                                           _lib.ptr(e.work), e.stream()))
+            _lib.check(lib.mde_center_step(e.n, e.d, e.p(e.X), e.p(e.dir), float(t), e.p(out), e.p(e.work), e._stream))
         elif self.kind == "standardized":
-            _lib.check(lib.mde_std_retract_step(e.n, e.d, _lib.ptr(e.X), _lib.ptr(e.dir), float(t), _lib.ptr(out), 1,
-                                                _lib.ptr(e.work), _lib.ptr(e.status), e.stream()))
+            _lib.check(lib.mde_std_retract_step(e.n, e.d, e.p(e.X), e.p(e.dir), float(t), e.p(out), 1, e.p(e.work),
+                                                e.p(e.status), e._stream))
         else:
             e.axpy(t, e.dir, e.X, out)
             self.retract(out)
@@ -219,8 +238,8 @@ class _NativeProblem(object):
         e, lib = self.e, self.e.lib
         if self.kind == "standardized":
             self.value_and_grad(X, project=False)
-            _lib.check(lib.mde_std_tangent_stats(e.n, e.d, _lib.ptr(X), _lib.ptr(e.g), _lib.ptr(e.dir),
-                                                 _lib.ptr(e.board), _lib.ptr(e.work), e.stream()))
+            _lib.check(lib.mde_std_tangent_stats(e.n, e.d, e.p(X), e.p(e.g), e.p(e.dir), e.p(e.board), e.p(e.work),
+                                                 e._stream))
         else:
             self.value_and_grad(X)
             e.stats(e.g, e.dir, X)
@@ -232,8 +251,7 @@ class _NativeProblem(object):
             e.gbuf.zero_()  # (an all-gather exchange overwrites the other ranks' rows instead)
         if self.binding.fused:
             _lib.check(lib.mde_average_distortion(
-                self.binding.plan.handle, _lib.ptr(X), e.d, ctypes.byref(self.fstruct), 1.0,
-                _lib.ptr(e.g), _lib.ptr(e.loss_dev), e.stream()))
+                self._plan_handle, e.p(X), e.d, self._fref, 1.0, e.p(e.g), e.p(e.loss_dev), e._stream))
         else:
             grad, value = ad._unfused(self.binding, X, True)
             e.g.copy_(grad)
@@ -250,7 +268,7 @@ class _NativeProblem(object):
 
     def check_status(self):
         # the status word travels with every read-back of the statistics board
-        if self.kind == "standardized" and int(self.e.host_status[0]) != 0:
+        if self.kind == "standardized" and int(self.e._host_status_np[0]) != 0:
             raise util.SolverError("Standardized retraction failed: X^T X is singular")
 
 
