@@ -155,7 +155,8 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_flat(
       const int64_t h = base + u * 64 + lane;
       ok[u] = h >= 0 && h < H;
       const int64_t hc = ok[u] ? h : 0;
-      row[u] = ok[u] ? hrow[hc] : -1;
+      const int rr = hrow[hc];  // (hc is in range either way: a plain load, the select afterwards)
+      row[u] = ok[u] ? rr : -1;
       un[u] = nbr[hc];
       p1[u] = a1s;
       if constexpr (INDIRECT) {
@@ -445,6 +446,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4(
   const float a0s = a0_scalar ? a0[0] : 0.0f;
   const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
   const wide_f4 zero = {0.f, 0.f, 0.f, 0.f};
+  const bool full = d4 == GL * K4;
 
   for (int r = wave; r < nrows; r += nwaves) {
     const int beg = rowptr[r], end = rowptr[r + 1];
@@ -492,13 +494,22 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4(
         p1[q] = p1_n[q];
       }
       wide_f4 xu[U][K4];
+      if (full) {
+        // (every lane has a column: plain loads -- a predicated load is a branch around it, and the
+        // gathers of a step then go out one after the other)
 #pragma unroll
-      for (int q = 0; q < U; ++q)
+        for (int q = 0; q < U; ++q)
 #pragma unroll
-        for (int j = 0; j < K4; ++j) {
-          const int c = lig + j * GL;
-          xu[q][j] = (c < d4) ? X4[u[q] * d4 + c] : zero;
-        }
+          for (int j = 0; j < K4; ++j) xu[q][j] = X4[u[q] * d4 + lig + j * GL];
+      } else {
+#pragma unroll
+        for (int q = 0; q < U; ++q)
+#pragma unroll
+          for (int j = 0; j < K4; ++j) {
+            const int c = lig + j * GL;
+            xu[q][j] = (c < d4) ? X4[u[q] * d4 + c] : zero;
+          }
+      }
       if (h0 + E * U < end) load_meta(h0 + E * U);
 #pragma unroll
       for (int q = 0; q < U; ++q) {

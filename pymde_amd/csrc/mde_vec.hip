@@ -153,8 +153,8 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_vec_stats(int64_t N, const float*
       xx += xv * xv;
     }
   };
-  // 16-byte loads, two per array in flight per thread (256 MB vectors at d = 128: the 4-byte form ran
-  // at 0.7 TB/s); each thread keeps its own fixed subsequence, so the sums do not depend on timing
+  // 16-byte loads (256 MB vectors at d = 128: the 4-byte form ran at 0.7 TB/s); each thread keeps its
+  // own fixed subsequence, so the sums do not depend on timing
   const bool vec = ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(d ? d : g) |
                      reinterpret_cast<uintptr_t>(x ? x : g)) & 15) == 0;
   const int64_t N4 = vec ? (N >> 2) : 0;
@@ -163,16 +163,33 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_vec_stats(int64_t N, const float*
   const float4* x4 = reinterpret_cast<const float4*>(x);
   const int64_t stride = (int64_t)gridDim.x * MDE_BLOCK;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N4; i += 2 * stride) {
-    const int64_t i2 = i + stride;
-    const bool two = i2 < N4;
-    const float4 ga = g4[i], gb = two ? g4[i2] : z4;
-    const float4 da = d ? d4[i] : z4, db = (d && two) ? d4[i2] : z4;
-    const float4 xa = x ? x4[i] : z4, xb = (x && two) ? x4[i2] : z4;
-    one(ga.x, da.x, xa.x); one(ga.y, da.y, xa.y); one(ga.z, da.z, xa.z); one(ga.w, da.w, xa.w);
-    if (two) {
-      one(gb.x, db.x, xb.x); one(gb.y, db.y, xb.y); one(gb.z, db.z, xb.z); one(gb.w, db.w, xb.w);
+  // four 16-byte loads per array in flight per thread, unpredicated in the main loop (a predicated
+  // load is a branch: the loads of a trip then go out one memory latency after the other)
+  int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x;
+  if (d && x) {
+    for (; i + 3 * stride < N4; i += 4 * stride) {
+      float4 ga[4], da[4], xa[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        ga[u] = g4[i + u * stride];
+        da[u] = d4[i + u * stride];
+        xa[u] = x4[i + u * stride];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        one(ga[u].x, da[u].x, xa[u].x);
+        one(ga[u].y, da[u].y, xa[u].y);
+        one(ga[u].z, da[u].z, xa[u].z);
+        one(ga[u].w, da[u].w, xa[u].w);
+      }
     }
+  }
+  for (; i < N4; i += stride) {
+    const float4 ga = g4[i], da = d ? d4[i] : z4, xa = x ? x4[i] : z4;
+    one(ga.x, da.x, xa.x);
+    one(ga.y, da.y, xa.y);
+    one(ga.z, da.z, xa.z);
+    one(ga.w, da.w, xa.w);
   }
   for (int64_t i = (N4 << 2) + (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N; i += stride)
     one(g[i], d ? d[i] : 0.0f, x ? x[i] : 0.0f);
