@@ -1485,33 +1485,36 @@ __device__ __forceinline__ double lb_transpose_sum(const double (&val)[NV]) {
 // MDE_BLOCK): the new pair y = g - g_prev, s = t d is written to the spare slot, g_prev <- g, and the
 // workgroup's share of every dot product the history update needs goes to partial[row * nb + b]
 // (rows 0..3: y*.s*, y*.y*, s*.g, y*.g; 4 + 5 j + k: pair j: s_j.y*, y_j.y*, s*.y_j, s_j.g, y_j.g),
-// eight stored pairs per pass.  PUBLISH: relaxed device-scope stores (read again inside the launch).
-template <bool PUBLISH>
+// G stored pairs per pass (8; 12 when the history is 9..12 pairs: one pass instead of two, whose second
+// would read the vectors again for the last few pairs).  PUBLISH: relaxed device-scope stores (read again
+// inside the launch).
+template <bool PUBLISH, int G = MDE_LB_GROUP>
 __device__ __forceinline__ void lb_stage_phase(int64_t N, const float* __restrict__ g, float* __restrict__ g_prev,
                                                const float* __restrict__ d, float t, float* __restrict__ buf,
                                                const LbDev* __restrict__ dv, double* __restrict__ partial,
-                                               double (*sm)[MDE_LB_NVAL]) {
+                                               double (*sm)[4 + 5 * G]) {
+  constexpr int NVAL = 4 + 5 * G;
   const int count = dv->count;
   const int spare = dv->order[count];
   float* s_new = buf + (int64_t)(2 * spare) * N;
   float* y_new = buf + (int64_t)(2 * spare + 1) * N;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int nb = gridDim.x, b = blockIdx.x;
-  for (int done = 0; done == 0 || done < count; done += MDE_LB_GROUP) {
+  for (int done = 0; done == 0 || done < count; done += G) {
     const bool first = done == 0;
     int pc = count - done;
-    if (pc > MDE_LB_GROUP) pc = MDE_LB_GROUP;
-    const float* ps[MDE_LB_GROUP];
-    const float* py[MDE_LB_GROUP];
+    if (pc > G) pc = G;
+    const float* ps[G];
+    const float* py[G];
 #pragma unroll
-    for (int j = 0; j < MDE_LB_GROUP; ++j) {
+    for (int j = 0; j < G; ++j) {
       const int slot = (j < pc) ? dv->order[done + j] : spare;
       ps[j] = buf + (int64_t)(2 * slot) * N;
       py[j] = buf + (int64_t)(2 * slot + 1) * N;
     }
-    double val[MDE_LB_NVAL];
+    double val[NVAL];
 #pragma unroll
-    for (int q = 0; q < MDE_LB_NVAL; ++q) val[q] = 0.0;
+    for (int q = 0; q < NVAL; ++q) val[q] = 0.0;
     for (int64_t i = (int64_t)b * MDE_BLOCK + threadIdx.x; i < N; i += (int64_t)nb * MDE_BLOCK) {
       const float gv = g[i];
       float yv, sv;
@@ -1531,14 +1534,14 @@ __device__ __forceinline__ void lb_stage_phase(int64_t N, const float* __restric
       }
       // all sixteen loads before the first use (slots beyond pc alias the spare pair: valid memory,
       // their sums are never written) -- a branch per pair would serialise sixteen memory latencies
-      float sj[MDE_LB_GROUP], yj[MDE_LB_GROUP];
+      float sj[G], yj[G];
 #pragma unroll
-      for (int j = 0; j < MDE_LB_GROUP; ++j) {
+      for (int j = 0; j < G; ++j) {
         sj[j] = ps[j][i];
         yj[j] = py[j][i];
       }
 #pragma unroll
-      for (int j = 0; j < MDE_LB_GROUP; ++j) {
+      for (int j = 0; j < G; ++j) {
         const double sd = sj[j], yd = yj[j];
         val[4 + 5 * j + 0] = fma(sd, (double)yv, val[4 + 5 * j + 0]);  // s_j . y*
         val[4 + 5 * j + 1] = fma(yd, (double)yv, val[4 + 5 * j + 1]);  // y_j . y*
@@ -1549,8 +1552,8 @@ __device__ __forceinline__ void lb_stage_phase(int64_t N, const float* __restric
     }
     // lane q holds the wave's total of value q -> LDS -> thread q adds the four waves
     const int nval = 4 + 5 * pc;
-    const double tot = lb_transpose_sum<MDE_LB_NVAL>(val);
-    if (lane < MDE_LB_NVAL) sm[wave][lane] = tot;
+    const double tot = lb_transpose_sum<NVAL>(val);
+    if (lane < NVAL) sm[wave][lane] = tot;
     __syncthreads();
     if ((int)threadIdx.x < nval && (first || threadIdx.x >= 4)) {
       const int q = threadIdx.x;
@@ -1944,14 +1947,15 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* 
 // (3) k_lbfgs_direction (above).
 // (4) k_lb_combine_all: d_out from all pairs, its statistics against g in the same pass, reduced by
 //     the last workgroup (what mde_vec_stats(g, d_out, NULL) writes).
+template <int G>
 __global__ __launch_bounds__(MDE_BLOCK) void k_lb_stage_all(int64_t N, const float* __restrict__ g,
                                                             float* __restrict__ g_prev,
                                                             const float* __restrict__ d, float t,
                                                             float* __restrict__ buf,
                                                             const LbDev* __restrict__ dv,
                                                             double* __restrict__ partial) {
-  __shared__ double sm[MDE_BLOCK / 64][MDE_LB_NVAL];
-  lb_stage_phase<false>(N, g, g_prev, d, t, buf, dv, partial, sm);
+  __shared__ double sm[MDE_BLOCK / 64][4 + 5 * G];
+  lb_stage_phase<false, G>(N, g, g_prev, d, t, buf, dv, partial, sm);
 }
 
 // dots[q] = sum_b partial[q * nb + b] for the 4 + 5 count rows that were written (one workgroup per
@@ -1988,7 +1992,51 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_combine_all(int64_t N, const f
   }
   __syncthreads();
   double gd = 0, gg = 0, g1 = 0, gm = 0, nf = 0, dd = 0, dm = 0;
-  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N;
+  auto tally = [&](float gv, float v) __attribute__((always_inline)) {
+    const double gvd = gv, dv2 = v;
+    gg += gvd * gvd;
+    const double ag = fabs(gvd);
+    g1 += ag;
+    gm = ag > gm ? ag : gm;
+    nf += (fabsf(gv) <= 3.402823466e+38f) ? 0.0 : 1.0;
+    gd += gvd * dv2;
+    dd += dv2 * dv2;
+    const double ad = fabs(dv2);
+    dm = ad > dm ? ad : dm;
+  };
+  // 16-byte form (N a multiple of 4, 16-byte aligned vectors -- every history slot then is too): four
+  // times the bytes per load instruction; 256 MB vectors: 3.8 -> TB/s measured in profiles/
+  const bool vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(buf) |
+                                     reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+  const int64_t N4 = vec ? (N >> 2) : 0;
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N4; i += (int64_t)gridDim.x * MDE_BLOCK) {
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 v = make_float4(c_g * gv.x, c_g * gv.y, c_g * gv.z, c_g * gv.w);
+    for (int j0 = 0; j0 < count; j0 += MDE_LB_GROUP) {
+      float4 sv[MDE_LB_GROUP], yv[MDE_LB_GROUP];
+#pragma unroll
+      for (int j = 0; j < MDE_LB_GROUP; ++j) {
+        const float4* sp = reinterpret_cast<const float4*>(buf + (int64_t)(2 * s_slot[j0 + j]) * N);
+        sv[j] = sp[i];
+        yv[j] = sp[N4 + i];
+      }
+#pragma unroll
+      for (int j = 0; j < MDE_LB_GROUP; ++j)
+        if (j0 + j < count) {
+          const float cs = s_cs[j0 + j], cy = s_cy[j0 + j];
+          v.x = fmaf(cy, yv[j].x, fmaf(cs, sv[j].x, v.x));
+          v.y = fmaf(cy, yv[j].y, fmaf(cs, sv[j].y, v.y));
+          v.z = fmaf(cy, yv[j].z, fmaf(cs, sv[j].z, v.z));
+          v.w = fmaf(cy, yv[j].w, fmaf(cs, sv[j].w, v.w));
+        }
+    }
+    reinterpret_cast<float4*>(out)[i] = v;
+    tally(gv.x, v.x);
+    tally(gv.y, v.y);
+    tally(gv.z, v.z);
+    tally(gv.w, v.w);
+  }
+  for (int64_t i = (N4 << 2) + (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N;
        i += (int64_t)gridDim.x * MDE_BLOCK) {
     const float gv = g[i];
     float v = c_g * gv;
@@ -2006,16 +2054,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_combine_all(int64_t N, const f
         if (j0 + j < count) v = fmaf(s_cy[j0 + j], yv[j], fmaf(s_cs[j0 + j], sv[j], v));
     }
     out[i] = v;
-    const double gvd = gv, dv2 = v;
-    gg += gvd * gvd;
-    const double ag = fabs(gvd);
-    g1 += ag;
-    gm = ag > gm ? ag : gm;
-    nf += (fabsf(gv) <= 3.402823466e+38f) ? 0.0 : 1.0;
-    gd += gvd * dv2;
-    dd += dv2 * dv2;
-    const double ad = fabs(dv2);
-    dm = ad > dm ? ad : dm;
+    tally(gv, v);
   }
   const int nb = gridDim.x, b = blockIdx.x;
   const double v8[8] = {gd, gg, g1, gm, nf, dd, dm, 0.0};
@@ -2056,8 +2095,11 @@ extern "C" int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, c
   }
   const int nb = mde_grid(N, MDE_BLOCK * 2, 1024);
   double* dots = work;  // the small area: 4 + 5 * 63 doubles at most
-  hipLaunchKernelGGL(k_lb_stage_all, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t, o->buf, o->dev,
-                     partial);
+  if (o->history > MDE_LB_GROUP && o->history <= 12)
+    hipLaunchKernelGGL(k_lb_stage_all<12>, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t, o->buf, o->dev, partial);
+  else
+    hipLaunchKernelGGL(k_lb_stage_all<MDE_LB_GROUP>, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t, o->buf,
+                       o->dev, partial);
   MDE_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_lb_reduce, dim3(4 + 5 * o->history), dim3(MDE_BLOCK), 0, st, nb, partial, o->dev, dots);
   MDE_LAUNCH_CHECK();

@@ -1,7 +1,7 @@
 # host_floor.py -- seconds per embed() iteration when the GPU work is negligible (tiny problem): what the
 # Python + ctypes + launch + read-back loop costs by itself
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import pymde_amd
 rng = np.random.default_rng(0)
 for cname in ("Standardized", "Centered"):

@@ -1,6 +1,6 @@
 # vecstats_time.py -- mde_vec_stats on config-5-sized vectors (3 x 256 MB): time per call and rate
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from pymde_amd import _lib, util
 lib = _lib.load(); dev = torch.device('cuda'); st = _lib.stream_ptr(dev)
 N = 500000 * 128
