@@ -68,8 +68,13 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_knn(int n, int nf, int k, const f
         const int e = tid + q * MDE_BLOCK;
         const int r = e >> 5, c = e & 31;
         const int gr = row0 + r, gc = col0 + r, f = k0 + c;
-        ra[q] = (gr < n && f < nf) ? X[(int64_t)gr * nf + f] : 0.0f;
-        rb[q] = (gc < n && f < nf) ? X[(int64_t)gc * nf + f] : 0.0f;
+        // plain loads from clamped addresses, zeroed afterwards: a predicated load is a branch around
+        // it and the sixteen loads of a chunk would go out one memory latency after the other
+        const int fc = f < nf ? f : nf - 1;
+        const float va = X[(int64_t)(gr < n ? gr : n - 1) * nf + fc];
+        const float vb = X[(int64_t)(gc < n ? gc : n - 1) * nf + fc];
+        ra[q] = (gr < n && f < nf) ? va : 0.0f;
+        rb[q] = (gc < n && f < nf) ? vb : 0.0f;
       }
     };
     fetch(0);
