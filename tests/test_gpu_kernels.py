@@ -626,6 +626,41 @@ def test_ring_kernel_on_dense_graphs(monkeypatch, d, fname):
     assert_grad_close(Xt.grad.cpu().numpy(), wgrad)
 
 
+def test_ring_kernel_on_dense_graphs_sharded(monkeypatch):
+    """The dense-graph layout (entries ordered by column) on vertex-range shards: every rank's rows
+    against the oracle's, W = 2 and 5 (ragged last shard)."""
+    import pymde_amd
+    from pymde_amd import distributed
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    monkeypatch.setenv("MDE_PANEL", "1")
+    rng = np.random.default_rng(29)
+    n, p, d = 12000, 2_000_000, 2
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    key = np.unique(np.minimum(i, j).astype(np.int64) * n + np.maximum(i, j))
+    edges = np.stack([key // n, key % n], 1)
+    p = len(edges)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    dev = (1.0 + rng.integers(0, 30, p)).astype(np.float32)
+    et = torch.tensor(edges, device=DEV)
+    f = pymde_amd.losses.Huber(torch.tensor(dev, device=DEV), 1.0)
+    Xt = torch.tensor(X, device=DEV)
+    wE, wgrad = oracle.average_distortion(edges, X, oracle.func("L_HUBER", dev, None, (1.0,)))
+    for world in (2, 5):
+        bounds = distributed.shard_bounds(n, et, world)
+        total = torch.zeros(n * d + 1, device=DEV)
+        for r in range(world):
+            lo, hi = distributed.shard_range(bounds, r)
+            buf = torch.zeros(n * d + 1, device=DEV)
+            b = Binding(EdgePlan(n, et, lo, hi), f)
+            fused_evaluate(b, Xt, buf[:n * d].view(n, d), buf[n * d:])
+            assert b.struct(d).layout == 1
+            assert float(buf[:lo * d].abs().sum()) == 0 and float(buf[hi * d:n * d].abs().sum()) == 0
+            total += buf
+        assert float(total[n * d]) == pytest.approx(wE, rel=1e-5), world
+        assert_grad_close(total[:n * d].view(n, d).cpu().numpy(), wgrad)
+
+
 def test_ring_layout_gives_way_on_hub_graphs():
     """Auto layout choice at a size where the LDS-ring kernel would normally run (n d 4 >= 6 MB): a hub
     vertex with half a million half-edges would need one wave iteration per entry (rows are distinct
