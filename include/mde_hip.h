@@ -378,6 +378,43 @@ int mde_lbfgs_dev_info(const mde_lbfgs* o, int32_t* count_host, int32_t* accepte
  * iteration as one HIP graph; measured slower than the launches it replaced, removed in round 3.) */
 int mde_copy_to_host(void* dst_host, const void* src_dev, int64_t bytes, void* stream);
 
+/* ---- one steady-state solver iteration as two calls ----------------------------------------------------
+ * The usual L-BFGS iteration accepts its first trial point (t = 1).  Everything such an iteration launches
+ * -- direction update (mde_lbfgs_dev_step), trial point retraction(X + dir) (mde_center_step /
+ * mde_std_retract_step), objective + gradient (mde_average_distortion), tangent projection + statistics,
+ * the read-back -- is described once by mde_turn_desc; mde_turn_enqueue launches it, and mde_turn_wait
+ * waits for it, applies the strong-Wolfe acceptance test of the first trial [ref: lbfgs.py:44-253, first
+ * pass of the bracketing loop: Armijo with c1 and |g_new.d| <= -c2 g.d] and, when the point is accepted
+ * and the caller allows it, launches the NEXT iteration at once -- the host's bookkeeping then runs while
+ * the GPU works.  A trial that is not accepted is handed back to the caller's line search unchanged.
+ * kind: 0 Centered, 1 Standardized.  X[cur] is the accepted iterate, X[1 - cur] receives the trial. */
+typedef struct mde_turn_desc {
+  mde_plan* plan;
+  const mde_func* func;
+  int64_t n;
+  int32_t d, kind;
+  float* X[2];
+  float* g;        /* n*d floats, followed by the loss word (loss_dev) */
+  float* g_prev;
+  float* dir;
+  float* loss_dev;
+  double* board;   /* statistics board: [0,8) trial statistics, [16,24) direction statistics */
+  double* work;
+  int32_t* status;
+  mde_lbfgs* lbfgs;
+  void* host_dst;            /* pinned mirror of [loss | status | pad | board[0,24)] */
+  const void* tail_src;
+  int64_t read_bytes;
+  const float* host_loss;
+  const int32_t* host_status;
+  const double* host_board;
+} mde_turn_desc;
+int mde_turn_enqueue(const mde_turn_desc* T, int32_t cur, float t_prev, void* stream);
+/* out (>= 24 doubles): [0] f_new, [1] accepted, [2] next iteration enqueued, [3] status word,
+ * [4,12) trial statistics, [12,20) direction statistics.  SYNC (waits for the stream). */
+int mde_turn_wait(const mde_turn_desc* T, int32_t cur, double f0, int32_t allow_next, double c1, double c2,
+                  double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

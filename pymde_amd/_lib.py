@@ -29,6 +29,15 @@ class MdeFunc(ctypes.Structure):
                 ("n0", c_f32), ("n1", c_f32), ("n2", c_f32), ("layout", c_i32)]
 
 
+class MdeTurnDesc(ctypes.Structure):
+    """Mirror of ``struct mde_turn_desc`` (include/mde_hip.h)."""
+    _fields_ = [("plan", c_vp), ("func", c_vp), ("n", c_i64), ("d", c_i32), ("kind", c_i32),
+                ("X", c_vp * 2), ("g", c_vp), ("g_prev", c_vp), ("dir", c_vp), ("loss_dev", c_vp),
+                ("board", c_vp), ("work", c_vp), ("status", c_vp), ("lbfgs", c_vp),
+                ("host_dst", c_vp), ("tail_src", c_vp), ("read_bytes", c_i64),
+                ("host_loss", c_vp), ("host_status", c_vp), ("host_board", c_vp)]
+
+
 # every exported symbol of include/mde_hip.h: name -> (restype, argtypes)
 SYMBOLS = {
     "mde_last_error": (ctypes.c_char_p, []),
@@ -94,6 +103,8 @@ SYMBOLS = {
     "mde_lbfgs_combine": (c_i32, [c_vp, c_vp, c_f32, ctypes.POINTER(c_f32),
                                   ctypes.POINTER(c_f32), c_vp, c_vp, c_vp, c_vp]),
     "mde_copy_to_host": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
+    "mde_turn_enqueue": (c_i32, [c_vp, c_i32, c_f32, c_vp]),
+    "mde_turn_wait": (c_i32, [c_vp, c_i32, ctypes.c_double, c_i32, ctypes.c_double, ctypes.c_double, c_vp, c_vp]),
 }
 
 _lib = None

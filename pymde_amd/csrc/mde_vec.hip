@@ -8,6 +8,7 @@
 #include "mde_common.h"
 
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -124,14 +125,39 @@ __device__ __forceinline__ void mde_publish8(const double (&v)[8], unsigned max_
   }
 }
 
+// ---------------------------------------------------------------- host mirror of the solver's read-back
+// The last kernel of an evaluation can write [loss | status | pad | board[0,24)] straight into the pinned
+// host mirror (device-visible at the same address) instead of a copy being enqueued behind it: one launch
+// (~4 us of a ~0.1 ms iteration) less.  host == nullptr: nothing is written.
+struct MdeMirror {
+  const float* loss_dev;
+  const int32_t* status;
+  const double* board;   // the device board whose first 8 doubles are `stats` of the kernel
+  char* host;
+  int head_bytes;        // bytes of [loss | status | pad] in front of the board
+};
+__device__ __forceinline__ void mde_mirror_write(const MdeMirror& m) {
+  if (!m.host) return;
+  __threadfence_block();
+  __syncthreads();  // the statistics rows written by this block are visible to it
+  double* hb = reinterpret_cast<double*>(m.host + m.head_bytes);
+  if (threadIdx.x < 24) {
+    const volatile double* b = m.board;
+    hb[threadIdx.x] = b[threadIdx.x];
+  }
+  if (threadIdx.x == 32) *reinterpret_cast<float*>(m.host) = *reinterpret_cast<const volatile float*>(m.loss_dev);
+  if (threadIdx.x == 33)
+    *reinterpret_cast<int32_t*>(m.host + 4) = m.status ? *reinterpret_cast<const volatile int32_t*>(m.status) : 0;
+}
+
 // ---------------------------------------------------------------- vector statistics
 // partial[q * nb + b], q: 0 g.d 1 g.g 2 sum|g| 3 max|g| 4 #nonfinite 5 d.d 6 max|d| 7 x.x
 __global__ __launch_bounds__(MDE_BLOCK) void k_vec_stats(int64_t N, const float* __restrict__ g,
                                                          const float* __restrict__ d,
                                                          const float* __restrict__ x,
                                                          double* __restrict__ partial,
-                                                         double* __restrict__ stats,
-                                                         unsigned int* __restrict__ ticket) {
+                                                         double* stats,
+                                                         unsigned int* __restrict__ ticket, MdeMirror mirror) {
   __shared__ double smem[8];
   double gd = 0, gg = 0, g1 = 0, gm = 0, nf = 0, dd = 0, dm = 0, xx = 0;
   auto one = [&](float gv, float dvf, float xvf) __attribute__((always_inline)) {
@@ -199,13 +225,14 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_vec_stats(int64_t N, const float*
   // the last block to arrive reduces the partials (fixed order: independent of arrival order)
   if (!mde_last_block(ticket)) return;
   mde_final_rows(8, nb, partial, stats, (1ull << 3) | (1ull << 6));
+  mde_mirror_write(mirror);
 }
 
 static int vec_stats_impl(int64_t N, const float* g, const float* d, const float* x, double* stats,
-                          double* work, hipStream_t st) {
+                          double* work, hipStream_t st, MdeMirror mirror = MdeMirror{nullptr, nullptr, nullptr, nullptr, 0}) {
   const int nb = mde_grid(N, MDE_BLOCK * 8, MDE_RED_BLOCKS);
   hipLaunchKernelGGL(k_vec_stats, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, d, x, work + MDE_SMALL_DOUBLES, stats,
-                     work_ticket(work, TK_STATS));
+                     work_ticket(work, TK_STATS), mirror);
   MDE_LAUNCH_CHECK();
   return MDE_OK;
 }
@@ -709,7 +736,8 @@ template <int D>
 __global__ __launch_bounds__(MDE_BLOCK) void k_rmul_tiny_stats(int64_t n, const float* __restrict__ X,
                                                                const double* __restrict__ G, float alpha, float* Z,
                                                                const float* __restrict__ dir, double* __restrict__ partial,
-                                                               double* __restrict__ stats, unsigned int* __restrict__ ticket) {
+                                                               double* stats, unsigned int* __restrict__ ticket,
+                                                               MdeMirror mirror) {
   float m[D * D];
 #pragma unroll
   for (int i = 0; i < D * D; ++i) m[i] = (float)(G[i] * (double)alpha);
@@ -747,16 +775,16 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_rmul_tiny_stats(int64_t n, const 
   mde_publish8(v, (1u << 3) | (1u << 6), partial, gridDim.x, blockIdx.x);
   if (!mde_last_block(ticket)) return;
   mde_final_rows(8, gridDim.x, partial, stats, (1ull << 3) | (1ull << 6));
+  mde_mirror_write(mirror);
 }
 
-extern "C" int mde_std_tangent_stats(int64_t n, int32_t d, const float* X, float* Z, const float* dir, double* stats,
-                                     double* work, void* stream) {
-  if (n <= 0 || d <= 0 || d > 2048 || !X || !Z || !stats || !work) return MDE_E_INVALID;
+static int std_tangent_stats_impl(int64_t n, int32_t d, const float* X, float* Z, const float* dir, double* stats,
+                                  double* work, void* stream, MdeMirror mirror) {
   hipStream_t st = mde_stream(stream);
   if (d > 4) {
     const int rc = mde_std_tangent(n, d, X, Z, work, stream);
     if (rc != MDE_OK) return rc;
-    return vec_stats_impl(n * (int64_t)d, Z, dir, X, stats, work, st);
+    return vec_stats_impl(n * (int64_t)d, Z, dir, X, stats, work, st, mirror);
   }
   double* G = work_mats(work);
   const int rc = gram_impl(n, d, d, Z, X, G, work_partials(work, d), work_ticket(work, TK_GRAM), st);
@@ -766,12 +794,18 @@ extern "C" int mde_std_tangent_stats(int64_t n, int32_t d, const float* X, float
 #define TINY(D_)                                                                                                  \
   if (d == D_)                                                                                                    \
     hipLaunchKernelGGL(k_rmul_tiny_stats<D_>, dim3(nb), dim3(MDE_BLOCK), 0, st, n, X, G, alpha, Z, dir,           \
-                       work_partials(work, d), stats, work_ticket(work, TK_STATS));
+                       work_partials(work, d), stats, work_ticket(work, TK_STATS), mirror);
   // (the partials go behind the matrices: G itself is still being read by workgroups that start late)
   TINY(1) TINY(2) TINY(3) TINY(4)
 #undef TINY
   MDE_LAUNCH_CHECK();
   return MDE_OK;
+}
+
+extern "C" int mde_std_tangent_stats(int64_t n, int32_t d, const float* X, float* Z, const float* dir, double* stats,
+                                     double* work, void* stream) {
+  if (n <= 0 || d <= 0 || d > 2048 || !X || !Z || !stats || !work) return MDE_E_INVALID;
+  return std_tangent_stats_impl(n, d, X, Z, dir, stats, work, stream, MdeMirror{nullptr, nullptr, nullptr, nullptr, 0});
 }
 
 // ---------------------------------------------------------------- C^{-1/2} of a small SPD matrix
@@ -2180,4 +2214,53 @@ extern "C" int mde_lbfgs_combine(mde_lbfgs* o, const float* g, float c_g, const 
     done += P.count;
   } while (done < o->count);
   return vec_stats_impl(N, g, d_out, nullptr, stats, work, st);
+}
+
+// ---------------------------------------------------------------- one solver iteration as two calls
+extern "C" int mde_turn_enqueue(const mde_turn_desc* T, int32_t cur, float t_prev, void* stream) {
+  if (!T || (cur != 0 && cur != 1) || (T->kind != 0 && T->kind != 1)) return MDE_E_INVALID;
+  const int64_t N = T->n * (int64_t)T->d;
+  float* Xc = T->X[cur];
+  float* Xt = T->X[1 - cur];
+  int rc = mde_lbfgs_dev_step(T->lbfgs, T->g, T->g_prev, T->dir, t_prev, T->dir, T->board + 16, T->work, stream);
+  if (rc != MDE_OK) return rc;
+  if (T->kind == 0)
+    rc = mde_center_step(T->n, T->d, Xc, T->dir, 1.0f, Xt, T->work, stream);
+  else
+    rc = mde_std_retract_step(T->n, T->d, Xc, T->dir, 1.0f, Xt, 1, T->work, T->status, stream);
+  if (rc != MDE_OK) return rc;
+  rc = mde_average_distortion(T->plan, Xt, T->d, T->func, 1.0f, T->g, T->loss_dev, stream);
+  if (rc != MDE_OK) return rc;
+  // the last kernel writes [loss | status | board] into the pinned mirror itself (no copy behind it)
+  const MdeMirror mirror{T->loss_dev, T->status, T->board, reinterpret_cast<char*>(T->host_dst),
+                         (int)(T->read_bytes - 8 * 24)};
+  if (T->kind == 0)
+    return vec_stats_impl(N, T->g, T->dir, Xt, T->board, T->work, mde_stream(stream), mirror);
+  return std_tangent_stats_impl(T->n, T->d, Xt, T->g, T->dir, T->board, T->work, stream, mirror);
+}
+
+extern "C" int mde_turn_wait(const mde_turn_desc* T, int32_t cur, double f0, int32_t allow_next, double c1, double c2,
+                             double* out, void* stream) {
+  if (!T || !out || (cur != 0 && cur != 1)) return MDE_E_INVALID;
+  MDE_HIP(hipStreamSynchronize(mde_stream(stream)));
+  const double f_new = (double)*T->host_loss;
+  const double* hb = T->host_board;
+  for (int q = 0; q < 8; ++q) {
+    out[4 + q] = hb[q];
+    out[12 + q] = hb[16 + q];
+  }
+  out[0] = f_new;
+  out[3] = (double)*T->host_status;
+  // the first pass of the bracketing loop at t = 1 (lbfgs.py:88-110): not bad, Armijo, curvature
+  const double gtd0 = hb[16 + 0], gtd_new = hb[0];
+  const bool bad = std::isnan(f_new) || std::isinf(f_new) || hb[4] != 0.0;
+  const bool accept = !bad && !(f_new > (f0 + c1 * 1.0 * gtd0)) && (std::fabs(gtd_new) <= -c2 * gtd0);
+  out[1] = accept ? 1.0 : 0.0;
+  out[2] = 0.0;
+  if (accept && allow_next && *T->host_status == 0) {
+    const int rc = mde_turn_enqueue(T, 1 - cur, 1.0f, stream);
+    if (rc != MDE_OK) return rc;
+    out[2] = 1.0;
+  }
+  return MDE_OK;
 }

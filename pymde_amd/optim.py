@@ -209,6 +209,24 @@ class _NativeProblem(object):
         else:
             raise TypeError("not a built-in constraint")
 
+    def turn_desc(self):
+        """The steady-state iteration as one descriptor (``mde_turn_desc``), or None when this problem
+        cannot take that path (exchange between ranks, unfused function, anchored rows)."""
+        e = self.e
+        if self.reducer is not None or not self.binding.fused or self.kind not in ("centered", "standardized"):
+            return None
+        T = _lib.MdeTurnDesc()
+        T.plan = self._plan_handle
+        T.func = ctypes.cast(ctypes.pointer(self.fstruct), ctypes.c_void_p)
+        T.n, T.d, T.kind = e.n, e.d, 0 if self.kind == "centered" else 1
+        T.X[0], T.X[1] = e.X.data_ptr(), e.X_trial.data_ptr()
+        T.g, T.g_prev, T.dir, T.loss_dev = e.g.data_ptr(), e.g_prev.data_ptr(), e.dir.data_ptr(), e.loss_dev.data_ptr()
+        T.board, T.work, T.status, T.lbfgs = e.board.data_ptr(), e.work.data_ptr(), e.status.data_ptr(), e.lbfgs
+        T.host_dst, T.tail_src = e._host_ptr, e._tail_ptr
+        T.read_bytes = e._head_bytes + 8 * (8 + _DIR)
+        T.host_loss, T.host_status, T.host_board = e.host_loss.data_ptr(), e.host_status.data_ptr(), e.host.data_ptr()
+        return T
+
     def retract(self, X):
         e, lib = self.e, self.e.lib
         if self.kind == "centered":
@@ -281,6 +299,9 @@ class _GenericProblem(object):
         self.e = engine
         self.objective_fn = objective_fn
         self.constraint = constraint
+
+    def turn_desc(self):
+        return None
 
     def retract(self, X):
         with torch.no_grad():
@@ -413,8 +434,17 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
 
     # The next iteration's direction update and first trial (t = 1) are enqueued as soon as the line
     # search has accepted a point -- before this iteration's bookkeeping, which then runs while the GPU
-    # works (the iteration is a chain of ~10 short kernels behind ~40 us of Python).
+    # works (the iteration is a chain of ~10 short kernels behind ~40 us of Python).  Where the library
+    # can describe the whole iteration (mde_turn_desc), the wait, the acceptance test of the first trial
+    # and the launch of the next iteration are ONE call (mde_turn_wait): no Python between the
+    # read-back and the next kernel.
     ahead = False
+    turn = problem.turn_desc() if (use_line_search and use_cached_loss) else None
+    if turn is not None:
+        turn_ref = ctypes.byref(turn)
+        turn_bufs = (e.X, e.X_trial)              # the tensors behind turn.X[0], turn.X[1]
+        turn_out = np.zeros(24, dtype=np.float64)
+        turn_out_ptr = ctypes.c_void_p(turn_out.ctypes.data)
 
     for iteration in range(max_iter):
         if snapshot_every is not None and iteration % snapshot_every == 0:
@@ -451,7 +481,25 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
             # the first trial point is enqueued before the direction statistics are known; both
             # come back in one read
             t_prev, t = t, 1.0
-            if ahead:
+            accepted_here = False
+            if ahead and turn is not None:
+                # wait, test the first trial, and (when it is accepted and the solve goes on) launch the
+                # next iteration -- one call
+                go_on = (iteration + 1 < max_iter and math.sqrt(last_gg) > eps
+                         and not (snapshot_every is not None and (iteration + 1) % snapshot_every == 0))
+                cur = 0 if e.X is turn_bufs[0] else 1
+                _lib.check(e.lib.mde_turn_wait(turn_ref, cur, float(loss), 1 if go_on else 0, 1e-4, 0.9,
+                                               turn_out_ptr, e._stream))
+                o = turn_out
+                tv = o[4:12]
+                last_eval["t"], last_eval["gg"], last_eval["xx"] = t, tv[_GG], tv[_XX]
+                first = (float(o[0]), tv[_GD], tv[_NONFINITE] == 0)
+                v = None
+                dv = o[12:20]
+                accepted_here = o[1] != 0.0
+                ahead_next = o[2] != 0.0
+                turn_status = int(o[3])
+            elif ahead:
                 first, v = finish_trial(t, extra=_DIR)   # (enqueued at the end of the last iteration)
             else:
                 e.update_direction(t_prev)
@@ -461,10 +509,12 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
                     first = None
                     v, _ = e.read_board(_DIR + 8)
             ahead = False
-            dv = v[_DIR:_DIR + 8]
+            if v is not None:
+                dv = v[_DIR:_DIR + 8]
             gtd, d_norm2, d_max = dv[_GD], math.sqrt(dv[_DD]), dv[_DMAX]
         else:
             first = None
+            accepted_here = False
 
         def phi_ls(tt, _cache=[first, t]):
             if _cache[0] is not None and tt == _cache[1]:
@@ -473,7 +523,11 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
             _cache[0] = None
             return phi(tt)[0]
 
-        if use_line_search:
+        if use_line_search and accepted_here:
+            # (mde_turn_wait applied the first pass of the search: Armijo and curvature hold at t = 1)
+            cached_loss = first[0]
+            last_gg = last_eval["gg"]
+        elif use_line_search:
             try:
                 loss_new, t, _ = _host.strong_wolfe(phi_ls, t, loss, gtd, d_max)
             except _host.LineSearchError as err:
@@ -491,14 +545,23 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
             problem.retract_step(t, e.X_trial)
             e.X, e.X_trial = e.X_trial, e.X
             new_xx = None
-        problem.check_status()
         norm_grad = grad_norms[-1]
-        if (use_line_search and use_cached_loss and t != 0 and norm_grad > eps and iteration + 1 < max_iter
-                and not (snapshot_every is not None and (iteration + 1) % snapshot_every == 0)):
-            e.update_direction(t)
-            enqueue_trial(1.0)
-            e.enqueue_read(8 + _DIR)
-            ahead = True
+        if accepted_here:
+            # the status word and the next launch were handled inside mde_turn_wait
+            if turn_status != 0:
+                raise util.SolverError("Standardized retraction failed: X^T X is singular")
+            ahead = ahead_next
+        else:
+            problem.check_status()
+            if (use_line_search and use_cached_loss and t != 0 and norm_grad > eps and iteration + 1 < max_iter
+                    and not (snapshot_every is not None and (iteration + 1) % snapshot_every == 0)):
+                if turn is not None:
+                    _lib.check(e.lib.mde_turn_enqueue(turn_ref, 0 if e.X is turn_bufs[0] else 1, float(t), e._stream))
+                else:
+                    e.update_direction(t)
+                    enqueue_trial(1.0)
+                    e.enqueue_read(8 + _DIR)
+                ahead = True
 
         times.append(time.time() - start)
         h = t

@@ -42,6 +42,24 @@ def test_mde_func_struct_layout_matches_header():
     assert _lib.MdeFunc.layout.offset == 56
 
 
+def test_turn_desc_layout_matches_header(tmp_path):
+    """struct mde_turn_desc as gcc lays it out from include/mde_hip.h against the ctypes mirror."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "t.c"
+    fields = [f for f, _ in _lib.MdeTurnDesc._fields_]
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mde_hip.h"\nint main(void){\n'
+                   'printf("%zu", sizeof(mde_turn_desc));\n'
+                   + "".join('printf(" %%zu", offsetof(mde_turn_desc, %s));\n' % f for f in fields)
+                   + 'return 0;}\n')
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert got[0] == ctypes.sizeof(_lib.MdeTurnDesc)
+    assert got[1:] == [getattr(_lib.MdeTurnDesc, f).offset for f in fields]
+
+
 # ---------------------------------------------------------------- no GPU -> loud failure
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_no_gpu_fails_loudly():
