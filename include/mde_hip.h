@@ -407,12 +407,14 @@ typedef struct mde_turn_desc {
   int64_t read_bytes;
   const float* host_loss;
   const int32_t* host_status;
-  const double* host_board;
+  const double* host_board;  /* >= 25 doubles: the last kernel of an iteration writes its sequence number behind
+                                the 24 mirrored board entries, and mde_turn_wait polls that word */
+  double seq;                /* (library state: sequence number of the iteration enqueued last) */
 } mde_turn_desc;
-int mde_turn_enqueue(const mde_turn_desc* T, int32_t cur, float t_prev, void* stream);
+int mde_turn_enqueue(mde_turn_desc* T, int32_t cur, float t_prev, void* stream);
 /* out (>= 24 doubles): [0] f_new, [1] accepted, [2] next iteration enqueued, [3] status word,
  * [4,12) trial statistics, [12,20) direction statistics.  SYNC (waits for the stream). */
-int mde_turn_wait(const mde_turn_desc* T, int32_t cur, double f0, int32_t allow_next, double c1, double c2,
+int mde_turn_wait(mde_turn_desc* T, int32_t cur, double f0, int32_t allow_next, double c1, double c2,
                   double* out, void* stream);
 
 #ifdef __cplusplus

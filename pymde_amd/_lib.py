@@ -35,7 +35,7 @@ class MdeTurnDesc(ctypes.Structure):
                 ("X", c_vp * 2), ("g", c_vp), ("g_prev", c_vp), ("dir", c_vp), ("loss_dev", c_vp),
                 ("board", c_vp), ("work", c_vp), ("status", c_vp), ("lbfgs", c_vp),
                 ("host_dst", c_vp), ("tail_src", c_vp), ("read_bytes", c_i64),
-                ("host_loss", c_vp), ("host_status", c_vp), ("host_board", c_vp)]
+                ("host_loss", c_vp), ("host_status", c_vp), ("host_board", c_vp), ("seq", ctypes.c_double)]
 
 
 # every exported symbol of include/mde_hip.h: name -> (restype, argtypes)

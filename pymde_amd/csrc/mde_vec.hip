@@ -135,6 +135,7 @@ struct MdeMirror {
   const double* board;   // the device board whose first 8 doubles are `stats` of the kernel
   char* host;
   int head_bytes;        // bytes of [loss | status | pad] in front of the board
+  double seq;            // written behind the 24 board entries once they are out (polled by the host)
 };
 __device__ __forceinline__ void mde_mirror_write(const MdeMirror& m) {
   if (!m.host) return;
@@ -148,6 +149,14 @@ __device__ __forceinline__ void mde_mirror_write(const MdeMirror& m) {
   if (threadIdx.x == 32) *reinterpret_cast<float*>(m.host) = *reinterpret_cast<const volatile float*>(m.loss_dev);
   if (threadIdx.x == 33)
     *reinterpret_cast<int32_t*>(m.host + 4) = m.status ? *reinterpret_cast<const volatile int32_t*>(m.status) : 0;
+  // the sequence word goes out behind the data: every writer fences to system scope, then one thread
+  // publishes (the host polls it instead of waiting for the stream's completion signal)
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    hb[24] = m.seq;
+    __threadfence_system();
+  }
 }
 
 // ---------------------------------------------------------------- vector statistics
@@ -229,7 +238,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_vec_stats(int64_t N, const float*
 }
 
 static int vec_stats_impl(int64_t N, const float* g, const float* d, const float* x, double* stats,
-                          double* work, hipStream_t st, MdeMirror mirror = MdeMirror{nullptr, nullptr, nullptr, nullptr, 0}) {
+                          double* work, hipStream_t st, MdeMirror mirror = MdeMirror{nullptr, nullptr, nullptr, nullptr, 0, 0.0}) {
   const int nb = mde_grid(N, MDE_BLOCK * 8, MDE_RED_BLOCKS);
   hipLaunchKernelGGL(k_vec_stats, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, d, x, work + MDE_SMALL_DOUBLES, stats,
                      work_ticket(work, TK_STATS), mirror);
@@ -805,7 +814,7 @@ static int std_tangent_stats_impl(int64_t n, int32_t d, const float* X, float* Z
 extern "C" int mde_std_tangent_stats(int64_t n, int32_t d, const float* X, float* Z, const float* dir, double* stats,
                                      double* work, void* stream) {
   if (n <= 0 || d <= 0 || d > 2048 || !X || !Z || !stats || !work) return MDE_E_INVALID;
-  return std_tangent_stats_impl(n, d, X, Z, dir, stats, work, stream, MdeMirror{nullptr, nullptr, nullptr, nullptr, 0});
+  return std_tangent_stats_impl(n, d, X, Z, dir, stats, work, stream, MdeMirror{nullptr, nullptr, nullptr, nullptr, 0, 0.0});
 }
 
 // ---------------------------------------------------------------- C^{-1/2} of a small SPD matrix
@@ -2217,7 +2226,7 @@ extern "C" int mde_lbfgs_combine(mde_lbfgs* o, const float* g, float c_g, const 
 }
 
 // ---------------------------------------------------------------- one solver iteration as two calls
-extern "C" int mde_turn_enqueue(const mde_turn_desc* T, int32_t cur, float t_prev, void* stream) {
+extern "C" int mde_turn_enqueue(mde_turn_desc* T, int32_t cur, float t_prev, void* stream) {
   if (!T || (cur != 0 && cur != 1) || (T->kind != 0 && T->kind != 1)) return MDE_E_INVALID;
   const int64_t N = T->n * (int64_t)T->d;
   float* Xc = T->X[cur];
@@ -2232,17 +2241,34 @@ extern "C" int mde_turn_enqueue(const mde_turn_desc* T, int32_t cur, float t_pre
   rc = mde_average_distortion(T->plan, Xt, T->d, T->func, 1.0f, T->g, T->loss_dev, stream);
   if (rc != MDE_OK) return rc;
   // the last kernel writes [loss | status | board] into the pinned mirror itself (no copy behind it)
+  static std::atomic<unsigned long long> turns{0};
+  T->seq = (double)(turns.fetch_add(1ull) + 1ull);  // (exact in a double for 2^53 iterations)
   const MdeMirror mirror{T->loss_dev, T->status, T->board, reinterpret_cast<char*>(T->host_dst),
-                         (int)(T->read_bytes - 8 * 24)};
+                         (int)(T->read_bytes - 8 * 24), T->seq};
   if (T->kind == 0)
     return vec_stats_impl(N, T->g, T->dir, Xt, T->board, T->work, mde_stream(stream), mirror);
   return std_tangent_stats_impl(T->n, T->d, Xt, T->g, T->dir, T->board, T->work, stream, mirror);
 }
 
-extern "C" int mde_turn_wait(const mde_turn_desc* T, int32_t cur, double f0, int32_t allow_next, double c1, double c2,
+extern "C" int mde_turn_wait(mde_turn_desc* T, int32_t cur, double f0, int32_t allow_next, double c1, double c2,
                              double* out, void* stream) {
   if (!T || !out || (cur != 0 && cur != 1)) return MDE_E_INVALID;
-  MDE_HIP(hipStreamSynchronize(mde_stream(stream)));
+  // Poll the sequence word the iteration's last kernel writes behind its data (a completion signal
+  // takes microseconds longer to reach a waiting thread); the stream is queried now and then, so the
+  // wait also ends -- with everything visible -- should the word never show up.
+  {
+    const volatile double* flag = T->host_board + 24;
+    hipStream_t st = mde_stream(stream);
+    for (unsigned spins = 0;; ++spins) {
+      if (*flag == T->seq) break;
+      if ((spins & 255u) == 255u) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) MDE_HIP(e);
+      }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
   const double f_new = (double)*T->host_loss;
   const double* hb = T->host_board;
   for (int q = 0; q < 8; ++q) {
