@@ -439,7 +439,7 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
     # and the launch of the next iteration are ONE call (mde_turn_wait): no Python between the
     # read-back and the next kernel.
     ahead = False
-    turn = problem.turn_desc() if (use_line_search and use_cached_loss) else None
+    turn = problem.turn_desc() if (use_line_search and use_cached_loss and not os.environ.get("MDE_NO_TURN")) else None
     if turn is not None:
         turn_ref = ctypes.byref(turn)
         turn_bufs = (e.X, e.X_trial)              # the tensors behind turn.X[0], turn.X[1]

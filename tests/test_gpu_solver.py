@@ -430,3 +430,35 @@ def test_fused_trial_point_and_projection_entry_points(d):
         rows = range(8) if with_dir else (1, 2, 3, 4, 7)
         for q in rows:
             assert float(b_got[q]) == pytest.approx(float(b_want[q]), rel=1e-12, abs=1e-300), q
+
+
+@pytest.mark.parametrize("cname", ["centered", "standardized"])
+def test_turn_calls_follow_the_python_loop_bit_for_bit(monkeypatch, cname):
+    """mde_turn_enqueue / mde_turn_wait (wait, first-trial strong-Wolfe test and launch of the next
+    iteration inside the library, read-back written by the last kernel) against the same solve driven
+    call by call from Python (MDE_NO_TURN=1): identical iterates and statistics, on a problem whose
+    line search both accepts t = 1 at once and has to bracket / zoom."""
+    import pymde_amd
+    rng = np.random.default_rng(17)
+    n, p = 6000, 60000
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    edges = torch.tensor(np.stack([i, j], 1), device=DEV)
+    w = torch.tensor(np.where(rng.random(p) < 0.3, -1.0, rng.uniform(0.5, 2.0, p)).astype(np.float32), device=DEV)
+    X0 = torch.tensor(rng.standard_normal((n, 2)).astype(np.float32), device=DEV)
+    runs = []
+    for no_turn in ("", "1"):
+        if no_turn:
+            monkeypatch.setenv("MDE_NO_TURN", no_turn)
+        else:
+            monkeypatch.delenv("MDE_NO_TURN", raising=False)
+        c = pymde_amd.Centered() if cname == "centered" else pymde_amd.Standardized()
+        mde = pymde_amd.MDE(n, 2, edges, pymde_amd.penalties.PushAndPull(w), constraint=c)
+        X = mde.embed(X=c.project_onto_constraint(X0.clone()), max_iter=60, eps=0.0)
+        st = mde.solve_stats
+        runs.append((X.clone(), list(st.average_distortions), list(st.residual_norms), list(st.step_size_percents)))
+    a, b = runs
+    assert torch.equal(a[0], b[0])
+    assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
+    # the search did more than accept t = 1 every time (otherwise this test checks less than it says)
+    assert len(set(round(s / max(a[3]), 3) for s in a[3])) > 3
