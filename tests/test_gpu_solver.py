@@ -462,3 +462,19 @@ def test_turn_calls_follow_the_python_loop_bit_for_bit(monkeypatch, cname):
     assert a[1] == b[1] and a[2] == b[2] and a[3] == b[3]
     # the search did more than accept t = 1 every time (otherwise this test checks less than it says)
     assert len(set(round(s / max(a[3]), 3) for s in a[3])) > 3
+    # short solves, a convergence stop and snapshots: the look-ahead must not run past the end of the loop
+    for kwargs in (dict(max_iter=1), dict(max_iter=2), dict(max_iter=3), dict(max_iter=40, eps=float(a[2][20])),
+                   dict(max_iter=12, snapshot_every=5)):
+        outs = []
+        for no_turn in ("", "1"):
+            if no_turn:
+                monkeypatch.setenv("MDE_NO_TURN", no_turn)
+            else:
+                monkeypatch.delenv("MDE_NO_TURN", raising=False)
+            c = pymde_amd.Centered() if cname == "centered" else pymde_amd.Standardized()
+            mde = pymde_amd.MDE(n, 2, edges, pymde_amd.penalties.PushAndPull(w), constraint=c)
+            X = mde.embed(X=c.project_onto_constraint(X0.clone()), **kwargs)
+            outs.append((X.clone(), list(mde.solve_stats.average_distortions), len(mde.solve_stats.snapshots)))
+        assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2], kwargs
+        if "eps" in kwargs:
+            assert len(outs[0][1]) < 40
