@@ -43,6 +43,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "mde_common.h"
@@ -106,8 +107,8 @@ __host__ __device__ constexpr int ring_max_span(int d) {
 #endif
   // (measured at config 4: 4..6 chunks of window leave the waves the most slack; 8 costs 4 %)
   constexpr int inflight = MDE_RING_NPROD * MDE_RING_DEPTH;
-  // (config 4: windows of 4 and 5 chunks measure the same, 6 costs 2 %: the slack is worth more than the padding)
-  return ring_slots(d) - inflight - 2 > 5 ? 5 : ring_slots(d) - inflight - 2;
+  // (the window is anchored per pair of iterations: the second one sees what the first left of it)
+  return ring_slots(d) - inflight - 2 > 6 ? 6 : ring_slots(d) - inflight - 2;
 }
 
 // header word of a wave iteration: [15:0] m = lowest chunk referenced, [20:16] span (highest = m +
@@ -247,9 +248,13 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
   const int per_it = nrows_w < 64 ? nrows_w : 64;
   const int bail = (!FILL && bail_factor > 0) ? bail_factor * ((end - beg + per_it - 1) / per_it) + 64 : 0x7fffffff;
   int last_chunk = (int)(((int64_t)((i / MDE_RING_NCW) % Q) * NC + Q - 1) / Q);
+  int m_lead = 0;
   while (nc > 0 || next < end) {
     const int m = (int)(keys[nc > 0 ? cq_pos[cur][0] : next] & JM);  // oldest candidate's chunk
-    const int lim = m + SPAN;
+    // the chunk window is anchored at the first iteration of a PAIR (the kernel does one hand-shake
+    // per pair: it publishes that iteration's m and waits for the newest chunk of both)
+    if (((out - first) & 1) == 0) m_lead = m;
+    const int lim = m_lead + SPAN;
     int nem = 0, nnew = 0;  // emitted so far, waiting so far (into buffer cur ^ 1)
     if (lane < 32) rcnt[lane] = ccnt[lane] = 0;
     __syncthreads();
@@ -360,9 +365,11 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
 //       its loss term is added by the entry whose row is the smaller vertex: 0 = no entry of the
 //       iteration, 1 = every entry, 2 = mixed (the kernel tests v < u per lane; only the
 //       iterations around the diagonal)
-//   [3] bit 0: the iteration has padding lanes
+//   [3] bits 1:0 (first iteration of a block of four only): loss class of the BLOCK -- 0 / 1 when every
+//       non-empty iteration of the block has that class, else 2 (the kernel branches once per block);
+//       bit 2: the iteration has padding lanes; bits 15:8: its number of entries
 #define MDE_RING_HW 4
-#define MDE_RING_H3_PAD 1u
+#define MDE_RING_H3_PAD 4u
 
 // One wave per iteration: deal its <= 64 entries to the lanes (ring_place: bank classes split
 // evenly over the 32-lane read passes and the 16-lane write passes), pad to 64 with dummies, write
@@ -427,6 +434,9 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int3
     // included) .. the newest chunk it references
     const uint32_t m = valid ? (uint32_t)__builtin_amdgcn_readfirstlane(it_m[it]) : 0u;
     const uint32_t need = max((uint32_t)(cw >> 8), m);
+    // the padding lanes read a column that is resident for sure: the first one of the oldest chunk
+    // of the PAIR of iterations (the kernel waits for that chunk before it issues the pair's reads)
+    const uint32_t mpad = valid ? (uint32_t)__builtin_amdgcn_readfirstlane(it_m[it & ~(int64_t)1]) : 0u;
     // element (iteration it, lane l) of a stream lives at ((it / 4) * 64 + l) * 4 + it % 4
     const size_t base = ((size_t)(it >> 2) * 64) * 4 + (size_t)(it & 3);
     if (act) {
@@ -439,16 +449,43 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int3
       // padding: a dummy row slot of the lane's own bank class, a resident column (first of chunk m)
       const int l = s_free[wv][lane - cnt];
       packed[base + (size_t)l * 4] = (((uint32_t)(R + (l & 31)) * 4u * (uint32_t)d) << 17) |
-                                     ((m % (uint32_t)S) * (uint32_t)C * 4u * (uint32_t)d + 16u);
+                                     ((mpad % (uint32_t)S) * (uint32_t)C * 4u * (uint32_t)d + 16u);
       peid[base + (size_t)l * 4] = -1;
     }
     if (lane == 0 && valid) {
       hdr[MDE_RING_HW * it] = m;
       hdr[MDE_RING_HW * it + 1] = need;
       hdr[MDE_RING_HW * it + 2] = lclass;
-      hdr[MDE_RING_HW * it + 3] = cnt < 64 ? MDE_RING_H3_PAD : 0u;
+      hdr[MDE_RING_HW * it + 3] = (cnt < 64 ? MDE_RING_H3_PAD : 0u) | ((uint32_t)cnt << 8);
     }
     __syncthreads();
+  }
+}
+
+// loss class of every block of four iterations (header word 3 of its first iteration, bits 1:0)
+__global__ __launch_bounds__(MDE_BLOCK) void k_ring_block_class(int64_t nblocks, uint32_t* __restrict__ hdr) {
+  const int64_t b = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x;
+  if (b >= nblocks) return;
+  bool any0 = false, any1 = false, any2 = false;
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t* h = hdr + (size_t)MDE_RING_HW * (4 * b + q);
+    if ((h[3] >> 8) == 0u) continue;  // an empty iteration adds nothing whatever the class
+    any0 |= h[2] == 0u;
+    any1 |= h[2] == 1u;
+    any2 |= h[2] == 2u;
+  }
+  const uint32_t cls = (any2 || (any0 && any1)) ? 2u : (any1 ? 1u : 0u);
+  hdr[(size_t)MDE_RING_HW * 4 * b + 3] = (hdr[(size_t)MDE_RING_HW * 4 * b + 3] & ~3u) | cls;
+  // one hand-shake per pair of iterations: the first one's `need` covers both.  An EMPTY iteration
+  // reads no column (its lanes sit on the first column of the pair's oldest chunk, k_ring_pack) and
+  // asks for nothing: on a sparse stream its own m may lie far beyond the pair's window.
+  for (int t = 0; t < 2; ++t) {
+    uint32_t* h0 = hdr + (size_t)MDE_RING_HW * (4 * b + 2 * t);
+    uint32_t* h1 = h0 + MDE_RING_HW;
+    uint32_t need = h0[0];
+    if ((h0[3] >> 8) != 0u) need = max(need, h0[1]);
+    if ((h1[3] >> 8) != 0u) need = max(need, h1[1]);
+    h0[1] = need;
   }
 }
 
@@ -458,7 +495,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_stats(int64_t nit, const uin
                                                           unsigned long long* __restrict__ stats) {
   unsigned long long a = 0, b = 0, c = 0;
   for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < nit; i += (int64_t)gridDim.x * MDE_BLOCK) {
-    a += hdr[MDE_RING_HW * i + 3] & MDE_RING_H3_PAD;
+    a += (hdr[MDE_RING_HW * i + 3] & MDE_RING_H3_PAD) ? 1u : 0u;
     b += hdr[MDE_RING_HW * i + 2] == 1u;
     c += hdr[MDE_RING_HW * i + 2] == 2u;
   }
@@ -665,6 +702,9 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
                      (int64_t)total_iters, it_ent, it_cnt, it_m, keys2, vals2, hrow, plan->nbr, plan->eid, z.R, z.Q, z.C,
                      z.S, z.JB, d, (int)plan->row_lo, place, packed, peid, hdr);
   RB(hipGetLastError());
+  hipLaunchKernelGGL(k_ring_block_class, dim3((unsigned)((total_iters / 4 + MDE_BLOCK - 1) / MDE_BLOCK)), dim3(MDE_BLOCK), 0, st,
+                     (int64_t)(total_iters / 4), hdr);
+  RB(hipGetLastError());
   RB(hipStreamSynchronize(st));
   if (getenv("MDE_RING_STATS")) {
     unsigned long long* dstat = reinterpret_cast<unsigned long long*>(iters);  // scratch, >= 3 words
@@ -685,6 +725,24 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
       for (int g = 0; g + MDE_RING_NCW <= nseg; g += MDE_RING_NCW) wg_mx = std::max(wg_mx, hb[g + MDE_RING_NCW] - hb[g]);
       fprintf(stderr, "[mde ring] iterations per consumer wave: min %d mean %.1f max %d; per workgroup: mean %.1f max %d\n", mn,
               (double)total_iters / nseg, mx, (double)total_iters * MDE_RING_NCW / nseg, wg_mx);
+    }
+    {
+      // self-check of the hand-shake contract: per pair of iterations, newest chunk - published chunk <= window
+      std::vector<uint32_t> hh((size_t)total_iters * MDE_RING_HW);
+      RB(hipMemcpy(hh.data(), hdr, hh.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      long long bad = 0;
+      int worst = 0;
+      for (int64_t it = 0; it + 1 < total_iters; it += 2) {
+        const int gap = (int)hh[it * MDE_RING_HW + 1] - (int)hh[it * MDE_RING_HW];
+        if (gap > span || hh[(it + 1) * MDE_RING_HW] < hh[it * MDE_RING_HW]) {
+          if (bad < 8)
+            fprintf(stderr, "[mde ring] pair at iteration %lld: m %u need %u | next m %u need %u\n", (long long)it, hh[it * MDE_RING_HW],
+                    hh[it * MDE_RING_HW + 1], hh[(it + 1) * MDE_RING_HW], hh[(it + 1) * MDE_RING_HW + 1]);
+          ++bad;
+        }
+        worst = std::max(worst, gap);
+      }
+      fprintf(stderr, "[mde ring] hand-shake contract: %lld of %d pairs exceed the window (worst gap %d chunks)\n", bad, total_iters / 2, worst);
     }
     fprintf(stderr, "[mde ring] d=%d R=%d NRB=%d Q=%d chunks=%d x %d cols, window %d, cap %d, placement %d: %d iterations for %lld half-edges "
             "(%.1f%% padding), %.1f%% with padding lanes; loss terms: %.1f%% of the iterations add all, %.2f%% test per lane\n",
@@ -976,6 +1034,11 @@ __device__ __forceinline__ void ring_dma_pieces(const void* gsrc, uint32_t lds_d
 __device__ __forceinline__ void ring_ctrl_store(uint32_t addr, int v) {
   asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
+// the consumers' control-word store as a compiler-counted LDS instruction
+__device__ __forceinline__ void ring_ctrl_store_counted(char* lds_base, uint32_t addr, int v) {
+  typedef __attribute__((address_space(3))) volatile int* lds_vint;
+  *(lds_vint)(lds_base + addr) = v;
+}
 __device__ __forceinline__ int ring_ctrl_load(uint32_t addr) {
   int v;
   asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
@@ -987,6 +1050,12 @@ __device__ __forceinline__ int ring_ctrl_load(uint32_t addr) {
 //   [0] consumer loop, [1] of it inside the chunk poll, [2] poll trips, [3] producer loop,
 //   [4] of it blocked on a slot, [5] of it waiting for DMA pieces to land, [6] slot polls
 __device__ unsigned long long g_ring_probe[8][1024];
+// hang diagnosis: a poll that spins longer than MDE_RING_SPINMAX trips leaves a record and gives up
+__device__ int g_ring_diag[64][8];
+__device__ int g_ring_ndiag;
+#ifndef MDE_RING_SPINMAX
+#define MDE_RING_SPINMAX 100000
+#endif
 #define RING_CLK() __builtin_readcyclecounter()
 #endif
 // CB: the first parameter comes from a codebook -- `packed` is the stream with value indices in its
@@ -1004,7 +1073,10 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     float* __restrict__ grad, float* __restrict__ partial, double* __restrict__ loss_partials, Fn fn,
     float fix_value, float grad_scale, float* __restrict__ loss_out, double loss_scale, int dbg_arg) {
 #if MDE_RING_ABLATE
-  const int dbg = dbg_arg;  // timing probes (tools/abl.sh): 1 consumers never wait, 2 no staging, 4 no evaluation, 8 producers never wait, 64 / 128 a role skips its loop
+#ifndef MDE_RING_ABLATE_MASK
+#define MDE_RING_ABLATE_MASK (~0)  // (a narrower mask lets hipcc fold the other probes away)
+#endif
+  const int dbg = dbg_arg & (MDE_RING_ABLATE_MASK);  // timing probes (tools/abl.sh): 1 consumers never wait, 2 no staging, 4 no evaluation, 8 producers never wait, 64 / 128 a role skips its loop
   const unsigned long long t_begin = __builtin_readcyclecounter();
 #else
   constexpr int dbg = 0;
@@ -1119,6 +1191,19 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           else
             __builtin_amdgcn_s_sleep(1);
 #if MDE_RING_ABLATE
+          if (pr_polls > MDE_RING_SPINMAX) {
+            if (lane == 0) {
+              const int k = atomicAdd(&g_ring_ndiag, 1);
+              if (k < 64) {
+                int* r = g_ring_diag[k];
+                r[0] = 2; r[1] = blockIdx.x; r[2] = p; r[3] = j; r[4] = minprog; r[5] = infl; r[6] = oldest; r[7] = j_hi;
+              }
+            }
+            pr_polls = 0;
+            minprog = j;  // (give up: overwrite the slot)
+          }
+#endif
+#if MDE_RING_ABLATE
           pr_blocked += RING_CLK() - tb0;
 #endif
           continue;
@@ -1127,7 +1212,8 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         pr_blocked += RING_CLK() - tb0;
 #endif
       }
-      const uint32_t dst = (uint32_t)RING_OFF + (uint32_t)slot * (uint32_t)CBYTES;
+      // (readfirstlane: the LDS base goes into M0 and must sit in an SGPR whatever hipcc's uniformity analysis says)
+      const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)RING_OFF + (uint32_t)slot * (uint32_t)CBYTES));
       if (!(dbg & 2)) {
         if (j != NC - 1) {
           // 1 KiB pieces, up to four per statement: the instruction offset advances the global and
@@ -1188,7 +1274,6 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     if (NB > 0 && !(dbg & 64)) {
       const bool a0_arr = !a0_scalar && !CB;
       const ring_u4* sp = reinterpret_cast<const ring_u4*>(packed) + (size_t)(ib >> 2) * 64 + lane;
-      const ring_u4* hp = reinterpret_cast<const ring_u4*>(hdr) + (size_t)ib;  // one 4-word header per iteration
       const ring_f4* ap = reinterpret_cast<const ring_f4*>(a0_arr ? a0 : reinterpret_cast<const float*>(packed)) +
                           (size_t)(ib >> 2) * 64 + lane;
       const int lastb = NB - 1;
@@ -1196,31 +1281,29 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       // stream loads are issued from ONE place (the refill after a block is consumed),
       // unconditional and clamped, never predicated: on every path the same loads are in flight
       // when a block is consumed, so the compiler's vmcnt counts are exact and nothing waits for a
-      // load just issued.  The headers of a block come with two scalar loads (uniform address).
+      // load just issued.
+      // The 16 header words of a block come with ONE vector load: lane l holds word l & 15, i.e. every
+      // row of 16 lanes holds the whole header, and a word reaches all lanes with a DPP row broadcast
+      // (one VALU instruction, no round trip through the scalar unit).  Round 3 fetched the headers
+      // with s_load_dwordx16: scalar loads share lgkmcnt with the LDS instructions and return out of
+      // order, so the first LDS wait after a refill drained the header load just issued.
       constexpr int PFB = MDE_RING_PFB;
-      ring_u4 pq[PFB] = {}, hq[PFB][4] = {};
+      ring_u4 pq[PFB] = {};
+      uint32_t hv[PFB] = {};
       ring_f4 wq[PFB] = {};
+      const uint32_t* hvp = hdr + (size_t)ib * MDE_RING_HW + (lane & 15);
       auto load_block = [&](int u, int b) __attribute__((always_inline)) {
         const int bc = min(b, lastb);
-#if MDE_RING_ABLATE
-        if (dbg & 8192) {
-          // (probe: block b of every wave of the grid side by side -- the addresses a [block][wave]
-          // stream layout would touch; the words read are not this wave's, use with 4096 only)
-          const size_t nw = (size_t)gridDim.x * NCW, tb = (size_t)(wave_iter[nw] >> 2);
-          const size_t at = ((size_t)bc * nw + blockIdx.x * NCW + wave) % tb;
-          pq[u] = reinterpret_cast<const ring_u4*>(packed)[at * 64 + lane];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) hq[u][k] = reinterpret_cast<const ring_u4*>(hdr)[at * 4 + k];
-          if (!CB) wq[u] = reinterpret_cast<const ring_f4*>(a0)[at * 64 + lane];
-          return;
-        }
+#if defined(MDE_RING_STREAM_L2)  // (design probe, wrong results: the packed words of 8 blocks over and over -- an L2-resident stream)
+        pq[u] = sp[(size_t)(bc & 7) * 64];
+#elif defined(MDE_RING_STREAM_NT)
+        pq[u] = __builtin_nontemporal_load(&sp[(size_t)bc * 64]);
+#else
+        pq[u] = sp[(size_t)bc * 64];
 #endif
-        pq[u] = sp[(size_t)((dbg & 1024) ? (bc & 7) : bc) * 64];  // (probe: packed words from L2, real headers)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) hq[u][k] = hp[(size_t)bc * 4 + k];
+        hv[u] = hvp[(size_t)bc * 16];
         if (!CB) wq[u] = ap[(size_t)bc * 64];
       };
-      int ready = j_lo;
 #if MDE_RING_ABLATE
       unsigned long long cs_t0 = RING_CLK(), cs_poll = 0, cs_trips = 0;
 #endif
@@ -1237,7 +1320,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         ring_ld<D>(L + (RING_OFF - 16) + colf, r.xc);  // (the field carries + 16: the base fits the instruction offset)
         return r;
       };
-      // this entry adds the loss term iff its row is the smaller vertex (iterations around the diagonal)
+      // this entry adds the loss term iff its row is the smaller vertex (blocks around the diagonal)
       auto counts_here = [&](uint32_t w, uint32_t hm) __attribute__((always_inline)) {
         const uint32_t off = (w & 0x1ffffu) - 16u;
         const uint32_t slot = off / (uint32_t)CBYTES, cidx = (off - slot * (uint32_t)CBYTES) / (4u * (uint32_t)D);
@@ -1247,9 +1330,12 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         const uint32_t vv = (uint32_t)(row_lo + r0) + (w >> 17) / (4u * (uint32_t)D);
         return vv < u;
       };
-      // evaluate the entry and add its gradient term to the row's accumulator (read earlier)
-      auto finish = [&](uint32_t w, const Pre& x, float (&acc)[D], float p1, uint32_t hm, uint32_t lcls)
+      // evaluate the entry and add its gradient term to the row's accumulator (read earlier).  LC is
+      // the loss class of the BLOCK (compile time: no branch per iteration): 0 no entry adds its loss
+      // term here, 1 every entry does, 2 test per lane.
+      auto finish = [&](auto lc_tag, uint32_t w, const Pre& x, float (&acc)[D], float p1, uint32_t hm)
           __attribute__((always_inline)) {
+        constexpr int LC = decltype(lc_tag)::value;
         const uint32_t rowaddr = w >> 17;
         float v[D], ss = 0.0f;
 #pragma unroll
@@ -1265,7 +1351,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           const float t = fmaf(d, sd, 1.0f);
           const float r = mde_rcp(fmaf(sd, t, 1.0e-30f));
           gd = x.p0 * r;
-          if (lcls != 0u) {
+          if constexpr (LC != 0) {
             // w log1p(u) = w ln2 log2(t) + (w / t) (u - (t - 1)), 1 / t = sqrt(d) r: the two sums are
             // kept apart and combined (with 1 / 1.5) once per wave
             const float c = d * sd - (t - 1.0f);
@@ -1276,7 +1362,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
               wl = real ? wl : 0.0f;
               gc = real ? gc : 0.0f;
             }
-            if (lcls == 2u) {
+            if constexpr (LC == 2) {
               const bool here = counts_here(w, hm);
               wl = here ? wl : 0.0f;
               gc = here ? gc : 0.0f;
@@ -1284,15 +1370,14 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
             loss = fmaf(wl, mde_log2(t), loss);
             loss2 = fmaf(gc, sd * c, loss2);
           }
-        } else if (lcls == 0u) {
-          float f;  // (unused: the loss arithmetic is dead code on this path)
-          fn.eval(ss, x.p0, p1, f, gd);
         } else {
-          float f;
+          float f;  // (dead code when LC == 0)
           fn.eval(ss, x.p0, p1, f, gd);
-          if (!LIN) f = (rowaddr < dummy_row) ? f : 0.0f;
-          if (lcls == 2u) f = counts_here(w, hm) ? f : 0.0f;
-          loss += f;
+          if constexpr (LC != 0) {
+            if (!LIN) f = (rowaddr < dummy_row) ? f : 0.0f;
+            if constexpr (LC == 2) f = counts_here(w, hm) ? f : 0.0f;
+            loss += f;
+          }
         }
         if (!HAS_GRAD) return;
         // (codebook values are finite -- mde_plan_expand_codebook refuses others)
@@ -1301,13 +1386,18 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         for (int c = 0; c < D; ++c) acc[c] = fmaf(v[c], g, acc[c]);
         ring_st<D>(L + GR_OFF + rowaddr, acc);
       };
+      // Hand-shake, once per PAIR of iterations (q = 0 or 2 of block u; header words at lanes 4 q ..):
+      // publish the oldest chunk this wave still reads (all reads of older chunks have been ISSUED,
+      // and the LDS executes in order; m never decreases along a stream) and wait until the newest
+      // chunk of the pair has landed.  The layout anchors the chunk window of a pair at the pair's
+      // first iteration (k_ring_schedule), so one test covers both.
       const uint32_t prog_addr = MDE_RING_CTRL_PROG + 4u * (uint32_t)wave;
-      auto sync_for = [&](uint32_t hm, uint32_t hneed) __attribute__((always_inline)) {
-        const int m = (int)hm, need = (int)hneed;
-        // (every read of chunks < m has been issued, and the LDS executes in order; m never
-        // decreases along a stream, so it is simply stored every time)
-        ring_ctrl_store(prog_addr, m);
-        if (need >= ready && !(dbg & 1)) {
+      int ready = j_lo;  // chunks below this have landed
+      auto sync_pair = [&](int u, int q) __attribute__((always_inline)) {
+        const int m = __builtin_amdgcn_readlane((int)hv[u], 4 * q);
+        const int need = __builtin_amdgcn_readlane((int)hv[u], 4 * q + 1);
+        ring_ctrl_store_counted(L, prog_addr, m);
+        if (__builtin_expect(need >= ready && !(dbg & 1), 0)) {
 #if MDE_RING_ABLATE
           const unsigned long long tp0 = RING_CLK();
 #endif
@@ -1318,6 +1408,18 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
             for (int pp = 1; pp < NPROD; ++pp) ready = min(ready, __builtin_amdgcn_readlane(fl, pp));
 #if MDE_RING_ABLATE
             ++cs_trips;
+            if (cs_trips > MDE_RING_SPINMAX) {
+              if (lane == 0) {
+                const int k = atomicAdd(&g_ring_ndiag, 1);
+                if (k < 64) {
+                  int* r = g_ring_diag[k];
+                  r[0] = 1; r[1] = blockIdx.x; r[2] = wave; r[3] = need; r[4] = ready; r[5] = m; r[6] = u * 4 + q; r[7] = NB;
+                }
+              }
+              cs_trips = 0;
+              ready = need + 1;
+              break;
+            }
 #endif
             if (need < ready) break;
             __builtin_amdgcn_s_sleep(MDE_RING_CSLEEP);
@@ -1328,60 +1430,65 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           asm volatile("" ::: "memory");
         }
       };
-      auto hword = [&](int u, int q, int k) __attribute__((always_inline)) {  // header word k of iteration q of block u
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)hq[u][q][k]);
-      };
 
-      // Software pipeline, one iteration deep: while iteration k is evaluated the operands of k + 1
-      // (x_v, x_u, parameter -- after the hand-shake for ITS chunks) are already on their way; the
-      // accumulator of k + 1 is read right behind the write of k (the LDS executes a wave's
-      // accesses in order, so a row shared by consecutive iterations sees the update).
+      // Software pipeline over PAIRS of iterations.  In the region of pair p the wave (after the
+      // hand-shake for the chunks of pair p + 1) issues the LDS reads of the operands of pair p + 1
+      // (x_v, x_u, parameter), then evaluates the two iterations of pair p (operands read one pair
+      // ago): accumulator write of k and, right behind it, the accumulator read of k + 1 (the LDS
+      // executes a wave's accesses in order, so a row shared by consecutive iterations sees the
+      // update).  Every LDS access of the loop is a compiler-counted instruction (the control-word
+      // store included: round 3 issued it from inline asm, which put hipcc's lgkmcnt counts off by
+      // one), and the region of a pair is ONE basic block: hipcc's scheduler interleaves the two
+      // evaluations and places the waits.
+      // What bounds this loop is instruction issue, not LDS or HBM (round 4, tools/r4_run.sh:
+      // the consumers alone take 0.15 ms with a test + branch per iteration and 0.10 ms as
+      // straight-line code; LDS conflicts and the accumulator chain cost nothing): hence one
+      // hand-shake branch per pair, one loss-class branch per block of four (three copies of the
+      // block body), and no header word through an SGPR.
+      Pre xa, xb;  // operands of the pair being evaluated
+      float acc[D];
+      auto block_body = [&](auto lc_tag, int u, int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = 2 * h;
+          // the pair after this one (block and slot); past the end of the stream it is a copy of
+          // the last block: resident chunks, harmless reads, nothing new published
+          const int un = h == 0 ? u : (u + 1) % PFB, qn = (q + 2) & 3;
+          sync_pair(un, qn);
+          const Pre xna = issue_x(pq[un][qn], (a0_scalar || CB) ? a0s : wq[un][qn]);
+          const Pre xnb = issue_x(pq[un][qn + 1], (a0_scalar || CB) ? a0s : wq[un][qn + 1]);
+          const float p1a = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q] : a1s;
+          const float p1b = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q + 1] : a1s;
+          const bool lc2 = decltype(lc_tag)::value == 2;
+          const uint32_t hma = lc2 ? (uint32_t)__builtin_amdgcn_readlane((int)hv[u], 4 * q) : 0u;
+          const uint32_t hmb = lc2 ? (uint32_t)__builtin_amdgcn_readlane((int)hv[u], 4 * q + 4) : 0u;
+          finish(lc_tag, pq[u][q], xa, acc, p1a, hma);
+          if (HAS_GRAD) ring_ld<D>(L + GR_OFF + (pq[u][q + 1] >> 17), acc);
+          finish(lc_tag, pq[u][q + 1], xb, acc, p1b, hmb);
+          if (HAS_GRAD) ring_ld<D>(L + GR_OFF + (pq[un][qn] >> 17), acc);
+          xa = xna;
+          xb = xnb;
+        }
+      };
 #pragma unroll
       for (int u = 0; u < PFB; ++u) load_block(u, u);
-      sync_for(hword(0, 0, 0), hword(0, 0, 1));
-      Pre x = issue_x(pq[0][0], (a0_scalar || CB) ? a0s : wq[0][0]);
-      float acc[D];
+      sync_pair(0, 0);
+      xa = issue_x(pq[0][0], (a0_scalar || CB) ? a0s : wq[0][0]);
+      xb = issue_x(pq[0][1], (a0_scalar || CB) ? a0s : wq[0][1]);
       if (HAS_GRAD) ring_ld<D>(L + GR_OFF + (pq[0][0] >> 17), acc);
       for (int base = 0; base < NB; base += PFB) {
 #pragma unroll
         for (int u = 0; u < PFB; ++u) {
           const int b = base + u;
           if (b < NB) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int un = q < 3 ? u : (u + 1) % PFB, qn = q < 3 ? q + 1 : 0;
-#if MDE_RING_ABLATE
-              if (dbg & 4096) {
-                // (probe: the stream alone -- packed words, parameters and headers are consumed, nothing else happens)
-                loss += __uint_as_float(pq[u][q] ^ hword(u, q, 0) ^ hword(u, q, 1)) * 0.0f + (CB ? 0.0f : wq[u][q] * 0.0f);
-                continue;
-              }
-#endif
-              // (past the end of the stream "next" is a copy of the last block: resident chunks,
-              // harmless reads, nothing published)
-              const uint32_t wn = pq[un][qn];
-              sync_for(hword(un, qn, 0), hword(un, qn, 1));
-              const Pre xn = issue_x(wn, (a0_scalar || CB) ? a0s : wq[un][qn]);
-              const float p1 = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q] : a1s;
-#if MDE_RING_ABLATE
-              // (probe, wrong results: the next accumulators are read BEFORE this iteration's write --
-              // what the loop would cost without the accumulator chain through LDS)
-              float accn[D];
-              if (HAS_GRAD && (dbg & 2048)) ring_ld<D>(L + GR_OFF + (wn >> 17), accn);
-#endif
-              if (!(dbg & 4))
-                finish(pq[u][q], x, acc, p1, hword(u, q, 0), hword(u, q, 2));
-              else
-                loss += __uint_as_float(pq[u][q]) * 0.0f + x.xr[0] * 0.0f;
-#if MDE_RING_ABLATE
-              if (HAS_GRAD && (dbg & 2048)) {
-#pragma unroll
-                for (int c = 0; c < D; ++c) acc[c] = accn[c];
-              } else
-#endif
-              if (HAS_GRAD) ring_ld<D>(L + GR_OFF + (wn >> 17), acc);
-              x = xn;
-            }
+            // loss class of the block: header word 3 of its first iteration
+            const int bcls = __builtin_amdgcn_readlane((int)hv[u], 3) & 3;
+            if (bcls == 0)
+              block_body(std::integral_constant<int, 0>(), u, b);
+            else if (bcls == 1)
+              block_body(std::integral_constant<int, 1>(), u, b);
+            else
+              block_body(std::integral_constant<int, 2>(), u, b);
           }
           load_block(u, b + PFB);
         }
@@ -1540,6 +1647,21 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
                      A.loss_out, 2.0 * A.loss_scale, dbg);
   MDE_LAUNCH_CHECK();
 #if MDE_RING_ABLATE
+  {
+    static int dl = 0;
+    if (++dl == 3) {
+      int nd = 0;
+      int hd[64][8];
+      (void)hipStreamSynchronize(A.st);
+      (void)hipMemcpyFromSymbol(&nd, HIP_SYMBOL(g_ring_ndiag), sizeof(int));
+      (void)hipMemcpyFromSymbol(hd, HIP_SYMBOL(g_ring_diag), sizeof(hd));
+      fprintf(stderr, "[mde ring diag] %d give-ups in the first launches\n", nd);
+      for (int k = 0; k < nd && k < 24; ++k)
+        fprintf(stderr, hd[k][0] == 1 ? "[mde ring diag] consumer wg %d wave %d: need %d ready %d m %d slot %d NB %d\n"
+                                      : "[mde ring diag] producer wg %d p %d: j %d minprog %d infl %d oldest %d j_hi %d\n",
+                hd[k][1], hd[k][2], hd[k][3], hd[k][4], hd[k][5], hd[k][6], hd[k][7]);
+    }
+  }
   if (dbg & 512) {
     static int launches = 0;
     if (++launches == 8) {
@@ -1631,6 +1753,15 @@ int mde_ring_try(mde_plan* plan, const float* X, int d, const mde_func* f, float
       rc = launch_ring<4, FN, LIN>(A, fn, nblocks);            \
     return rc == MDE_OK ? 1 : rc;                              \
   } while (0)
+#ifdef MDE_RING_MINIMAL
+  // (design experiments: only the headline instantiation, everything else on the CSR kernels)
+  if (d == 2 && f->kind_neg == MDE_F_NONE && f->kind == MDE_F_LOG1P && ea == 2) {
+    FnSingle<MDE_F_LOG1P, 2> fn{a};
+    rc = launch_ring<2, FnSingle<MDE_F_LOG1P, 2>, true>(A, fn, nblocks);
+    return rc == MDE_OK ? 1 : rc;
+  }
+  return 0;
+#else
   if (d == 2 || d == 3) {
     if (f->kind_neg == MDE_F_NONE) {
       if (f->kind == MDE_F_LOG1P && ea == 2) RING(FnSingle<MDE_F_LOG1P COMMA 2>, true);
@@ -1648,5 +1779,6 @@ int mde_ring_try(mde_plan* plan, const float* X, int d, const mde_func* f, float
     }
   }
   RING(FnRuntime, false);
+#endif
 #undef RING
 }

@@ -553,7 +553,11 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
             ahead = ahead_next
         else:
             problem.check_status()
+            # (not when the accepted t is not the last evaluated point -- new_xx is None: the next
+            # iteration first has to compute ||X|| with a statistics pass of its own, and that pass
+            # would overwrite the board slots the enqueued trial reports into)
             if (use_line_search and use_cached_loss and t != 0 and norm_grad > eps and iteration + 1 < max_iter
+                    and new_xx is not None
                     and not (snapshot_every is not None and (iteration + 1) % snapshot_every == 0)):
                 if turn is not None:
                     _lib.check(e.lib.mde_turn_enqueue(turn_ref, 0 if e.X is turn_bufs[0] else 1, float(t), e._stream))
