@@ -12,9 +12,10 @@ struct mde_ring_layout {
   int rows_per_block = 0, n_row_blocks = 0;
   int col_groups = 1;           // Q: workgroups per row block, each walking 1/Q of the chunks
   int chunk_cols = 0, n_chunks = 0;
+  int ring_off = 0, slots = 0;  // LDS byte offset of the chunk ring and its number of slots (depend on rows_per_block)
   int64_t n_iters = 0;          // wave iterations of all streams
   int64_t H = 0;                // padded entry count = 64 * n_iters
-  uint32_t* packed = nullptr;   // [H] LDS row address << 17 | ring byte offset
+  uint32_t* packed = nullptr;   // [H] absolute LDS addresses of x_v and x_u (ring_pack_word, mde_ring.hip)
   int32_t* eid = nullptr;       // [H] original edge id (parameter expansion), -1 for padding
   uint32_t* hdr = nullptr;      // [2 * n_iters] chunk window | padding flag and loss class of an iteration
   int32_t* wave_iter = nullptr; // [n_row_blocks * col_groups * NCW + 1]

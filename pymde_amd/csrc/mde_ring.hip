@@ -49,35 +49,44 @@
 #include "mde_common.h"
 #include "mde_functions.h"
 #include "mde_plan.h"
-#include "mde_ring_place.h"
 #define COMMA ,
 
-// Static LDS map (bytes).  The region bases are compile-time constants below 2^16, so the
-// kernel's LDS instructions carry them as immediate offsets and the packed words hold absolute
-// row addresses.
-#define MDE_RING_XR_OFF 0          // x_v of the block's rows (+ one dummy slot), control words at the tail
-#define MDE_RING_GR_OFF 32768      // gradient accumulators (same slots)
-#define MDE_RING_OFF 65536         // the chunk ring
-#define MDE_RING_BYTES 98304
-#define MDE_RING_CTRL_OFF (32768 - 256)
-#define MDE_RING_CTRL_PROG (MDE_RING_CTRL_OFF)        // int prog[16]: oldest chunk consumer w still reads
-#define MDE_RING_CTRL_F (MDE_RING_CTRL_OFF + 64)      // int F[NPROD]: next chunk whose pieces of producer p have not landed
-#define MDE_RING_CTRL_CB (MDE_RING_CTRL_OFF + 96)     // float[8]: parameter codebook
+// LDS map (bytes) of the kernel, per embedding dimension d:
+//   [0, XCAP)              x_v of the block's rows (R rows + 32 dummy rows for padding lanes)
+//   [XCAP, XCAP + 256)     control words: prog[16], F[8], parameter codebook[8]
+//   [XCAP + 256, ...)      gradient accumulators, same slots as x_v (GR_OFF = XCAP + 256)
+//   [ring_off, 160 KB)     the chunk ring: S slots of CBYTES bytes (ring_off and S depend on R)
+// XCAP (= the tallest row block) is a compile-time constant per d chosen so that GR_OFF + row
+// address stays below 2^16: the accumulator and control accesses carry their region base as the
+// 16-bit immediate offset of the LDS instruction.  The packed words hold ABSOLUTE LDS addresses.
+// Round 4: row blocks twice as tall as round 3's (the staging volume -- every workgroup streams
+// the whole table past its rows -- is what the kernel's duration followed), which leaves ~36 KB of
+// ring at d = 2; the chunks in flight therefore live in the producers' VGPRs, not in ring slots.
+#define MDE_RING_LDS_BYTES 163840
+__host__ __device__ constexpr int ring_row_cap(int d) { return d == 1 ? 12288 : (d == 2 ? 7872 : (d == 3 ? 5216 : 3936)); }
+__host__ __device__ constexpr int ring_ctrl_off(int d) { return (ring_row_cap(d) + 32) * 4 * d; }
+__host__ __device__ constexpr int ring_gr_off(int d) { return ring_ctrl_off(d) + 256; }
+#define MDE_RING_CTRL_PROG(d) (ring_ctrl_off(d))        // int prog[16]: oldest chunk consumer w still reads
+#define MDE_RING_CTRL_F(d) (ring_ctrl_off(d) + 64)      // int F[NPROD]: next chunk of producer p that has not landed
+#define MDE_RING_CTRL_CB(d) (ring_ctrl_off(d) + 96)     // float[8]: parameter codebook
 #ifndef MDE_RING_NCW
-#define MDE_RING_NCW 10            // consumer waves (config 4, round 3: 8 -> 0.243, 10 -> 0.230, 12 -> 0.238, 14 -> 0.246 ms)
+#define MDE_RING_NCW 8             // consumer waves (two per SIMD; with the 4 producers every SIMD holds 3 waves)
 #endif
 #ifndef MDE_RING_CSLEEP
 #define MDE_RING_CSLEEP 1          // s_sleep argument of a consumer waiting for a chunk (x 64 clocks)
 #endif
 #ifndef MDE_RING_PRODPRIO
-#define MDE_RING_PRODPRIO 3
+#define MDE_RING_PRODPRIO 0        // (round 3's LDS-DMA producers ran at priority 3; the VGPR-staged ones take issue slots from the consumers: 0.208 -> 0.192 ms at 0)
+#endif
+#ifndef MDE_RING_CONSPRIO
+#define MDE_RING_CONSPRIO 0
 #endif
 #ifndef MDE_RING_NPROD
-#define MDE_RING_NPROD 2           // producer waves
+#define MDE_RING_NPROD 4           // producer waves
 #endif
 #define MDE_RING_BS (64 * (MDE_RING_NCW + MDE_RING_NPROD))
 #ifndef MDE_RING_DEPTH
-#define MDE_RING_DEPTH 2           // chunks in flight per producer (<= 4)
+#define MDE_RING_DEPTH 2           // chunks in flight (in VGPRs) per producer wave
 #endif
 #ifndef MDE_RING_PFB
 #define MDE_RING_PFB 3             // stream blocks (4 iterations each) in flight per consumer wave
@@ -86,29 +95,28 @@
 #ifndef MDE_RING_ABLATE
 #define MDE_RING_ABLATE 0
 #endif
-#ifndef MDE_RING_DMA_IMM
-#define MDE_RING_DMA_IMM 1
-#endif
 #define MDE_RING_DONE 0x7fffffff
 
-// chunk geometry per embedding dimension: CBYTES bytes (PIECES x 1 KiB DMA pieces) per chunk
+// chunk geometry per embedding dimension: CBYTES bytes (PIECES x 1 KiB) per chunk
 #ifndef MDE_RING_C2
-#define MDE_RING_C2 1024
+#define MDE_RING_C2 512
 #endif
-__host__ __device__ constexpr int ring_chunk_cols(int d) { return d == 1 ? 2048 : (d == 2 ? MDE_RING_C2 : 512); }
+__host__ __device__ constexpr int ring_chunk_cols(int d) { return d == 1 ? 1024 : (d == 2 ? MDE_RING_C2 : 256); }
 __host__ __device__ constexpr int ring_chunk_bytes(int d) { return ring_chunk_cols(d) * 4 * d; }
-__host__ __device__ constexpr int ring_slots(int d) { return MDE_RING_BYTES / ring_chunk_bytes(d); }
-// an iteration may reference chunks m .. m + span: the ring also holds the chunks in flight
-// (tools/dmaprobe: the LDS-DMA fill needs ~48 KB in flight per CU to run at its 22 - 33 clocks per KiB;
-// with 32 KB it drops to 42 and everything waits for the producers) and two slots of slack
-__host__ __device__ constexpr int ring_max_span(int d) {
+// ring placement for row blocks of R rows
+__host__ __device__ constexpr int ring_off_for(int d, int R) { return (ring_gr_off(d) + (R + 32) * 4 * d + 255) / 256 * 256; }
+__host__ __device__ constexpr int ring_slots_for(int d, int R) {
+  return (MDE_RING_LDS_BYTES - ring_off_for(d, R)) / ring_chunk_bytes(d) > 32 ? 32
+                                                                               : (MDE_RING_LDS_BYTES - ring_off_for(d, R)) / ring_chunk_bytes(d);
+}
+// a PAIR of iterations may reference chunks m .. m + span; the ring also needs slack for the
+// spread between the consumer waves (a slot is free once ALL of them are past its chunk)
+__host__ __device__ constexpr int ring_max_span(int S) {
 #ifdef MDE_RING_SPAN
   return MDE_RING_SPAN;
 #endif
-  // (measured at config 4: 4..6 chunks of window leave the waves the most slack; 8 costs 4 %)
-  constexpr int inflight = MDE_RING_NPROD * MDE_RING_DEPTH;
-  // (the window is anchored per pair of iterations: the second one sees what the first left of it)
-  return ring_slots(d) - inflight - 2 > 6 ? 6 : ring_slots(d) - inflight - 2;
+  // (config 4 at 9 slots: windows of 4 / 5 / 6 chunks measure 0.188 / 0.190 / 0.194 ms, 3 costs padding: 0.201)
+  return S - 5 > 6 ? 6 : (S - 5 < 2 ? 2 : S - 5);
 }
 
 // header word of a wave iteration: [15:0] m = lowest chunk referenced, [20:16] span (highest = m +
@@ -226,14 +234,14 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
                                                       const int32_t* __restrict__ iter_base,
                                                       int32_t* __restrict__ it_ent, int32_t* __restrict__ it_cnt,
                                                       int32_t* __restrict__ it_m) {
-  __shared__ int flag[4096];                // per row of the block: priority of the entry that holds it
+  __shared__ int flag[12288 + 32];          // per row of the block: priority of the entry that holds it
   __shared__ int cq_pos[2][MDE_RING_CARRY]; // waiting entries (sorted position), double buffered
   __shared__ int cq_age[2][MDE_RING_CARRY];
   __shared__ int em[64];                    // entries of the iteration being formed
   __shared__ int rcnt[32], ccnt[32];        // entries per bank class in it
   const int i = blockIdx.x, lane = threadIdx.x;
   if (i >= nseg) return;
-  for (int r = lane; r < 4096; r += 64) flag[r] = 0x7fffffff;
+  for (int r = lane; r < 12288 + 32; r += 64) flag[r] = 0x7fffffff;
   __syncthreads();
   const int beg = seg[i], end = seg[i + 1];
   const int rb = (i / MDE_RING_NCW) / Q;
@@ -371,8 +379,55 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
 #define MDE_RING_HW 4
 #define MDE_RING_H3_PAD 4u
 
-// One wave per iteration: deal its <= 64 entries to the lanes (ring_place: bank classes split
-// evenly over the 32-lane read passes and the 16-lane write passes), pad to 64 with dummies, write
+// Packed word of an entry (absolute LDS byte addresses, fixed when the layout is built):
+//   d = 2:  [2:0] parameter codebook index (0 when the parameters stream as fp32)
+//           [15:3] x_v address / 8 (the accumulator sits GR_OFF above it)   [30:16] x_u address / 8
+//   else:   [15:0] x_v address (a multiple of 4)                            [31:16] x_u address / 4
+__host__ __device__ inline uint32_t ring_pack_word(int d, uint32_t rowaddr, uint32_t coladdr) {
+  return d == 2 ? (rowaddr | ((coladdr >> 3) << 16)) : (rowaddr | ((coladdr >> 2) << 16));
+}
+
+// Lane placement of one iteration, wave-parallel (round 3 ran a serial Euler split on one lane per
+// iteration: 170 ms of the layout build).  LDS bank rules of gfx950 (tools/valuprobe): a wave64 b64 read
+// is served in two passes of 32 lanes and costs, per pass, the deepest bank class (8-byte slot mod
+// 32); a b64 write in four passes of 16 lanes over 16 classes.  The row side carries three of the
+// four random accesses of an entry (x_v, accumulator read, accumulator write), so the ROW classes
+// are dealt evenly: entries of a class alternate between the two 32-lane halves, and inside a half the
+// entries of a class mod 16 alternate between its two 16-lane quarters (classes with an odd count hand
+// their extra entry to the halves / quarters in turn).  The column classes are capped by the
+// scheduler and otherwise left as they fall.
+// in: act (lane holds an entry), rc (its row class, 0..31).  out: the lane that handles the entry.
+__device__ __forceinline__ int ring_place_wave(bool act, int rc, int lane) {
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  int rank = 0, par = 0, oddacc = 0;
+  for (int c = 0; c < 32; ++c) {
+    const unsigned long long m = __ballot(act && rc == c);
+    if (rc == c) {
+      rank = __popcll(m & lt);
+      par = oddacc & 1;
+    }
+    oddacc += __popcll(m) & 1;
+  }
+  const int half = (rank + par) & 1;
+  int quarter = 0;
+  for (int h = 0; h < 2; ++h) {
+    int oa = 0;
+    for (int c = 0; c < 16; ++c) {
+      const unsigned long long m = __ballot(act && half == h && (rc & 15) == c);
+      if (half == h && (rc & 15) == c) quarter = (__popcll(m & lt) + (oa & 1)) & 1;
+      oa += __popcll(m) & 1;
+    }
+  }
+  int pos = 0;
+  for (int g = 0; g < 4; ++g) {
+    const unsigned long long m = __ballot(act && half * 2 + quarter == g);
+    if (half * 2 + quarter == g) pos = __popcll(m & lt);
+  }
+  // (a quarter holds at most 16: a half gets at most ceil(cnt / 2) <= 32 entries, a quarter half of that)
+  return half * 32 + quarter * 16 + pos;
+}
+
+// One wave per iteration: deal its <= 64 entries to the lanes, pad to 64 with dummies, write
 // packed words, edge ids and the header.
 __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int32_t* __restrict__ it_ent,
                                                          const int32_t* __restrict__ it_cnt,
@@ -382,16 +437,15 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int3
                                                          const int32_t* __restrict__ hrow,
                                                          const int32_t* __restrict__ nbr,
                                                          const int32_t* __restrict__ eid, int R, int Q, int C, int S,
-                                                         int JB, int d, int row_lo, int place,
+                                                         int ring_off, int JB, int d, int row_lo, int place,
                                                          uint32_t* __restrict__ packed,
                                                          int32_t* __restrict__ peid, uint32_t* __restrict__ hdr) {
-  __shared__ RingPlaceScratch scratch[MDE_BLOCK / 64];
-  __shared__ uint8_t s_rc[MDE_BLOCK / 64][64], s_cc[MDE_BLOCK / 64][64], s_lane[MDE_BLOCK / 64][64],
-      s_free[MDE_BLOCK / 64][64];
+  __shared__ uint8_t s_taken[MDE_BLOCK / 64][64], s_free[MDE_BLOCK / 64][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int64_t nw = ((int64_t)gridDim.x * MDE_BLOCK) >> 6;
   const uint32_t JM = (1u << JB) - 1u;
   const int sh = ring_cls_shift(d), cm = ring_cls_mask(d);
+  const uint32_t cbytes = (uint32_t)C * 4u * (uint32_t)d;
   // (the waves of a block run the same number of trips: the barriers below are block-wide)
   for (int64_t itb = (int64_t)blockIdx.x * (MDE_BLOCK / 64); itb < nit; itb += nw) {
     const int64_t it = itb + wv;
@@ -400,7 +454,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int3
     const int cnt = cw & 0xff;
     const bool act = valid && lane < cnt;
     uint32_t key = 0, q = 0, col = 0, rowaddr = 0, ring = 0;
-    int grow = 0;
+    int grow = 0, rcls = 0;
     if (act) {
       const int pos = it_ent[(size_t)it * 64 + lane];
       key = keys[pos];
@@ -410,20 +464,20 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int3
       rowaddr = (uint32_t)(grow - rb * R) * 4u * (uint32_t)d;
       const uint32_t j = key & JM;
       col = (uint32_t)nbr[q];
-      ring = ((j % (uint32_t)S) * (uint32_t)C + (col - j * (uint32_t)C)) * 4u * (uint32_t)d;
-      s_rc[wv][lane] = (uint8_t)((rowaddr >> sh) & (uint32_t)cm);
-      s_cc[wv][lane] = (uint8_t)((ring >> sh) & (uint32_t)cm);
+      ring = (uint32_t)ring_off + (j % (uint32_t)S) * cbytes + (col - j * (uint32_t)C) * 4u * (uint32_t)d;
+      rcls = (int)((rowaddr >> sh) & (uint32_t)cm);
     }
+    s_taken[wv][lane] = 0;
     __syncthreads();
-    if (lane == 0 && valid) {
-      if (place) {
-        ring_place(cnt, s_rc[wv], s_cc[wv], s_lane[wv], s_free[wv], scratch[wv]);
-      } else {
-        for (int e = 0; e < 64; ++e) {
-          s_lane[wv][e] = (uint8_t)e;
-          if (e >= cnt) s_free[wv][e - cnt] = (uint8_t)e;
-        }
-      }
+    int l = lane;
+    if (place) l = ring_place_wave(act, rcls, lane);
+    if (act) s_taken[wv][l] = 1;
+    __syncthreads();
+    {
+      // the lanes nobody took, in ascending order, for the padding entries
+      const bool fr = !s_taken[wv][lane];
+      const unsigned long long fm = __ballot(fr);
+      if (fr) s_free[wv][__popcll(fm & ((1ull << lane) - 1ull))] = (uint8_t)lane;
     }
     __syncthreads();
     // whose loss terms: the entry whose row is the smaller vertex of the edge
@@ -440,17 +494,14 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int3
     // element (iteration it, lane l) of a stream lives at ((it / 4) * 64 + l) * 4 + it % 4
     const size_t base = ((size_t)(it >> 2) * 64) * 4 + (size_t)(it & 3);
     if (act) {
-      const int l = s_lane[wv][lane];
-      // (the column field is the ring byte offset + 16: the kernel reads at ring base - 16 + field,
-      // which fits the 16-bit offset of the LDS instruction)
-      packed[base + (size_t)l * 4] = (rowaddr << 17) | (ring + 16u);
+      packed[base + (size_t)l * 4] = ring_pack_word(d, rowaddr, ring);
       peid[base + (size_t)l * 4] = eid[q];
     } else if (valid) {
-      // padding: a dummy row slot of the lane's own bank class, a resident column (first of chunk m)
-      const int l = s_free[wv][lane - cnt];
-      packed[base + (size_t)l * 4] = (((uint32_t)(R + (l & 31)) * 4u * (uint32_t)d) << 17) |
-                                     ((mpad % (uint32_t)S) * (uint32_t)C * 4u * (uint32_t)d + 16u);
-      peid[base + (size_t)l * 4] = -1;
+      // padding: a dummy row slot of the lane's own bank class, a resident column
+      const int lf = s_free[wv][lane - cnt];
+      packed[base + (size_t)lf * 4] = ring_pack_word(d, (uint32_t)(R + (lf & 31)) * 4u * (uint32_t)d,
+                                                     (uint32_t)ring_off + (mpad % (uint32_t)S) * cbytes);
+      peid[base + (size_t)lf * 4] = -1;
     }
     if (lane == 0 && valid) {
       hdr[MDE_RING_HW * it] = m;
@@ -523,7 +574,7 @@ static int bits_for_u64(uint64_t maxval) {
 }
 
 struct RingSizes {
-  int R, NRB, Q, C, NC, S, JB;
+  int R, NRB, Q, C, NC, S, JB, ring_off, span;
 };
 
 // Decide the block height and the column groups for dimension d; false when the layout is not
@@ -533,12 +584,13 @@ static bool choose_sizes(const mde_plan* plan, int d, RingSizes* z) {
   if (d < 1 || d > 4 || nloc <= 0 || plan->H <= 0) return false;
   const int mode = panel_mode();
   if (mode == 0) return false;
-  // Geometry: NRB row blocks x Q column groups ~ one workgroup per CU (256).  Tall blocks first
-  // (many rows per consumer wave keep the distinct-rows iterations full, and the staging volume is
-  // NRB x table bytes), up to what fits below the control words; the CUs left over are filled
-  // with column groups of at least `minch` chunks each (one ring window).  Config 4 (n = 1M, d = 2):
-  // 253 blocks of 3968 rows, Q = 1; an 8-way shard of it: 32 blocks x 8 groups; a dense 40k-node
-  // problem: 32 blocks of 1280 rows x 8 groups of 5 chunks.
+  // Geometry: NRB row blocks x Q column groups ~ one workgroup per CU (256).  Tall blocks first:
+  // the staging volume is NRB x table bytes (every workgroup streams the table past its rows), and
+  // many rows per consumer wave keep the distinct-rows iterations full.  The block height is capped
+  // by what fits the LDS next to a ring of >= 8 chunks (ring_row_cap); the CUs left over are filled
+  // with column groups of at least `minch` chunks each (one ring window), whose partial rows a second
+  // launch adds.  Config 4 (n = 1M, d = 2): 128 blocks of 7872 rows x 2 column groups; an 8-way shard
+  // of it: 16 blocks x 16 groups; a dense 40k-node problem: 32 blocks of 1280 rows x 8 groups.
   const int C = ring_chunk_cols(d);
   const int64_t nc = (plan->n + C - 1) / C;
   if (nc > 65535 || nc < 2) return false;
@@ -549,7 +601,7 @@ static bool choose_sizes(const mde_plan* plan, int d, RingSizes* z) {
   if (getenv("MDE_RING_ROWS")) pr = atoi(getenv("MDE_RING_ROWS"));
   if (pr > nloc) pr = nloc;
   pr = ((pr + 63) / 64) * 64;
-  const int64_t pr_max = (MDE_RING_CTRL_OFF / (4 * d) - 32) / 64 * 64;  // 32 dummy row slots for padding lanes
+  const int64_t pr_max = ring_row_cap(d);
   if (pr > pr_max) pr = pr_max;
   const int64_t nrb = (nloc + pr - 1) / pr;
   int Q = (int)std::min<int64_t>(qmax, std::max<int64_t>(1, 256 / nrb));
@@ -562,14 +614,21 @@ static bool choose_sizes(const mde_plan* plan, int d, RingSizes* z) {
     // half-edges that 64 B of L2 traffic per 8-byte gather is what the CSR kernel spends its time on
     // (40k nodes, 100M half-edges: 0.60 -> 0.30 ms per evaluation)
     if ((int64_t)plan->n * d * 4 < (6 << 20) && plan->H < ((int64_t)16 << 20)) return false;
-    if ((double)plan->H / ((double)nrb * MDE_RING_NCW * (double)nc) < 64.0 / (0.6 * ring_max_span(d))) return false;
   }
+  const int S = ring_slots_for(d, (int)pr);
+  if (S < 6) return false;
+  int span = ring_max_span(S);
+  if (getenv("MDE_RING_SPAN")) span = std::min(S - 2, std::max(1, atoi(getenv("MDE_RING_SPAN"))));
+  // auto: a pair of 64-entry iterations must fit the ring window
+  if (mode != 1 && (double)plan->H / ((double)nrb * MDE_RING_NCW * (double)nc) < 128.0 / (0.8 * span)) return false;
   z->R = (int)pr;
   z->NRB = (int)nrb;
   z->Q = Q;
   z->C = C;
   z->NC = (int)nc;
-  z->S = ring_slots(d);
+  z->S = S;
+  z->ring_off = ring_off_for(d, (int)pr);
+  z->span = span;
   z->JB = jb;
   return true;
 }
@@ -670,7 +729,7 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   const int cap_default = d == 4 ? 8 : 4;
   const int cap = getenv("MDE_RING_CAP") ? std::max(1, atoi(getenv("MDE_RING_CAP"))) : cap_default;
   const int place = getenv("MDE_RING_PLACE") ? atoi(getenv("MDE_RING_PLACE")) : 1;
-  const int span = getenv("MDE_RING_SPAN") ? std::min(ring_max_span(d), std::max(1, atoi(getenv("MDE_RING_SPAN")))) : ring_max_span(d);
+  const int span = z.span;
   hipLaunchKernelGGL(k_ring_schedule<false>, dim3(nseg), dim3(64), 0, st, nseg, seg, bounds, keys2, vals2, hrow, plan->nbr,
                      JM, span, z.R, z.Q, z.NC, d, cap, panel_mode() == 1 ? 0 : 4, iters, nullptr, nullptr, nullptr, nullptr);
   RB(hipGetLastError());
@@ -700,7 +759,7 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   RB(hipGetLastError());
   hipLaunchKernelGGL(k_ring_pack, dim3(mde_grid((int64_t)total_iters * 64, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st,
                      (int64_t)total_iters, it_ent, it_cnt, it_m, keys2, vals2, hrow, plan->nbr, plan->eid, z.R, z.Q, z.C,
-                     z.S, z.JB, d, (int)plan->row_lo, place, packed, peid, hdr);
+                     z.S, z.ring_off, z.JB, d, (int)plan->row_lo, place, packed, peid, hdr);
   RB(hipGetLastError());
   hipLaunchKernelGGL(k_ring_block_class, dim3((unsigned)((total_iters / 4 + MDE_BLOCK - 1) / MDE_BLOCK)), dim3(MDE_BLOCK), 0, st,
                      (int64_t)(total_iters / 4), hdr);
@@ -760,6 +819,8 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   L.col_groups = z.Q;
   L.chunk_cols = z.C;
   L.n_chunks = z.NC;
+  L.ring_off = z.ring_off;
+  L.slots = z.S;
   L.n_iters = total_iters;
   L.H = Hp;
   L.packed = packed;
@@ -992,49 +1053,12 @@ __device__ __forceinline__ void ring_st(char* p, const float (&v)[D]) {
   }
 }
 
-// one 1 KiB LDS-DMA piece: lane l copies the 16 bytes at gsrc to LDS byte address lds_dst + 16 l
-// (M0 carries the wave-uniform LDS base; hipcc neither counts the load nor preserves M0 around
-// the statement, so M0 is saved and restored inside it and the waits are explicit)
-__device__ __forceinline__ void ring_dma16(const void* gsrc, uint32_t lds_dst) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gsrc), "s"(lds_dst)
-      : "memory");
-}
-
-// N <= 4 consecutive pieces in one statement (one M0 set-up; the 13-bit instruction offset covers
-// 4 KiB)
-template <int N>
-__device__ __forceinline__ void ring_dma_pieces(const void* gsrc, uint32_t lds_dst) {
-  static_assert(N >= 1 && N <= 4, "1..4 pieces");
-  unsigned keep;
-  if constexpr (N == 1)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-  else if constexpr (N == 2)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:1024\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-  else if constexpr (N == 3)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-  else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:1024\n\tglobal_load_lds_dwordx4 %1, off offset:2048\n\t"
-                 "global_load_lds_dwordx4 %1, off offset:3072\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-
 // control words: explicit LDS instructions on absolute addresses (a `volatile` generic pointer
 // would turn into flat loads / stores and drag vmcnt(0) waits into the stream pipeline)
 __device__ __forceinline__ void ring_ctrl_store(uint32_t addr, int v) {
   asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
-// the consumers' control-word store as a compiler-counted LDS instruction
+// the same as a compiler-counted LDS instruction (its lgkmcnt bookkeeping stays exact)
 __device__ __forceinline__ void ring_ctrl_store_counted(char* lds_base, uint32_t addr, int v) {
   typedef __attribute__((address_space(3))) volatile int* lds_vint;
   *(lds_vint)(lds_base + addr) = v;
@@ -1048,7 +1072,7 @@ __device__ __forceinline__ int ring_ctrl_load(uint32_t addr) {
 #if MDE_RING_ABLATE
 // timing probes (MDE_RING_DBG & 512): per workgroup, shader clocks summed over its waves
 //   [0] consumer loop, [1] of it inside the chunk poll, [2] poll trips, [3] producer loop,
-//   [4] of it blocked on a slot, [5] of it waiting for DMA pieces to land, [6] slot polls
+//   [4] of it blocked on a slot, [6] slot polls
 __device__ unsigned long long g_ring_probe[8][1024];
 // hang diagnosis: a poll that spins longer than MDE_RING_SPINMAX trips leaves a record and gives up
 __device__ int g_ring_diag[64][8];
@@ -1063,11 +1087,11 @@ __device__ int g_ring_ndiag;
 // LIN: f(0) = 0 whatever the lane's parameter is once that parameter is 0 (the functors
 // instantiated below): padding lanes carry parameter 0, sit on a dummy row and need no masking.
 // The loss term of an edge is added on ONE of its two entries (the one whose row is the smaller
-// vertex; header word 1 says, per iteration, none / all / test per lane), so half of the
-// iterations skip the loss arithmetic altogether; the gradient is owner-computes as before.
+// vertex; the header says, per block of four iterations, none / all / test per lane), so half of the
+// blocks skip the loss arithmetic altogether; the gradient is owner-computes as before.
 template <int D, class Fn, bool HAS_GRAD, bool CB, bool LIN>
 __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
-    int nloc, int row_lo, int n, int R, int Q, int NC, const int32_t* __restrict__ wave_iter,
+    int nloc, int row_lo, int n, int R, int Q, int NC, int ring_off, int S, const int32_t* __restrict__ wave_iter,
     const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ packed, const float* __restrict__ a0,
     const float* __restrict__ a1, int a0_scalar, int a1_scalar, const float* __restrict__ X,
     float* __restrict__ grad, float* __restrict__ partial, double* __restrict__ loss_partials, Fn fn,
@@ -1076,20 +1100,20 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
 #ifndef MDE_RING_ABLATE_MASK
 #define MDE_RING_ABLATE_MASK (~0)  // (a narrower mask lets hipcc fold the other probes away)
 #endif
-  const int dbg = dbg_arg & (MDE_RING_ABLATE_MASK);  // timing probes (tools/abl.sh): 1 consumers never wait, 2 no staging, 4 no evaluation, 8 producers never wait, 64 / 128 a role skips its loop
-  const unsigned long long t_begin = __builtin_readcyclecounter();
+  const int dbg = dbg_arg & (MDE_RING_ABLATE_MASK);  // timing probes: 1 consumers never wait, 8 producers never wait, 64 / 128 a role skips its loop, 512 clocks
 #else
   constexpr int dbg = 0;
 #endif
   constexpr int BS = MDE_RING_BS, NCW = MDE_RING_NCW, NPROD = MDE_RING_NPROD;
-  constexpr int GR_OFF = MDE_RING_GR_OFF, RING_OFF = MDE_RING_OFF;
-  constexpr int C = ring_chunk_cols(D), CBYTES = ring_chunk_bytes(D), S = ring_slots(D), PIECES = CBYTES / 1024;
+  constexpr int GR_OFF = ring_gr_off(D), CTRL_PROG = MDE_RING_CTRL_PROG(D), CTRL_F = MDE_RING_CTRL_F(D), CTRL_CB = MDE_RING_CTRL_CB(D);
+  constexpr int C = ring_chunk_cols(D), CBYTES = ring_chunk_bytes(D), PIECES = CBYTES / 1024;
+  static_assert(GR_OFF + (ring_row_cap(D) + 32) * 4 * D <= 65536 + GR_OFF && GR_OFF < 65536 && CTRL_CB + 32 < 65536,
+                "region bases must fit the 16-bit offset of the LDS instructions");
+  static_assert(NPROD <= 8 && NCW <= 16, "control-word layout");
   // statically sized: the LDS addresses unpacked from the stream are absolute
-  __shared__ __attribute__((aligned(16))) char L[MDE_RING_OFF + MDE_RING_BYTES];
+  __shared__ __attribute__((aligned(16))) char L[MDE_RING_LDS_BYTES];
   float* XR = reinterpret_cast<float*>(L);           // x_v of the block's rows
   float* GR = reinterpret_cast<float*>(L + GR_OFF);  // gradient accumulators (same slots)
-  int* prog = reinterpret_cast<int*>(L + MDE_RING_CTRL_PROG);  // (prologue only; polled with ring_ctrl_*)
-  int* F = reinterpret_cast<int*>(L + MDE_RING_CTRL_F);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keep it scalar
   // block b = rb * Q + qg: row block rb, column group qg owns chunks [j_lo, j_hi)
@@ -1104,171 +1128,141 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
   // ---- prologue: accumulators, x_v, control words
   {
     float4* z = reinterpret_cast<float4*>(L + GR_OFF);
-    for (int i = tid; i < (MDE_RING_OFF - GR_OFF) / 16; i += BS) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int nz = ((R + 32) * 4 * D + 15) / 16;
+    for (int i = tid; i < nz; i += BS) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* Xrow = X + (size_t)(row_lo + r0) * D;
     if ((reinterpret_cast<uintptr_t>(Xrow) & 15) == 0) {
-      // 16-byte loads, all issued before the first LDS store
+      // 16-byte loads, eight in flight per thread
       const ring_f4* X4 = reinterpret_cast<const ring_f4*>(Xrow);
       ring_f4* XR4 = reinterpret_cast<ring_f4*>(L);
       const int n4 = (nr * D) >> 2;
-      constexpr int PER = (MDE_RING_CTRL_OFF / 16 + BS - 1) / BS;
-      ring_f4 t[PER];
+      for (int i0 = 0; i0 < n4; i0 += 8 * BS) {
+        ring_f4 t[8];
 #pragma unroll
-      for (int k = 0; k < PER; ++k) t[k] = X4[min(tid + k * BS, max(n4 - 1, 0))];
+        for (int k = 0; k < 8; ++k) t[k] = X4[min(i0 + tid + k * BS, max(n4 - 1, 0))];
 #pragma unroll
-      for (int k = 0; k < PER; ++k)
-        if (tid + k * BS < n4) XR4[tid + k * BS] = t[k];
+        for (int k = 0; k < 8; ++k)
+          if (i0 + tid + k * BS < n4) XR4[i0 + tid + k * BS] = t[k];
+      }
       for (int i = (n4 << 2) + tid; i < nr * D; i += BS) XR[i] = Xrow[i];
     } else {
       for (int i = tid; i < nr * D; i += BS) XR[i] = Xrow[i];
     }
     if (tid < 32 * D) XR[R * D + tid] = 0.0f;  // the dummy rows
+    int* prog = reinterpret_cast<int*>(L + CTRL_PROG);
+    int* F = reinterpret_cast<int*>(L + CTRL_F);
     if (tid < 16) prog[tid] = (tid < NCW) ? j_lo : MDE_RING_DONE;
     if (tid >= 16 && tid < 16 + NPROD) F[tid - 16] = j_lo + (tid - 16);
     if (CB && tid >= 32 && tid < 32 + MDE_RING_CB_VALUES)
-      reinterpret_cast<float*>(L + MDE_RING_CTRL_CB)[tid - 32] = a0[tid - 32] * Fn::kParamScale;
+      reinterpret_cast<float*>(L + CTRL_CB)[tid - 32] = a0[tid - 32] * Fn::kParamScale;
   }
   __syncthreads();
-  // No compiler-counted load may be pending past this point: the producers' LDS-DMA pieces are
-  // invisible to hipcc's vmcnt bookkeeping, and a wait it inserts for one of ITS loads (or for
-  // re-using such a load's destination register) would drain the pieces in flight with it.
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
   float loss = 0.0f, loss2 = 0.0f;  // (the fused Log1p path keeps the log2 terms and the corrections apart)
 
   if (wave >= NCW) {
-    __builtin_amdgcn_s_setprio(MDE_RING_PRODPRIO);  // the DMA issue ahead of the consumers' instructions (-2.5 %)
-    // ---------------- producer p: chunks j_lo + p, j_lo + p + NPROD, ...
+    if (MDE_RING_PRODPRIO) __builtin_amdgcn_s_setprio(MDE_RING_PRODPRIO);
+    // ---------------- producer p: chunks j_lo + p, j_lo + p + NPROD, ...  staged through VGPRs:
+    // DEPTH chunks are in flight as plain 16-byte global loads (compiler-counted), the oldest one is
+    // written into its ring slot (ds_write_b128) once every consumer is past the chunk that slot
+    // held, and published.  The chunks in flight need no ring slot (round 3's LDS-DMA parked every
+    // chunk in flight in a slot: with row blocks twice as tall the ring is too small for that).
     const int p = wave - NCW;
     const char* Xb = reinterpret_cast<const char*>(X);
-    const char* Xl = Xb + lane * 16;
     const size_t nbytes = (size_t)n * D * 4;
-    const size_t last16 = nbytes - 16;
-    int minprog = j_lo, infl = 0;
-    int slot = (j_lo + p) % S;
-    int j = j_lo + p;         // next chunk to issue
-    int oldest = j;           // oldest chunk in flight (valid while infl > 0)
-    // wait for the oldest chunk in flight and publish it (F[p] = my next chunk that has not landed)
-#if MDE_RING_ABLATE
-    unsigned long long pr_t0 = RING_CLK(), pr_blocked = 0, pr_retire = 0, pr_polls = 0;
-#endif
-    auto retire = [&]() __attribute__((always_inline)) {
-#if MDE_RING_ABLATE
-      const unsigned long long tr0 = RING_CLK();
-#endif
-      if (infl == 4)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * 3) : "memory");
-      else if (infl == 3)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES * 2) : "memory");
-      else if (infl == 2)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
-      else
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      oldest += NPROD;
-      ring_ctrl_store(MDE_RING_CTRL_F + 4u * (uint32_t)p, oldest);
-      --infl;
-#if MDE_RING_ABLATE
-      pr_retire += RING_CLK() - tr0;
-#endif
+    const size_t last16 = nbytes - 16;  // (X is 16-byte aligned, n * D * 4 >= 16: checked by the launcher)
+    constexpr int DEPTH = MDE_RING_DEPTH;
+    ring_f4 buf[DEPTH][PIECES];
+    auto fetch = [&](int k, int j) __attribute__((always_inline)) {
+      // (a chunk past the end of this producer's range: clamped, harmless, never written)
+      const size_t off0 = (size_t)min(j, NC - 1) * CBYTES + (size_t)lane * 16;
+#pragma unroll
+      for (int i = 0; i < PIECES; ++i) {
+        const size_t off = off0 + (size_t)i * 1024;
+        buf[k][i] = *reinterpret_cast<const ring_f4*>(Xb + (off < last16 ? off : last16));
+      }
     };
-    static_assert(MDE_RING_DEPTH >= 1 && MDE_RING_DEPTH <= 4, "retire() spells out the wait counts of up to four chunks in flight");
-    while (j < j_hi && !(dbg & 128)) {
-      // slot j % S still holds chunk j - S until every consumer is past it
-      if (j - S >= minprog && !(dbg & 8)) {
+    int minprog = j_lo;
 #if MDE_RING_ABLATE
-        const unsigned long long tb0 = RING_CLK();
-        ++pr_polls;
+    unsigned long long pr_t0 = RING_CLK(), pr_blocked = 0, pr_polls = 0;
 #endif
-        // one LDS read (lane w = consumer w), then a scalar minimum over the consumers' lanes
-        const int v = ring_ctrl_load(MDE_RING_CTRL_PROG + 4u * (uint32_t)(lane & 15));
-        int mn = __builtin_amdgcn_readlane(v, 0);
 #pragma unroll
-        for (int w = 1; w < NCW; ++w) mn = min(mn, __builtin_amdgcn_readlane(v, w));
-        minprog = mn;
-        if (j - S >= minprog) {
-          // blocked: meanwhile publish what has landed (a consumer may be waiting for exactly that)
-          if (infl > 0)
-            retire();
-          else
-            __builtin_amdgcn_s_sleep(1);
+    for (int k = 0; k < DEPTH; ++k) fetch(k, j_lo + p + k * NPROD);
+    int slot = (j_lo + p) % S;
+    for (int j0 = j_lo + p; j0 < j_hi && !(dbg & 128); j0 += DEPTH * NPROD) {
+#pragma unroll
+      for (int k = 0; k < DEPTH; ++k) {
+        const int j = j0 + k * NPROD;
+        if (j < j_hi) {
+          // slot j % S still holds chunk j - S until every consumer is past it
+          while (j - S >= minprog && !(dbg & 8)) {
 #if MDE_RING_ABLATE
-          if (pr_polls > MDE_RING_SPINMAX) {
-            if (lane == 0) {
-              const int k = atomicAdd(&g_ring_ndiag, 1);
-              if (k < 64) {
-                int* r = g_ring_diag[k];
-                r[0] = 2; r[1] = blockIdx.x; r[2] = p; r[3] = j; r[4] = minprog; r[5] = infl; r[6] = oldest; r[7] = j_hi;
+            const unsigned long long tb0 = RING_CLK();
+            ++pr_polls;
+#endif
+            // one LDS read (lane w = consumer w), then a scalar minimum over the consumers' lanes
+            const int v = ring_ctrl_load(CTRL_PROG + 4u * (uint32_t)(lane & 15));
+            int mn = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+            for (int w = 1; w < NCW; ++w) mn = min(mn, __builtin_amdgcn_readlane(v, w));
+            minprog = mn;
+            if (j - S >= minprog) __builtin_amdgcn_s_sleep(1);
+#if MDE_RING_ABLATE
+            pr_blocked += RING_CLK() - tb0;
+            if (pr_polls > MDE_RING_SPINMAX) {
+              if (lane == 0) {
+                const int kk = atomicAdd(&g_ring_ndiag, 1);
+                if (kk < 64) {
+                  int* r = g_ring_diag[kk];
+                  r[0] = 2; r[1] = blockIdx.x; r[2] = p; r[3] = j; r[4] = minprog; r[5] = S; r[6] = j_lo; r[7] = j_hi;
+                }
               }
+              pr_polls = 0;
+              minprog = j;  // (give up: overwrite the slot)
             }
-            pr_polls = 0;
-            minprog = j;  // (give up: overwrite the slot)
+#endif
           }
-#endif
-#if MDE_RING_ABLATE
-          pr_blocked += RING_CLK() - tb0;
-#endif
-          continue;
-        }
-#if MDE_RING_ABLATE
-        pr_blocked += RING_CLK() - tb0;
-#endif
-      }
-      // (readfirstlane: the LDS base goes into M0 and must sit in an SGPR whatever hipcc's uniformity analysis says)
-      const uint32_t dst = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)RING_OFF + (uint32_t)slot * (uint32_t)CBYTES));
-      if (!(dbg & 2)) {
-        if (j != NC - 1) {
-          // 1 KiB pieces, up to four per statement: the instruction offset advances the global and
-          // the LDS address together
-          const char* src = Xl + (size_t)j * CBYTES;
-#if MDE_RING_DMA_IMM
-          // (groups of four pieces; PIECES is 4..16)
-          ring_dma_pieces<(PIECES < 4 ? PIECES : 4)>(src, dst);
-          if constexpr (PIECES > 4) ring_dma_pieces<(PIECES - 4 < 4 ? PIECES - 4 : 4)>(src + 4096, dst + 4096u);
-          if constexpr (PIECES > 8) ring_dma_pieces<(PIECES - 8 < 4 ? PIECES - 8 : 4)>(src + 8192, dst + 8192u);
-          if constexpr (PIECES > 12) ring_dma_pieces<(PIECES - 12 < 4 ? PIECES - 12 : 4)>(src + 12288, dst + 12288u);
-#else
+          char* dst = L + (uint32_t)__builtin_amdgcn_readfirstlane(ring_off + slot * CBYTES) + lane * 16;
+          if (j != NC - 1 || (nbytes & 15) == 0) {
 #pragma unroll
-          for (int k = 0; k < PIECES; ++k) ring_dma_pieces<1>(src + k * 1024, dst + (uint32_t)k * 1024u);
-#endif
-        } else {
-          // the table's last chunk: lanes whose 16 bytes would cross its end load a clamped address
-          const size_t off0 = (size_t)j * CBYTES + (size_t)lane * 16;
+            for (int i = 0; i < PIECES; ++i) *reinterpret_cast<ring_f4*>(dst + i * 1024) = buf[k][i];
+          } else {
+            // the table's last chunk when the table is not a multiple of 16 bytes: the lane whose 16
+            // bytes straddle the end loaded the LAST 16 bytes instead -- shift them into place
+            const size_t off0 = (size_t)j * CBYTES + (size_t)lane * 16;
 #pragma unroll
-          for (int k = 0; k < PIECES; ++k) {
-            const size_t off = off0 + (size_t)k * 1024;
-            ring_dma_pieces<1>(Xb + (off < last16 ? off : last16), dst + (uint32_t)k * 1024u);
+            for (int i = 0; i < PIECES; ++i) {
+              const size_t off = off0 + (size_t)i * 1024;
+              ring_f4 v = buf[k][i];
+              if (off > last16 && off < nbytes) {
+                const int sh4 = (int)((off - last16) >> 2);  // 1..3 floats
+                const float t1 = v[1], t2 = v[2], t3 = v[3];
+                v[0] = sh4 == 1 ? t1 : (sh4 == 2 ? t2 : t3);
+                v[1] = sh4 == 1 ? t2 : (sh4 == 2 ? t3 : 0.0f);
+                v[2] = sh4 == 1 ? t3 : 0.0f;
+                v[3] = 0.0f;
+              }
+              *reinterpret_cast<ring_f4*>(dst + i * 1024) = v;
+            }
           }
+          // (the LDS executes a wave's accesses in order: whoever sees the new F sees the chunk)
+          ring_ctrl_store_counted(L, CTRL_F + 4u * (uint32_t)p, j + NPROD);
+          fetch(k, j + DEPTH * NPROD);
+          slot += NPROD;
+          while (slot >= S) slot -= S;
         }
       }
-      if (infl == 0) oldest = j;
-      ++infl;
-      j += NPROD;
-      slot += NPROD;
-      slot = slot >= S ? slot - S : slot;
-      if (infl == MDE_RING_DEPTH) retire();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // when the table is not a multiple of 16 bytes its final dwords are put in place by hand
-    if ((nbytes & 15) && (NC - 1) >= j_lo && (NC - 1) < j_hi && ((NC - 1 - j_lo) % NPROD) == p) {
-      const size_t tail0 = nbytes & ~(size_t)15;
-      const int nt = (int)((nbytes - tail0) >> 2);
-      if (lane < nt) {
-        const size_t off = tail0 + (size_t)lane * 4 - (size_t)(NC - 1) * CBYTES;
-        *reinterpret_cast<float*>(L + RING_OFF + ((NC - 1) % S) * CBYTES + off) =
-            *reinterpret_cast<const float*>(Xb + tail0 + (size_t)lane * 4);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    ring_ctrl_store(MDE_RING_CTRL_F + 4u * (uint32_t)p, MDE_RING_DONE);
+    ring_ctrl_store_counted(L, CTRL_F + 4u * (uint32_t)p, MDE_RING_DONE);
 #if MDE_RING_ABLATE
     if ((dbg & 512) && lane == 0 && blockIdx.x < 1024) {
       atomicAdd(&g_ring_probe[3][blockIdx.x], RING_CLK() - pr_t0);
       atomicAdd(&g_ring_probe[4][blockIdx.x], pr_blocked);
-      atomicAdd(&g_ring_probe[5][blockIdx.x], pr_retire);
       atomicAdd(&g_ring_probe[6][blockIdx.x], pr_polls);
     }
 #endif
   } else {
     // ---------------- consumer: my contiguous stream of wave iterations, 4 per block
+    if (MDE_RING_CONSPRIO) __builtin_amdgcn_s_setprio(MDE_RING_CONSPRIO);
     const int ib = __builtin_amdgcn_readfirstlane(wave_iter[blockIdx.x * NCW + wave]);
     const int NB = (__builtin_amdgcn_readfirstlane(wave_iter[blockIdx.x * NCW + wave + 1]) - ib) >> 2;
     if (NB > 0 && !(dbg & 64)) {
@@ -1312,22 +1306,26 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       struct Pre {
         float xr[D], xc[D], p0;
       };
+      // packed word -> LDS byte addresses (ring_pack_word)
+      auto row_of = [&](uint32_t w) __attribute__((always_inline)) { return D == 2 ? (w & 0xfff8u) : (w & 0xffffu); };
+      auto col_of = [&](uint32_t w) __attribute__((always_inline)) {
+        return D == 2 ? ((w >> 13) & 0x3fff8u) : ((w >> 14) & 0x3fffcu);
+      };
       auto issue_x = [&](uint32_t w, float p0) __attribute__((always_inline)) {
         Pre r;
-        const uint32_t rowaddr = w >> 17, colf = w & (CB ? 0x1fff8u : 0x1ffffu);
-        r.p0 = CB ? *reinterpret_cast<const float*>(L + MDE_RING_CTRL_CB + ((w & 7u) << 2)) : p0 * Fn::kParamScale;
-        ring_ld<D>(L + rowaddr, r.xr);
-        ring_ld<D>(L + (RING_OFF - 16) + colf, r.xc);  // (the field carries + 16: the base fits the instruction offset)
+        r.p0 = CB ? *reinterpret_cast<const float*>(L + CTRL_CB + ((w & 7u) << 2)) : p0 * Fn::kParamScale;
+        ring_ld<D>(L + row_of(w), r.xr);
+        ring_ld<D>(L + col_of(w), r.xc);
         return r;
       };
       // this entry adds the loss term iff its row is the smaller vertex (blocks around the diagonal)
       auto counts_here = [&](uint32_t w, uint32_t hm) __attribute__((always_inline)) {
-        const uint32_t off = (w & 0x1ffffu) - 16u;
+        const uint32_t off = col_of(w) - (uint32_t)ring_off;
         const uint32_t slot = off / (uint32_t)CBYTES, cidx = (off - slot * (uint32_t)CBYTES) / (4u * (uint32_t)D);
         const uint32_t ms = hm % (uint32_t)S;
         const uint32_t j = hm + (slot >= ms ? slot - ms : slot + (uint32_t)S - ms);
         const uint32_t u = j * (uint32_t)C + cidx;
-        const uint32_t vv = (uint32_t)(row_lo + r0) + (w >> 17) / (4u * (uint32_t)D);
+        const uint32_t vv = (uint32_t)(row_lo + r0) + row_of(w) / (4u * (uint32_t)D);
         return vv < u;
       };
       // evaluate the entry and add its gradient term to the row's accumulator (read earlier).  LC is
@@ -1336,7 +1334,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       auto finish = [&](auto lc_tag, uint32_t w, const Pre& x, float (&acc)[D], float p1, uint32_t hm)
           __attribute__((always_inline)) {
         constexpr int LC = decltype(lc_tag)::value;
-        const uint32_t rowaddr = w >> 17;
+        const uint32_t rowaddr = row_of(w);
         float v[D], ss = 0.0f;
 #pragma unroll
         for (int c = 0; c < D; ++c) {
@@ -1386,23 +1384,23 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         for (int c = 0; c < D; ++c) acc[c] = fmaf(v[c], g, acc[c]);
         ring_st<D>(L + GR_OFF + rowaddr, acc);
       };
-      // Hand-shake, once per PAIR of iterations (q = 0 or 2 of block u; header words at lanes 4 q ..):
-      // publish the oldest chunk this wave still reads (all reads of older chunks have been ISSUED,
-      // and the LDS executes in order; m never decreases along a stream) and wait until the newest
-      // chunk of the pair has landed.  The layout anchors the chunk window of a pair at the pair's
-      // first iteration (k_ring_schedule), so one test covers both.
-      const uint32_t prog_addr = MDE_RING_CTRL_PROG + 4u * (uint32_t)wave;
+      // Hand-shake, once per PAIR of iterations (q = 0 or 2 of block u; header words at lanes 4 q ..).
+      // A wave needs its chunks resident only at the moment it ISSUES the LDS reads of a pair (the LDS
+      // executes in order: whatever lands later lands behind them): wait_pair() waits until the newest
+      // chunk of the pair has landed, then the reads go out, then release_to() publishes the oldest
+      // chunk of the NEXT pair -- between two hand-shakes the wave holds nothing, so the slots it is
+      // done with are free a whole pair earlier than with "publish, wait, read".  The layout anchors
+      // the chunk window of a pair at its first iteration (k_ring_schedule), so one test covers both.
+      const uint32_t prog_addr = CTRL_PROG + 4u * (uint32_t)wave;
       int ready = j_lo;  // chunks below this have landed
-      auto sync_pair = [&](int u, int q) __attribute__((always_inline)) {
-        const int m = __builtin_amdgcn_readlane((int)hv[u], 4 * q);
+      auto wait_pair = [&](int u, int q) __attribute__((always_inline)) {
         const int need = __builtin_amdgcn_readlane((int)hv[u], 4 * q + 1);
-        ring_ctrl_store_counted(L, prog_addr, m);
         if (__builtin_expect(need >= ready && !(dbg & 1), 0)) {
 #if MDE_RING_ABLATE
           const unsigned long long tp0 = RING_CLK();
 #endif
           for (;;) {
-            const int fl = ring_ctrl_load(MDE_RING_CTRL_F + 4u * (uint32_t)min(lane, NPROD - 1));
+            const int fl = ring_ctrl_load(CTRL_F + 4u * (uint32_t)min(lane, NPROD - 1));
             ready = __builtin_amdgcn_readlane(fl, 0);
 #pragma unroll
             for (int pp = 1; pp < NPROD; ++pp) ready = min(ready, __builtin_amdgcn_readlane(fl, pp));
@@ -1413,7 +1411,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
                 const int k = atomicAdd(&g_ring_ndiag, 1);
                 if (k < 64) {
                   int* r = g_ring_diag[k];
-                  r[0] = 1; r[1] = blockIdx.x; r[2] = wave; r[3] = need; r[4] = ready; r[5] = m; r[6] = u * 4 + q; r[7] = NB;
+                  r[0] = 1; r[1] = blockIdx.x; r[2] = wave; r[3] = need; r[4] = ready; r[5] = 0; r[6] = u * 4 + q; r[7] = NB;
                 }
               }
               cs_trips = 0;
@@ -1429,6 +1427,11 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
 #endif
           asm volatile("" ::: "memory");
         }
+      };
+      // (m never decreases along a stream; past its end the headers are copies of the last block and
+      // the value published is merely too old)
+      auto release_to = [&](int u, int q) __attribute__((always_inline)) {
+        ring_ctrl_store_counted(L, prog_addr, __builtin_amdgcn_readlane((int)hv[u], 4 * q));
       };
 
       // Software pipeline over PAIRS of iterations.  In the region of pair p the wave (after the
@@ -1454,28 +1457,31 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           // the pair after this one (block and slot); past the end of the stream it is a copy of
           // the last block: resident chunks, harmless reads, nothing new published
           const int un = h == 0 ? u : (u + 1) % PFB, qn = (q + 2) & 3;
-          sync_pair(un, qn);
+          wait_pair(un, qn);
           const Pre xna = issue_x(pq[un][qn], (a0_scalar || CB) ? a0s : wq[un][qn]);
           const Pre xnb = issue_x(pq[un][qn + 1], (a0_scalar || CB) ? a0s : wq[un][qn + 1]);
+          release_to((u + 1) % PFB, q);  // (the pair after that one: next block, same slot)
           const float p1a = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q] : a1s;
           const float p1b = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q + 1] : a1s;
           const bool lc2 = decltype(lc_tag)::value == 2;
           const uint32_t hma = lc2 ? (uint32_t)__builtin_amdgcn_readlane((int)hv[u], 4 * q) : 0u;
           const uint32_t hmb = lc2 ? (uint32_t)__builtin_amdgcn_readlane((int)hv[u], 4 * q + 4) : 0u;
           finish(lc_tag, pq[u][q], xa, acc, p1a, hma);
-          if (HAS_GRAD) ring_ld<D>(L + GR_OFF + (pq[u][q + 1] >> 17), acc);
+          if (HAS_GRAD) ring_ld<D>(L + GR_OFF + row_of(pq[u][q + 1]), acc);
           finish(lc_tag, pq[u][q + 1], xb, acc, p1b, hmb);
-          if (HAS_GRAD) ring_ld<D>(L + GR_OFF + (pq[un][qn] >> 17), acc);
+          if (HAS_GRAD) ring_ld<D>(L + GR_OFF + row_of(pq[un][qn]), acc);
           xa = xna;
           xb = xnb;
         }
       };
 #pragma unroll
       for (int u = 0; u < PFB; ++u) load_block(u, u);
-      sync_pair(0, 0);
+      release_to(0, 0);  // (a sparse stream may begin chunks after j_lo: the producers must know before this wave waits)
+      wait_pair(0, 0);
       xa = issue_x(pq[0][0], (a0_scalar || CB) ? a0s : wq[0][0]);
       xb = issue_x(pq[0][1], (a0_scalar || CB) ? a0s : wq[0][1]);
-      if (HAS_GRAD) ring_ld<D>(L + GR_OFF + (pq[0][0] >> 17), acc);
+      release_to(0, 2);
+      if (HAS_GRAD) ring_ld<D>(L + GR_OFF + row_of(pq[0][0]), acc);
       for (int base = 0; base < NB; base += PFB) {
 #pragma unroll
         for (int u = 0; u < PFB; ++u) {
@@ -1502,19 +1508,12 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
 #endif
     }
     if constexpr (Fn::kRingFused) loss = fmaf(loss, 0.6931471805599453f, loss2) * (1.0f / Fn::kParamScale);
-    ring_ctrl_store(MDE_RING_CTRL_PROG + 4u * (uint32_t)wave, MDE_RING_DONE);
+    ring_ctrl_store_counted(L, CTRL_PROG + 4u * (uint32_t)wave, MDE_RING_DONE);
     // (the two roles are laid out one after the other: leave no counted load pending here, or
     // hipcc carries the stream prefetches into the producer code as waits -- see above)
     __builtin_amdgcn_s_waitcnt(0x0F70);
   }
   __syncthreads();
-#if MDE_RING_ABLATE
-  if (tid == 0 && (dbg & 256)) {
-    // probe: when this workgroup started and how long its main phase took (s_memtime ticks)
-    loss_partials[1024 + blockIdx.x] = (double)(__builtin_readcyclecounter() - t_begin);
-    loss_partials[2048 + blockIdx.x] = (double)t_begin;
-  }
-#endif
   if (HAS_GRAD) {
     // Q == 1: the rows are final.  Q > 1: unscaled per-group partials, summed by k_ring_combine
     float* grow = (Q == 1) ? grad + (size_t)(row_lo + r0) * D : partial + ((size_t)qg * nloc + r0) * D;
@@ -1642,7 +1641,7 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
   // (every edge adds its loss term once here, not once per endpoint: twice the caller's scale)
   hipLaunchKernelGGL(kern, dim3(L.n_row_blocks * Q), dim3(MDE_RING_BS), 0, A.st,
                      (int)(A.plan->row_hi - A.plan->row_lo), (int)A.plan->row_lo, (int)A.plan->n,
-                     L.rows_per_block, Q, L.n_chunks, L.wave_iter, L.hdr, stream, a0, A.a1, A.a0_scalar,
+                     L.rows_per_block, Q, L.n_chunks, L.ring_off, L.slots, L.wave_iter, L.hdr, stream, a0, A.a1, A.a0_scalar,
                      A.a1_scalar, A.X, A.grad, L.partial, A.plan->partials, fn, fix_value, out_scale,
                      A.loss_out, 2.0 * A.loss_scale, dbg);
   MDE_LAUNCH_CHECK();
@@ -1678,22 +1677,6 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
               s[0] / L8 / MDE_RING_NCW, s[1] / L8 / MDE_RING_NCW, 100.0 * s[1] / s[0], s[2] / L8 / MDE_RING_NCW,
               s[3] / L8 / MDE_RING_NPROD, s[4] / L8 / MDE_RING_NPROD, 100.0 * s[4] / s[3], s[5] / L8 / MDE_RING_NPROD,
               100.0 * s[5] / s[3], s[6] / L8 / MDE_RING_NPROD);
-    }
-  }
-  if (dbg & 256) {
-    static int printed = 0;
-    if (printed++ == 3) {
-      const int nb = L.n_row_blocks * Q;
-      std::vector<double> h(3072);
-      (void)hipStreamSynchronize(A.st);
-      (void)hipMemcpy(h.data(), A.plan->partials, 3072 * sizeof(double), hipMemcpyDeviceToHost);
-      double mn = 1e300, mx = 0, sum = 0, t0 = 1e300, t1 = 0;
-      for (int i = 0; i < nb && i < 1024; ++i) {
-        mn = std::min(mn, h[1024 + i]); mx = std::max(mx, h[1024 + i]); sum += h[1024 + i];
-        t0 = std::min(t0, h[2048 + i]); t1 = std::max(t1, h[2048 + i] + h[1024 + i]);
-      }
-      fprintf(stderr, "[mde ring] workgroup main-phase ticks: min %.0f mean %.0f max %.0f; first start -> last end %.0f\n",
-              mn, sum / nb, mx, t1 - t0);
     }
   }
 #endif
