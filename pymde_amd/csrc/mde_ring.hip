@@ -594,7 +594,10 @@ static bool choose_sizes(const mde_plan* plan, int d, RingSizes* z) {
   const int C = ring_chunk_cols(d);
   const int64_t nc = (plan->n + C - 1) / C;
   if (nc > 65535 || nc < 2) return false;
-  const int minch = getenv("MDE_RING_MINCH") ? std::max(1, atoi(getenv("MDE_RING_MINCH"))) : 5;
+  // (a stream ends with a few thin iterations -- the waiting entries drain under the distinct-rows rule --
+  // and is padded to whole blocks: a column group must be long enough to amortise that; 10 chunks are
+  // the column counts round 3 tuned with chunks twice as wide)
+  const int minch = getenv("MDE_RING_MINCH") ? std::max(1, atoi(getenv("MDE_RING_MINCH"))) : 10;
   const int qmax = (int)std::min<int64_t>(16, std::max<int64_t>(1, nc / minch));
   int64_t pr = (nloc * qmax + 255) / 256;
   if (pr < 64 * MDE_RING_NCW) pr = 64 * MDE_RING_NCW;  // >= 64 rows per consumer wave, even if CUs stay empty
