@@ -254,7 +254,10 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
   const int w_ = i % MDE_RING_NCW;
   const int nrows_w = max(1, bounds[rb * (MDE_RING_NCW + 1) + w_ + 1] - bounds[rb * (MDE_RING_NCW + 1) + w_]);
   const int per_it = nrows_w < 64 ? nrows_w : 64;
-  const int bail = (!FILL && bail_factor > 0) ? bail_factor * ((end - beg + per_it - 1) / per_it) + 64 : 0x7fffffff;
+  // (a sparse stream -- the short last row block -- needs its iterations for the chunk windows it has to
+  // walk, a pair of iterations per SPAN + 1 chunks: that is not a hub either)
+  const int walk = 2 * ((NC / Q + SPAN + 1) / (SPAN + 1));
+  const int bail = (!FILL && bail_factor > 0) ? bail_factor * max((end - beg + per_it - 1) / per_it, walk) + 64 : 0x7fffffff;
   int last_chunk = (int)(((int64_t)((i / MDE_RING_NCW) % Q) * NC + Q - 1) / Q);
   int m_lead = 0;
   while (nc > 0 || next < end) {
