@@ -14,7 +14,7 @@ Prints ONE JSON line: metric/value = edges/s/iter, plus
   roofline     -- algorithmic bytes (12.32 B/edge) / fused-kernel duration (median of
                   per-launch HIP-event times on the launching stream), against the 8 TB/s HBM peak;
                   `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of THIS kernel
-                  source (profiles/r03_pmc_traffic.json, ignored when the source has changed since)
+                  source (profiles/r04_pmc_traffic.json, ignored when the source has changed since)
   cpu_baseline -- the reference's op sequence (average_distortion.py:68-105: index gathers,
                   pow/sum/sqrt, the penalty under autograd, two scatter_add_) restated in torch and
                   timed on ALL of this host's cores (kind "torch-aten-sequence"); the OpenMP CPU
@@ -56,7 +56,7 @@ REFERENCE_TORCH_CPU = {"value": 5.57e6, "unit": "edges/s/iter", "cores": 8,
                        "source": "tools/ref_cpu_time.py, round 2 (the survey session's container measured 9.3e6)"}
 # the files that define the measured kernel (k_fused_ring, its layout and its functors); the CSR
 # kernels of mde_distortion.hip are not what the PMC passes measure
-KERNEL_SOURCES = ["pymde_amd/csrc/mde_ring.hip", "pymde_amd/csrc/mde_ring_place.h", "pymde_amd/csrc/mde_functions.h"]
+KERNEL_SOURCES = ["pymde_amd/csrc/mde_ring.hip", "pymde_amd/csrc/mde_functions.h"]
 
 
 def source_sha():
@@ -70,14 +70,18 @@ def source_sha():
 def pmc_traffic(key):
     """HBM bytes per launch recorded by the PMC passes (tools/pmc_traffic.sh), or None when the
     record is missing or belongs to another version of the kernel source."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
     try:
         rec = json.load(open(path))
     except Exception:
         return None, None
     if rec.get("source_sha") != source_sha():
-        return None, "profiles/r03_pmc_traffic.json is from another kernel source (stale): ignored"
-    return rec.get("bytes_per_launch", {}).get(key), "profiles/r03_pmc_traffic.json (rocprofv3 --pmc, bytes/launch)"
+        return None, "profiles/r04_pmc_traffic.json is from another kernel source (stale): ignored"
+    b = rec.get("bytes_per_launch", {})
+    v = b.get(key)
+    if v is not None and key.startswith("ring") and "ring_combine" in b:
+        v += b["ring_combine"]  # (the 2 column groups per row block: their partial rows are added by a second launch)
+    return v, "profiles/r04_pmc_traffic.json (rocprofv3 --pmc, bytes/launch; ring kernel + combine launch)"
 
 
 def make_workload(device, n=N_ITEMS, deg=OUT_DEGREE, d=DIM):
@@ -302,7 +306,8 @@ def run_config4(args, world, rank, device):
     achieved = alg_bytes / (k_ms * 1e-3)
     layout = int(binding.struct(d).layout)
     fn_name = "Log1p" if args.variant == "4a" else "PushPull<Log1p,Log>"
-    kernel = ("k_fused_ring<2,%s,%s> (LDS-resident rows + LDS-DMA chunk ring, loss reduced in the same launch)"
+    kernel = ("k_fused_ring<2,%s,%s> (LDS-resident rows, chunk ring filled through the producers' VGPRs, loss reduced in "
+              "the same launch) + k_ring_combine (adds the column groups' partial rows)"
               % (fn_name, "codebook" if binding.codebook else "fp32 stream")) if layout == 1 \
         else "k_fused_small<2,G,%s> (CSR) + 1-block loss finalize" % fn_name
     traffic, traffic_src = (None, None)

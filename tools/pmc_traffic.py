@@ -25,6 +25,8 @@ def classify(name):
         flags = [t.strip() for t in targs.split(",")][-3:]
         if len(flags) == 3 and flags[0] == "true":
             return "ring_codebook" if flags[1] == "true" else "ring_fp32"
+    if "k_ring_combine" in name:
+        return "ring_combine"
     if "k_fused_wide4" in name:
         return "wide4"
     if "k_fused_small" in name:

@@ -10,7 +10,7 @@
 #include <cstdlib>
 #include <random>
 #include <vector>
-#include "../pymde_amd/csrc/mde_ring_place.h"
+#include "ring_place_r3.h"
 
 struct Ent { int chunk, row, col, age; };
 
