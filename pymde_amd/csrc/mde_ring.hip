@@ -41,6 +41,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <type_traits>
@@ -222,30 +223,51 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_seg(int64_t H, uint32_t nseg
 #define MDE_RING_CARRY 256  // waiting entries a stream can hold
 __host__ __device__ constexpr int ring_cls_shift(int d) { return d == 2 ? 3 : (d == 4 ? 4 : 2); }
 __host__ __device__ constexpr int ring_cls_mask(int d) { return d == 4 ? 15 : 31; }
+// meta[pos] for every sorted position: local row (bits 15:0) | row bank class (23:16) | column bank
+// class (31:24) -- everything the scheduler needs of an entry besides its chunk (keys[pos] & JM), in
+// stream order: the scheduler's loads are contiguous (round 3 chased pos -> vals -> hrow / nbr, three
+// dependent random loads per candidate: 2 x 43 ms at config 4)
+__global__ __launch_bounds__(MDE_BLOCK) void k_ring_meta(int64_t H, const uint32_t* __restrict__ keys,
+                                                         const uint32_t* __restrict__ vals,
+                                                         const int32_t* __restrict__ hrow,
+                                                         const int32_t* __restrict__ nbr, int JB, int R, int Q, int d,
+                                                         uint32_t* __restrict__ meta) {
+  const int sh = ring_cls_shift(d), cm = ring_cls_mask(d), rowbytes = 4 * d;
+  for (int64_t pos = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; pos < H; pos += (int64_t)gridDim.x * MDE_BLOCK) {
+    const uint32_t q = vals[pos];
+    const int rb = (int)((keys[pos] >> JB) / MDE_RING_NCW) / Q;
+    const uint32_t row = (uint32_t)(hrow[q] - rb * R);
+    const uint32_t rc = ((row * (uint32_t)rowbytes) >> sh) & (uint32_t)cm;
+    const uint32_t cc = (((uint32_t)nbr[q] * (uint32_t)rowbytes) >> sh) & (uint32_t)cm;  // (chunks start on class 0)
+    meta[pos] = row | (rc << 16) | (cc << 24);
+  }
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* __restrict__ seg,
                                                       const int32_t* __restrict__ bounds,
                                                       const uint32_t* __restrict__ keys,
-                                                      const uint32_t* __restrict__ vals,
-                                                      const int32_t* __restrict__ hrow,
-                                                      const int32_t* __restrict__ nbr, uint32_t JM, int SPAN,
+                                                      const uint32_t* __restrict__ meta, uint32_t JM, int SPAN,
                                                       int R, int Q, int NC, int d, int cap, int bail_factor,
                                                       int32_t* __restrict__ iters,
                                                       const int32_t* __restrict__ iter_base,
                                                       int32_t* __restrict__ it_ent, int32_t* __restrict__ it_cnt,
-                                                      int32_t* __restrict__ it_m) {
-  __shared__ int flag[12288 + 32];          // per row of the block: priority of the entry that holds it
-  __shared__ int cq_pos[2][MDE_RING_CARRY]; // waiting entries (sorted position), double buffered
+                                                      int32_t* __restrict__ it_m, int flag_rows,
+                                                      const int32_t* __restrict__ caps) {
+  extern __shared__ int flag[];                  // [flag_rows] per row of the WAVE: priority of the entry that holds it
+  __shared__ int cq_pos[2][MDE_RING_CARRY];      // waiting entries (sorted position), double buffered,
+  __shared__ uint32_t cq_meta[2][MDE_RING_CARRY];  // ... their meta word,
+  __shared__ int cq_chunk[2][MDE_RING_CARRY];    // ... their chunk
   __shared__ int cq_age[2][MDE_RING_CARRY];
-  __shared__ int em[64];                    // entries of the iteration being formed
-  __shared__ int rcnt[32], ccnt[32];        // entries per bank class in it
+  __shared__ int em[64], em_row[64];             // entries of the iteration being formed
+  __shared__ int rcnt[32], ccnt[32];             // entries per bank class in it
   const int i = blockIdx.x, lane = threadIdx.x;
   if (i >= nseg) return;
-  for (int r = lane; r < 12288 + 32; r += 64) flag[r] = 0x7fffffff;
+  for (int r = lane; r < flag_rows; r += 64) flag[r] = 0x7fffffff;
   __syncthreads();
   const int beg = seg[i], end = seg[i + 1];
   const int rb = (i / MDE_RING_NCW) / Q;
-  const int sh = ring_cls_shift(d), cm = ring_cls_mask(d), rowbytes = 4 * d;
+  const int row_base = bounds[rb * (MDE_RING_NCW + 1) + i % MDE_RING_NCW] - rb * R;  // first local row of this wave
   const int first = FILL ? iter_base[i] : 0;
   int out = first, next = beg, nc = 0, cur = 0;
   // counting pass, auto mode: a stream that needs several times the iterations its entries would fill
@@ -257,38 +279,36 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
   // (a sparse stream -- the short last row block -- needs its iterations for the chunk windows it has to
   // walk, a pair of iterations per SPAN + 1 chunks: that is not a hub either)
   const int walk = 2 * ((NC / Q + SPAN + 1) / (SPAN + 1));
-  const int bail = (!FILL && bail_factor > 0) ? bail_factor * max((end - beg + per_it - 1) / per_it, walk) + 64 : 0x7fffffff;
+  // FILL with `caps`: the single-pass build -- the stream writes into a region of caps[i] iterations
+  // (the same bound) and reports how many it used
+  const int bail = caps ? caps[i] - 4
+                        : ((!FILL && bail_factor > 0) ? bail_factor * max((end - beg + per_it - 1) / per_it, walk) + 64 : 0x7fffffff);
   int last_chunk = (int)(((int64_t)((i / MDE_RING_NCW) % Q) * NC + Q - 1) / Q);
   int m_lead = 0;
   while (nc > 0 || next < end) {
-    const int m = (int)(keys[nc > 0 ? cq_pos[cur][0] : next] & JM);  // oldest candidate's chunk
+    const int m = nc > 0 ? cq_chunk[cur][0] : (int)(keys[next] & JM);  // oldest candidate's chunk
     // the chunk window is anchored at the first iteration of a PAIR (the kernel does one hand-shake
-    // per pair: it publishes that iteration's m and waits for the newest chunk of both)
+    // per pair: it waits for the newest chunk of both)
     if (((out - first) & 1) == 0) m_lead = m;
     const int lim = m_lead + SPAN;
-    int nem = 0, nnew = 0;  // emitted so far, waiting so far (into buffer cur ^ 1)
+    int nem = 0, nnew = 0, mx = 0;  // emitted so far, waiting so far (into buffer cur ^ 1), newest chunk emitted
     if (lane < 32) rcnt[lane] = ccnt[lane] = 0;
     __syncthreads();
     // offer a batch of candidates (stream order = ascending priority)
-    auto offer = [&](int pos, int age, int prio) {
-      int row = 0, rc = -1, cc = -2;
-      if (pos >= 0) {
-        const uint32_t q = vals[pos];
-        row = hrow[q] - rb * R;
-        rc = ((row * rowbytes) >> sh) & cm;
-        cc = (int)((((uint32_t)nbr[q] * (uint32_t)rowbytes) >> sh) & (uint32_t)cm);  // (chunks start on class 0)
-        atomicMin(&flag[row], prio);
-      }
+    auto offer = [&](int pos, uint32_t mw, int chunk, int age, int prio) {
+      const int row = pos >= 0 ? (int)(mw & 0xffffu) - row_base : 0;  // (relative to the wave's first row)
+      const int rc = pos >= 0 ? (int)((mw >> 16) & 0xffu) : -1, cc = pos >= 0 ? (int)(mw >> 24) : -2;
+      if (pos >= 0) atomicMin(&flag[row], prio);
       __syncthreads();
       const bool rowwin = pos >= 0 && flag[row] == prio;
       // how many earlier row winners of this batch share my classes (whether or not they pass
       // their own caps: slightly pessimistic, deterministic and parallel)
       int rkR = 0, rkC = 0;
       const int rcw = rowwin ? rc : -1, ccw = rowwin ? cc : -2;
-      for (int t = 0; t < 64; ++t) {
-        const int rt = __builtin_amdgcn_readlane(rcw, t), ct = __builtin_amdgcn_readlane(ccw, t);
-        rkR += (t < lane) && (rt == rc);
-        rkC += (t < lane) && (ct == cc);
+      for (int c = 0; c < 32; ++c) {
+        const unsigned long long mr = __ballot(rcw == c), mc = __ballot(ccw == c);
+        if (rc == c) rkR = __popcll(mr & ((1ull << lane) - 1ull));
+        if (cc == c) rkC = __popcll(mc & ((1ull << lane) - 1ull));
       }
       const bool capok = rowwin && (rcnt[rc] + rkR < cap) && (ccnt[cc] + rkC < cap);
       const bool win = rowwin && (capok || age >= MDE_RING_FORCE);
@@ -298,14 +318,18 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
       const bool emit = win && widx < 64;
       if (emit) {
         em[widx] = pos;
+        em_row[widx] = row;
         atomicAdd(&rcnt[rc], 1);
         atomicAdd(&ccnt[cc], 1);
       }
+      mx = max(mx, emit ? chunk : 0);
       const bool lose = pos >= 0 && !emit;
       const unsigned long long lm = __ballot(lose);
       const int lidx = nnew + __popcll(lm & ((1ull << lane) - 1ull));
       if (lose && lidx < MDE_RING_CARRY) {
         cq_pos[cur ^ 1][lidx] = pos;
+        cq_meta[cur ^ 1][lidx] = mw;
+        cq_chunk[cur ^ 1][lidx] = chunk;
         cq_age[cur ^ 1][lidx] = win ? age : age + 1;
       }
       // (overflow of the waiting queue cannot happen: a batch is only offered while
@@ -318,7 +342,9 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
     // the waiting entries first, 64 at a time
     for (int c0 = 0; c0 < nc; c0 += 64) {
       const int k = c0 + lane;
-      offer(k < nc ? cq_pos[cur][k] : -1, k < nc ? cq_age[cur][k] : 0, prio + lane);
+      const bool has = k < nc;
+      offer(has ? cq_pos[cur][k] : -1, has ? cq_meta[cur][k] : 0u, has ? cq_chunk[cur][k] : 0, has ? cq_age[cur][k] : 0,
+            prio + lane);
       prio += 64;
     }
     // then new entries while lanes are free and the window allows (a few rounds: entries that
@@ -326,22 +352,21 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
     for (int round = 0; round < 6 && nem < 64 && next < end && nnew + 64 <= MDE_RING_CARRY; ++round) {
       const int want = 64 - nem;
       const int cand = next + lane;
-      const bool take = lane < want && cand < end && (int)(keys[cand] & JM) <= lim;
+      const bool in = lane < want && cand < end;
+      const int chunk = in ? (int)(keys[cand] & JM) : 0x7fffffff;
+      const bool take = in && chunk <= lim;
       const int ntake = __popcll(__ballot(take));
       if (ntake == 0) break;
-      offer(take ? cand : -1, 0, prio + lane);
+      offer(take ? cand : -1, take ? meta[cand] : 0u, chunk, 0, prio + lane);
       prio += 64;
       next += ntake;
     }
-    // the rows claimed in this iteration are released
-    if (lane < nem) flag[hrow[vals[em[lane]]] - rb * R] = 0x7fffffff;
-    for (int k = lane; k < nnew; k += 64) flag[hrow[vals[cq_pos[cur ^ 1][k]]] - rb * R] = 0x7fffffff;
-    {
-      // newest chunk the iteration references
-      int mx = lane < nem ? (int)(keys[em[lane]] & JM) : 0;
-      mx = mde_wave_max(mx);
-      if (nem > 0) last_chunk = mx;
-    }
+    // the rows claimed in this iteration are released (a waiting entry keeps its row claimed until
+    // here: later entries of that row do not overtake it)
+    if (lane < nem) flag[em_row[lane]] = 0x7fffffff;
+    for (int k = lane; k < nnew; k += 64) flag[(int)(cq_meta[cur ^ 1][k] & 0xffffu) - row_base] = 0x7fffffff;
+    mx = mde_wave_max(mx);
+    if (nem > 0) last_chunk = mx;  // newest chunk the iteration references
     if (FILL) {
       if (lane < nem) it_ent[(size_t)out * 64 + lane] = em[lane];
       if (lane == 0) {
@@ -366,7 +391,26 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
     }
     ++out;
   }
-  if (!FILL && lane == 0) iters[i] = out;
+  if (iters && lane == 0) iters[i] = out - first;
+}
+
+// caps[i] = iterations reserved for stream i by the single-pass build: `factor` times what its entries
+// (or its chunk windows) need at least, a multiple of 4
+__global__ __launch_bounds__(MDE_BLOCK) void k_ring_caps(int nseg, const int32_t* __restrict__ seg,
+                                                         const int32_t* __restrict__ bounds, int R, int Q, int NC, int SPAN,
+                                                         int factor, int32_t* __restrict__ caps) {
+  const int i = blockIdx.x * MDE_BLOCK + threadIdx.x;
+  if (i > nseg) return;
+  if (i == nseg) {
+    caps[i] = 0;
+    return;
+  }
+  const int rb = (i / MDE_RING_NCW) / Q, w = i % MDE_RING_NCW;
+  const int nrows_w = max(1, bounds[rb * (MDE_RING_NCW + 1) + w + 1] - bounds[rb * (MDE_RING_NCW + 1) + w]);
+  const int per_it = nrows_w < 64 ? nrows_w : 64;
+  const int walk = 2 * ((NC / Q + SPAN + 1) / (SPAN + 1));
+  const int need = max((seg[i + 1] - seg[i] + per_it - 1) / per_it, walk);
+  caps[i] = (factor * need + 64 + 4 + 3) & ~3;
 }
 
 // Header of a wave iteration, four words (scalar registers in the kernel: no field extraction):
@@ -432,7 +476,9 @@ __device__ __forceinline__ int ring_place_wave(bool act, int rc, int lane) {
 
 // One wave per iteration: deal its <= 64 entries to the lanes, pad to 64 with dummies, write
 // packed words, edge ids and the header.
-__global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int32_t* __restrict__ it_ent,
+__global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, int nseg, const int32_t* __restrict__ iter_base,
+                                                         const int32_t* __restrict__ src_base,
+                                                         const int32_t* __restrict__ it_ent,
                                                          const int32_t* __restrict__ it_cnt,
                                                          const int32_t* __restrict__ it_m,
                                                          const uint32_t* __restrict__ keys,
@@ -453,13 +499,24 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int3
   for (int64_t itb = (int64_t)blockIdx.x * (MDE_BLOCK / 64); itb < nit; itb += nw) {
     const int64_t it = itb + wv;
     const bool valid = it < nit;
-    const int cw = valid ? __builtin_amdgcn_readfirstlane(it_cnt[it]) : 0;  // entries | newest chunk << 8
+    // where the scheduler left iteration `it` (the single-pass build reserves a region per stream):
+    // stream s = the last one with iter_base[s] <= it
+    int64_t src = it;
+    if (valid && src_base) {
+      int lo = 0, hi = nseg;  // iter_base[lo] <= it < iter_base[hi]
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)iter_base[mid] <= it) lo = mid; else hi = mid;
+      }
+      src = (int64_t)src_base[lo] + (it - (int64_t)iter_base[lo]);
+    }
+    const int cw = valid ? __builtin_amdgcn_readfirstlane(it_cnt[src]) : 0;  // entries | newest chunk << 8
     const int cnt = cw & 0xff;
     const bool act = valid && lane < cnt;
     uint32_t key = 0, q = 0, col = 0, rowaddr = 0, ring = 0;
     int grow = 0, rcls = 0;
     if (act) {
-      const int pos = it_ent[(size_t)it * 64 + lane];
+      const int pos = it_ent[(size_t)src * 64 + lane];
       key = keys[pos];
       q = vals[pos];
       const int rb = (int)((key >> JB) / MDE_RING_NCW) / Q;
@@ -489,11 +546,11 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, const int3
     const uint32_t lclass = ncount == 0 ? 0u : (ncount == cnt ? 1u : 2u);
     // chunk window of the iteration: the oldest chunk its stream still needs (waiting entries
     // included) .. the newest chunk it references
-    const uint32_t m = valid ? (uint32_t)__builtin_amdgcn_readfirstlane(it_m[it]) : 0u;
+    const uint32_t m = valid ? (uint32_t)__builtin_amdgcn_readfirstlane(it_m[src]) : 0u;
     const uint32_t need = max((uint32_t)(cw >> 8), m);
     // the padding lanes read a column that is resident for sure: the first one of the oldest chunk
     // of the PAIR of iterations (the kernel waits for that chunk before it issues the pair's reads)
-    const uint32_t mpad = valid ? (uint32_t)__builtin_amdgcn_readfirstlane(it_m[it & ~(int64_t)1]) : 0u;
+    const uint32_t mpad = valid ? (uint32_t)__builtin_amdgcn_readfirstlane(it_m[src & ~(int64_t)1]) : 0u;  // (regions start on multiples of 4)
     // element (iteration it, lane l) of a stream lives at ((it / 4) * 64 + l) * 4 + it % 4
     const size_t base = ((size_t)(it >> 2) * 64) * 4 + (size_t)(it & 3);
     if (act) {
@@ -681,6 +738,16 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     e = (call);                                  \
     if (e != hipSuccess) return fail(e, #call);  \
   } while (0)
+  // (MDE_RING_STATS: where the build's time goes, host side included)
+  const bool stats_on = getenv("MDE_RING_STATS") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto tick = [&](const char* what) {
+    if (!stats_on) return;
+    (void)hipStreamSynchronize(st);
+    const auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[mde ring build] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t_last).count());
+    t_last = t1;
+  };
   const size_t hb = (size_t)H * sizeof(uint32_t);
   RB(hipMalloc(&keys, hb));
   RB(hipMalloc(&vals, hb));
@@ -691,6 +758,7 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   RB(hipMalloc(&seg, ((size_t)nseg + 1) * sizeof(int32_t)));
   RB(hipMalloc(&iters, ((size_t)nseg + 1) * sizeof(int32_t)));
   RB(hipMalloc(&iter_base, ((size_t)nseg + 1) * sizeof(int32_t)));
+  tick("scratch allocations");
   hipLaunchKernelGGL(k_ring_bounds, dim3((z.NRB * (MDE_RING_NCW + 1) + MDE_BLOCK - 1) / MDE_BLOCK), dim3(MDE_BLOCK), 0,
                      st, (int)nloc, z.R, z.NRB, plan->rowptr, bounds);
   RB(hipGetLastError());
@@ -731,42 +799,148 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
                      z.JB, keys2, seg);
   RB(hipGetLastError());
   RB(hipMemsetAsync(iters, 0, ((size_t)nseg + 1) * sizeof(int32_t), st));
+  tick("keys, sorts, segments");
   // bank-class cap of the scheduler and the lane placement (environment: design ablations only)
   const int cap_default = d == 4 ? 8 : 4;
   const int cap = getenv("MDE_RING_CAP") ? std::max(1, atoi(getenv("MDE_RING_CAP"))) : cap_default;
   const int place = getenv("MDE_RING_PLACE") ? atoi(getenv("MDE_RING_PLACE")) : 1;
   const int span = z.span;
-  hipLaunchKernelGGL(k_ring_schedule<false>, dim3(nseg), dim3(64), 0, st, nseg, seg, bounds, keys2, vals2, hrow, plan->nbr,
-                     JM, span, z.R, z.Q, z.NC, d, cap, panel_mode() == 1 ? 0 : 4, iters, nullptr, nullptr, nullptr, nullptr);
+  // (keys is free from here on: it holds the scheduler's meta words)
+  uint32_t* meta = keys;
+  hipLaunchKernelGGL(k_ring_meta, dim3(mde_grid(H, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st, H, keys2, vals2, hrow, plan->nbr,
+                     z.JB, z.R, z.Q, d, meta);
   RB(hipGetLastError());
-  RB(hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, iters, iter_base, nseg + 1, st));
-  int32_t total_iters = 0;
-  RB(hipMemcpyAsync(&total_iters, iter_base + nseg, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  RB(hipStreamSynchronize(st));
+  // rows of the largest wave range (the scheduler keeps one LDS word per row of its wave)
+  int flag_rows = 64;
+  {
+    std::vector<int32_t> hbd((size_t)z.NRB * (MDE_RING_NCW + 1));
+    RB(hipMemcpyAsync(hbd.data(), bounds, hbd.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    RB(hipStreamSynchronize(st));
+    for (int b = 0; b < z.NRB; ++b)
+      for (int w = 0; w < MDE_RING_NCW; ++w)
+        flag_rows = std::max(flag_rows, hbd[(size_t)b * (MDE_RING_NCW + 1) + w + 1] - hbd[(size_t)b * (MDE_RING_NCW + 1) + w]);
+    flag_rows = (flag_rows + 63) / 64 * 64;
+  }
+  const size_t flag_bytes = (size_t)flag_rows * sizeof(int);
+  // Single pass: every stream schedules into a region of caps[i] iterations (4 x what its entries or its
+  // chunk windows need at least -- the bound beyond which auto mode gives the layout up anyway) and
+  // reports how many it used; k_ring_pack compacts.  A stream that overflows its region (a hub row)
+  // ends the build in auto mode; a forced build (MDE_PANEL=1) then takes the exact two-pass route:
+  // count without a limit, allocate, fill.  (Round 3 always counted first: the scheduler ran twice.)
+  int32_t *caps = nullptr, *cap_base = nullptr;
+  RB(hipMalloc(&caps, ((size_t)nseg + 1) * sizeof(int32_t)));
+  RB(hipMalloc(&cap_base, ((size_t)nseg + 1) * sizeof(int32_t)));
+  auto drop_caps = [&]() {
+    if (caps) (void)hipFree(caps);
+    if (cap_base) (void)hipFree(cap_base);
+    caps = cap_base = nullptr;
+  };
+  int32_t total_iters = 0, total_cap = 0;
+  hipLaunchKernelGGL(k_ring_caps, dim3((nseg + 1 + MDE_BLOCK - 1) / MDE_BLOCK), dim3(MDE_BLOCK), 0, st, nseg, seg, bounds, z.R, z.Q,
+                     z.NC, span, 4, caps);
+  e = hipGetLastError();
+  if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, caps, cap_base, nseg + 1, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(&total_cap, cap_base + nseg, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  bool single = e == hipSuccess && total_cap > 0 && (int64_t)total_cap * 64 < ((int64_t)1 << 33);
+  if (e != hipSuccess) {
+    drop_caps();
+    return fail(e, "ring layout: stream capacities");
+  }
+  if (single) {
+    e = hipMalloc(&it_ent, (size_t)total_cap * 64 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&it_cnt, (size_t)total_cap * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&it_m, (size_t)total_cap * sizeof(int32_t));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      single = false;  // (not enough memory for the generous regions: count first)
+      void* ps[] = {it_ent, it_cnt, it_m};
+      for (void* q : ps)
+        if (q) (void)hipFree(q);
+      it_ent = it_cnt = it_m = nullptr;
+    }
+  }
+  if (single) {
+    hipLaunchKernelGGL(k_ring_schedule<true>, dim3(nseg), dim3(64), flag_bytes, st, nseg, seg, bounds, keys2, meta, JM, span, z.R,
+                       z.Q, z.NC, d, cap, 4, iters, cap_base, it_ent, it_cnt, it_m, flag_rows, caps);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, iters, iter_base, nseg + 1, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&total_iters, iter_base + nseg, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+      drop_caps();
+      return fail(e, "ring layout: single-pass schedule");
+    }
+    tick("meta + single scheduling pass");
+    if (total_iters <= 0 || (int64_t)total_iters * 64 >= ((int64_t)1 << 31) - 64) {
+      // a stream overflowed its region (or the layout is too large for 32-bit positions)
+      if (panel_mode() != 1) {
+        drop_caps();
+        release(true);
+        return 0;
+      }
+      single = false;
+      void* ps[] = {it_ent, it_cnt, it_m};
+      for (void* q : ps)
+        if (q) (void)hipFree(q);
+      it_ent = it_cnt = it_m = nullptr;
+    }
+  }
+  if (!single) {
+    hipLaunchKernelGGL(k_ring_schedule<false>, dim3(nseg), dim3(64), flag_bytes, st, nseg, seg, bounds, keys2, meta, JM, span,
+                       z.R, z.Q, z.NC, d, cap, panel_mode() == 1 ? 0 : 4, iters, nullptr, nullptr, nullptr, nullptr, flag_rows,
+                       nullptr);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, iters, iter_base, nseg + 1, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(&total_iters, iter_base + nseg, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+      drop_caps();
+      return fail(e, "ring layout: counting pass");
+    }
+    tick("meta + counting pass");
+  }
   const int64_t Hp = (int64_t)total_iters * 64;  // padded half-edge count
   if (total_iters <= 0 || Hp >= ((int64_t)1 << 31) - 64) {
+    drop_caps();
     release(true);
     return 0;  // too large for 32-bit positions: the caller keeps the CSR layout
   }
   if (panel_mode() != 1 && (double)Hp > 1.35 * (double)H) {
     // distinct rows per iteration cost too much padding on this graph (hub rows): CSR kernel
+    drop_caps();
     release(true);
     return 0;
   }
-  RB(hipMalloc(&it_ent, (size_t)total_iters * 64 * sizeof(int32_t)));
-  RB(hipMalloc(&it_cnt, (size_t)total_iters * sizeof(int32_t)));
-  RB(hipMalloc(&it_m, (size_t)total_iters * sizeof(int32_t)));
-  RB(hipMalloc(&packed, (size_t)Hp * sizeof(uint32_t)));
-  RB(hipMalloc(&peid, (size_t)Hp * sizeof(int32_t)));
-  RB(hipMalloc(&hdr, (size_t)total_iters * MDE_RING_HW * sizeof(uint32_t)));
-  if (z.Q > 1) RB(hipMalloc(&partial, sizeof(float) * (size_t)z.Q * (size_t)nloc * (size_t)d));
-  hipLaunchKernelGGL(k_ring_schedule<true>, dim3(nseg), dim3(64), 0, st, nseg, seg, bounds, keys2, vals2, hrow, plan->nbr,
-                     JM, span, z.R, z.Q, z.NC, d, cap, 0, nullptr, iter_base, it_ent, it_cnt, it_m);
-  RB(hipGetLastError());
-  hipLaunchKernelGGL(k_ring_pack, dim3(mde_grid((int64_t)total_iters * 64, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st,
-                     (int64_t)total_iters, it_ent, it_cnt, it_m, keys2, vals2, hrow, plan->nbr, plan->eid, z.R, z.Q, z.C,
-                     z.S, z.ring_off, z.JB, d, (int)plan->row_lo, place, packed, peid, hdr);
-  RB(hipGetLastError());
+  e = hipSuccess;
+  if (!single) {
+    e = hipMalloc(&it_ent, (size_t)total_iters * 64 * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&it_cnt, (size_t)total_iters * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc(&it_m, (size_t)total_iters * sizeof(int32_t));
+  }
+  if (e == hipSuccess) e = hipMalloc(&packed, (size_t)Hp * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc(&peid, (size_t)Hp * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMalloc(&hdr, (size_t)total_iters * MDE_RING_HW * sizeof(uint32_t));
+  if (e == hipSuccess && z.Q > 1) e = hipMalloc(&partial, sizeof(float) * (size_t)z.Q * (size_t)nloc * (size_t)d);
+  if (e != hipSuccess) {
+    drop_caps();
+    return fail(e, "ring layout: output allocations");
+  }
+  tick("output allocations");
+  if (!single) {
+    hipLaunchKernelGGL(k_ring_schedule<true>, dim3(nseg), dim3(64), flag_bytes, st, nseg, seg, bounds, keys2, meta, JM, span, z.R,
+                       z.Q, z.NC, d, cap, 0, nullptr, iter_base, it_ent, it_cnt, it_m, flag_rows, nullptr);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_ring_pack, dim3(mde_grid((int64_t)total_iters * 64, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st,
+                       (int64_t)total_iters, nseg, iter_base, single ? cap_base : nullptr, it_ent, it_cnt, it_m, keys2, vals2, hrow,
+                       plan->nbr, plan->eid, z.R, z.Q, z.C, z.S, z.ring_off, z.JB, d, (int)plan->row_lo, place, packed, peid, hdr);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);  // (cap_base is read by the pack kernel)
+  drop_caps();
+  if (e != hipSuccess) return fail(e, "ring layout: fill / pack");
   hipLaunchKernelGGL(k_ring_block_class, dim3((unsigned)((total_iters / 4 + MDE_BLOCK - 1) / MDE_BLOCK)), dim3(MDE_BLOCK), 0, st,
                      (int64_t)(total_iters / 4), hdr);
   RB(hipGetLastError());
@@ -816,7 +990,9 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
             100.0 * hstat[2] / total_iters);
   }
 #undef RB
+  tick("fill pass, pack, classes");
   release(false);
+  tick("scratch release");
   mde_ring_layout& L = plan->ring;
   ring_free(L);
   L.d = d;
