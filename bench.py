@@ -507,6 +507,78 @@ def run_config5_embed(args, device):
     }
 
 
+def run_config4_embed(args, device):
+    """The headline shape as an embed() (SURVEY 8d's secondary metric): n = 1M, |E| = 50M, d = 2, Log1p,
+    Centered and Standardized -- seconds per projected L-BFGS iteration after a warm-up solve, objective
+    evaluations per iteration, and what building the problem costs (plan / ring layout / parameters)."""
+    import ctypes
+    import pymde_amd
+    from pymde_amd import _lib
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    n, d = args.n, DIM
+    edges, w, _ = make_workload(device, n=n)
+    p = edges.shape[0]
+    lib = _lib.load()
+
+    def timed(fn):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize(device)
+        return r, time.perf_counter() - t0
+
+    # what the problem costs to build, stage by stage (the same calls MDE.__init__ and the first
+    # evaluation make)
+    plan, t_plan = timed(lambda: EdgePlan(n, edges))
+    _, t_layout = timed(lambda: lib.mde_plan_layout(plan.handle, d, _lib.stream_ptr(device)))
+    f = pymde_amd.penalties.Log1p(w)
+    binding, t_bind = timed(lambda: Binding(plan, f))
+    _, t_struct = timed(lambda: binding.struct(d))
+    del binding, plan
+    iters = max(args.steps if args.steps != 200 else 30, 1)
+    records = {}
+    for cname, c in (("Centered", pymde_amd.Centered()), ("Standardized", pymde_amd.Standardized())):
+        mde, t_mde = timed(lambda: pymde_amd.MDE(n, d, edges, pymde_amd.penalties.Log1p(w), constraint=c, device=device))
+        torch.manual_seed(0)
+        X0 = c.initialization(n, d, device=device).contiguous()
+        _, t_first = timed(lambda: mde.embed(X=X0.clone(), max_iter=5, eps=0.0))     # warm-up (builds layout + binding)
+        _, dt = timed(lambda: mde.embed(X=X0.clone(), max_iter=iters, eps=0.0))
+        st = mde.solve_stats
+        n_it = max(int(st.iterations), 1)
+        X = mde.X.detach().contiguous()
+        buf = torch.zeros(n * d + 1, dtype=torch.float32, device=device)
+        grad, loss = buf[:n * d].view(n, d), buf[n * d:]
+        b = mde._binding()
+        t_eval, _ = time_launches(lambda: fused_evaluate(b, X, grad, loss), 20, device)
+        Z = torch.randn((n, d), device=device)
+        t_tan, _ = time_launches(lambda: c.project_onto_tangent_space(X, Z, inplace=True), 20, device)
+        Y = X.clone()
+        t_ret, _ = time_launches(lambda: c.project_onto_constraint(Y, inplace=True), 20, device)
+        records[cname] = {
+            "s_per_iter": dt / n_it, "ms_per_iter": 1e3 * dt / n_it, "iterations": n_it,
+            "evaluations": st.evaluations, "evaluations_per_iteration": (st.evaluations or 0) / n_it,
+            "first_embed_5_iterations_s": t_first, "mde_constructor_s": t_mde,
+            "average_distortions": [float(v) for v in st.average_distortions[:8]],
+            "component_ms": {"average_distortion fwd+bwd (ring kernel + combine)": t_eval,
+                             "tangent projection": t_tan, "retraction": t_ret},
+        }
+        del mde
+    main = records["Centered"]
+    return {
+        "metric": "seconds/iteration of MDE.embed(), n=1M |E|=50M d=2 Log1p", "value": main["s_per_iter"], "unit": "s/iter",
+        "n_gpus": 1, "steps": main["iterations"], "warmup": 5, "ms_per_step": main["ms_per_iter"], "higher_is_better": False,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3] / SURVEY 8d config 4a as an embed(): n=%d, |E|=%d uniform-random edges "
+                               "(out-degree 50), d=2, penalties.Log1p(1.5), weights in {1,2}, L-BFGS memory 10, "
+                               "X0 = constraint.initialization; value = the Centered solve" % (n, p),
+                   "parallelism": "single GPU", "edges_per_s_per_iter": p / main["s_per_iter"],
+                   "embed": records,
+                   "problem_build_s": {"edge plan (validate, sort, CSR)": t_plan, "ring layout": t_layout,
+                                       "parameters (expand + codebook)": t_bind + t_struct,
+                                       "total": t_plan + t_layout + t_bind + t_struct}},
+    }
+
+
 # ------------------------------------------------------------------------------------------ configs 2, 3
 def scale_free_edges(n, m, seed):
     """Barabasi-Albert-style preferential attachment (m links per new node), numpy only."""
@@ -624,7 +696,7 @@ def main():
     ap.add_argument("--config", type=int, default=4, choices=(2, 3, 4, 5))
     ap.add_argument("--variant", default="4a", choices=("4a", "4b"),
                     help="config 4 only: 4a Log1p (the headline), 4b PushAndPull(Log1p, Log) with 1/3 repulsive edges")
-    ap.add_argument("--embed", action="store_true", help="config 5 only: a Standardized embed() at that shape")
+    ap.add_argument("--embed", action="store_true", help="configs 4 and 5: a full embed() at that shape (s/iter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-codebook", action="store_true",
                     help="stream the weights as fp32 (8 B/half-edge) even though they take 2 values")
@@ -663,7 +735,11 @@ def main():
     device = torch.device("cuda", (local_rank % ndev) if world > 1 else 0)
     torch.cuda.set_device(device)
 
-    if args.config == 4:
+    if args.config == 4 and args.embed:
+        if world > 1:
+            raise SystemExit("--config 4 --embed is a single-GPU record")
+        out = run_config4_embed(args, device)
+    elif args.config == 4:
         out = run_config4(args, world, rank, device)
     elif world > 1:
         raise SystemExit("--config %d is a single-GPU record" % args.config)

@@ -370,6 +370,15 @@ int mde_lbfgs_dev_reset(mde_lbfgs* o, void* stream);
 int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, const float* d, float t,
                        float* d_out, double* stats, double* work, void* stream);
 int mde_lbfgs_dev_info(const mde_lbfgs* o, int32_t* count_host, int32_t* accepted_host, void* stream);
+/* Which form mde_lbfgs_dev_step takes (process-wide; read from the environment on first use:
+ * MDE_LB_UNFUSED, MDE_LB_DEBUG = "blocks,spins,lds_bytes").  For N <= 2^18 the step is ONE launch whose
+ * workgroups meet at grid-wide arrival points; an ordinary launch cannot guarantee that they are all
+ * resident, so a workgroup that waits longer than `spins` polls gives up and a rescue kernel queued
+ * behind redoes the step from the staged sums -- the direction is the four-launch path's either way.
+ * unfused != 0 forces the four launches; blocks / spins / lds_bytes > 0 (tests) launch that many
+ * workgroups, with that spin limit and that much dynamic LDS each, so that the give-up path can be
+ * provoked.  A negative argument leaves that setting as it is. */
+int mde_lbfgs_debug_knobs(int32_t unfused, int32_t blocks, int32_t spins, int32_t lds_bytes);
 
 /* ---- the solver's read-back -------------------------------------------------------------------------
  * device -> pinned-host copy on the stream: [loss | status | statistics board] travels in one copy per

@@ -99,6 +99,7 @@ SYMBOLS = {
     "mde_lbfgs_commit": (c_i32, [c_vp, c_i32]),
     "mde_lbfgs_dev_reset": (c_i32, [c_vp, c_vp]),
     "mde_lbfgs_dev_step": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_vp]),
+    "mde_lbfgs_debug_knobs": (c_i32, [c_i32, c_i32, c_i32, c_i32]),
     "mde_lbfgs_dev_info": (c_i32, [c_vp, ctypes.POINTER(c_i32), ctypes.POINTER(c_i32), c_vp]),
     "mde_lbfgs_combine": (c_i32, [c_vp, c_vp, c_f32, ctypes.POINTER(c_f32),
                                   ctypes.POINTER(c_f32), c_vp, c_vp, c_vp, c_vp]),

@@ -1893,8 +1893,14 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* 
                                                         const float* d, float t, float* __restrict__ buf,
                                                         LbDev* __restrict__ dv, int history, float* out,  // (out may be d)
                                                         double* __restrict__ partial, double* __restrict__ stats,
-                                                        unsigned int* __restrict__ flags, unsigned int epoch) {
+                                                        unsigned int* __restrict__ flags, unsigned int epoch,
+                                                        unsigned int spin_limit) {
   constexpr int LD = MDE_LB_FUSED_LD;
+  extern __shared__ char lb_debug_lds[];  // (only a test asks for dynamic LDS: it limits the workgroups per CU)
+  (void)lb_debug_lds;
+  // words behind the three flag rows: [0] = epoch once some workgroup gave up waiting, [1] = epoch once
+  // the step is complete (k_lb_rescue redoes the step from the staged sums when it is not)
+  unsigned int* verdict = flags + 3 * MDE_LB_FUSED_MAXBLOCKS;
   __shared__ double sm[MDE_BLOCK / 64][MDE_LB_NVAL];
   __shared__ double s_dots[4 + 5 * LD];
   __shared__ double s_SY[LD * LD], s_YY[LD * LD];
@@ -1913,18 +1919,27 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* 
     __syncthreads();
     unsigned int* f = flags + which * MDE_LB_FUSED_MAXBLOCKS;
     if (threadIdx.x == 0) __hip_atomic_store(f + b, epoch + (unsigned int)which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (!wait) return;
-    // (a workgroup that never sees the others arrive gives up after ~1 s and lets the result be wrong
-    // rather than hanging the queue)
-    for (unsigned int spins = 0; spins < (1u << 22); ++spins) {
+    if (!wait) return true;
+    // The arrival points need every workgroup of the launch resident at once (an ordinary launch of at
+    // most 128 workgroups: normally true).  A workgroup that does not see the others arrive within the
+    // spin limit -- another process holds the CUs -- says so in verdict[0] and LEAVES: nobody gets past
+    // a later arrival point then, nothing of the step's outputs is final, and k_lb_rescue (queued
+    // behind this kernel) redoes the step from the staged sums.  Never a wrong direction, never a hang.
+    for (unsigned int spins = 0;; ++spins) {
       bool ok = true;
       for (int k = threadIdx.x; k < nb; k += MDE_BLOCK)
         ok = ok && __hip_atomic_load(f + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch + (unsigned int)which;
       if (__syncthreads_and(ok ? 1 : 0)) break;
+      const bool failed = __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
+      if (__syncthreads_or((failed || spins >= spin_limit) ? 1 : 0)) {
+        if (threadIdx.x == 0) __hip_atomic_store(verdict, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return false;
+      }
       __builtin_amdgcn_s_sleep(1);
     }
+    return __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch;
   };
-  grid_arrive(0, true);
+  if (!grid_arrive(0, true)) return;
   // ---- phase 2a: workgroup q adds row q of the partials (k_lb_reduce: same order of additions)
   const int nrows = 4 + 5 * count;
   double* dots_g = partial + (int64_t)(4 + 5 * LD + 8) * nb;  // behind the dot-product and statistics rows
@@ -1935,7 +1950,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* 
     if (threadIdx.x == 0) mde_st_partial(dots_g + q, tot);
     __syncthreads();
   }
-  grid_arrive(1, true);
+  if (!grid_arrive(1, true)) return;
   // ---- phase 2b: every workgroup runs the direction step on the same numbers
   for (int q = threadIdx.x; q < nrows; q += MDE_BLOCK) s_dots[q] = mde_ld_partial(dots_g + q);
   __syncthreads();
@@ -1978,9 +1993,73 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* 
   mde_publish8(v8, (1u << 3) | (1u << 6), spart, nb, b);
   // workgroup 0 finishes: the statistics rows, and the bookkeeping back to LbDev (everyone has
   // finished reading it when the third flag is up)
-  grid_arrive(2, b == 0);
+  if (!grid_arrive(2, b == 0)) return;
   if (b != 0) return;
   mde_final_rows(8, nb, spart, stats, (1ull << 3) | (1ull << 6));
+  if (wave == 0) lb_write_back<LD>(dv, history, s_SY, s_YY, &s_out);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(verdict + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Queued behind every k_lb_fused launch: nothing to do when that launch completed (verdict[1] ==
+// epoch; one workgroup, a few microseconds).  Otherwise -- some workgroup gave up at an arrival point --
+// ONE workgroup redoes phases 2 and 3 from the sums every workgroup staged in phase 1 (phase 1 has no
+// waits: all of them ran it; its side effects -- g_prev <- g, the new pair in its slot -- are exactly
+// what the four-launch path leaves behind its first launch), slowly but correctly: row sums, the
+// direction step, d_out and its statistics, the bookkeeping.
+__global__ __launch_bounds__(MDE_BLOCK) void k_lb_rescue(int64_t N, const float* __restrict__ g, const float* __restrict__ buf,
+                                                         LbDev* __restrict__ dv, int history, float* out, int nb,
+                                                         double* __restrict__ partial, double* __restrict__ stats,
+                                                         unsigned int* __restrict__ flags, unsigned int epoch) {
+  constexpr int LD = MDE_LB_FUSED_LD;
+  unsigned int* verdict = flags + 3 * MDE_LB_FUSED_MAXBLOCKS;
+  if (__hip_atomic_load(verdict + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return;
+  if (threadIdx.x == 0) verdict[2] += 1u;  // (how often the rescue had to run: tests read it from the work buffer)
+  __shared__ double sm[MDE_BLOCK / 64][MDE_LB_NVAL];
+  __shared__ double s_dots[4 + 5 * LD];
+  __shared__ double s_SY[LD * LD], s_YY[LD * LD];
+  __shared__ LbOut s_out;
+  const int wave = threadIdx.x >> 6;
+  const int nrows = 4 + 5 * dv->count;
+  for (int q = 0; q < nrows; ++q) {
+    double r = 0.0;
+    for (int k = threadIdx.x; k < nb; k += MDE_BLOCK) r += mde_ld_partial(partial + (int64_t)q * nb + k);
+    const double tot = mde_block_sum(r, &sm[0][0]);
+    if (threadIdx.x == 0) s_dots[q] = tot;
+    __syncthreads();
+  }
+  if (wave == 0) lb_direction_core<LD>(dv, s_dots, history, s_SY, s_YY, &s_out);
+  __syncthreads();
+  const int m = s_out.m;
+  const float c_g = s_out.c_g;
+  double gd = 0, gg = 0, g1 = 0, gm = 0, nf = 0, dd = 0, dm = 0;
+  for (int64_t i = threadIdx.x; i < N; i += MDE_BLOCK) {
+    const float gv = g[i];
+    float v = c_g * gv;
+    for (int j = 0; j < m; ++j) {
+      const float* sp = buf + (int64_t)(2 * s_out.order[j]) * N;
+      v = fmaf(s_out.cy[j], sp[N + i], fmaf(s_out.cs[j], sp[i], v));
+    }
+    out[i] = v;
+    const double gvd = gv, dv2 = v;
+    gg += gvd * gvd;
+    const double ag = fabs(gvd);
+    g1 += ag;
+    gm = ag > gm ? ag : gm;
+    nf += (fabsf(gv) <= 3.402823466e+38f) ? 0.0 : 1.0;
+    gd += gvd * dv2;
+    dd += dv2 * dv2;
+    const double ad = fabs(dv2);
+    dm = ad > dm ? ad : dm;
+  }
+  const double v8[8] = {gd, gg, g1, gm, nf, dd, dm, 0.0};
+  for (int q = 0; q < 8; ++q) {
+    const bool is_max = q == 3 || q == 6;
+    const double r = is_max ? mde_block_max(v8[q], &sm[0][0]) : mde_block_sum(v8[q], &sm[0][0]);
+    if (threadIdx.x == 0) stats[q] = r;
+    __syncthreads();
+  }
   if (wave == 0) lb_write_back<LD>(dv, history, s_SY, s_YY, &s_out);
 }
 
@@ -2113,6 +2192,29 @@ extern "C" int mde_lbfgs_dev_reset(mde_lbfgs* o, void* stream) {
   return MDE_OK;
 }
 
+// (environment knobs are read once, not per step: MDE_LB_UNFUSED forces the four-launch path;
+// MDE_LB_DEBUG = "blocks,spins,lds_bytes" lets a test launch more workgroups than can be resident and
+// watch the rescue kernel take over; mde_lbfgs_debug_knobs changes them inside a process)
+struct LbKnobs {
+  bool unfused;
+  int blocks, spins, lds;
+  LbKnobs() : unfused(getenv("MDE_LB_UNFUSED") != nullptr), blocks(0), spins(0), lds(0) {
+    if (const char* e = getenv("MDE_LB_DEBUG")) sscanf(e, "%d,%d,%d", &blocks, &spins, &lds);
+  }
+};
+static LbKnobs& lb_knobs() {
+  static LbKnobs k;
+  return k;
+}
+extern "C" int mde_lbfgs_debug_knobs(int32_t unfused, int32_t blocks, int32_t spins, int32_t lds_bytes) {
+  LbKnobs& k = lb_knobs();
+  if (unfused >= 0) k.unfused = unfused != 0;
+  if (blocks >= 0) k.blocks = blocks;
+  if (spins >= 0) k.spins = spins;
+  if (lds_bytes >= 0) k.lds = lds_bytes;
+  return MDE_OK;
+}
+
 // One whole L-BFGS direction update without a host round trip: stage (y = g - g_prev, s = t d,
 // g_prev <- g), accept / reject, two-loop recursion, d_out = the new direction, stats as
 // mde_vec_stats(g, d_out, NULL).  ASYNC.  (The host-driven mde_lbfgs_stage / commit / combine act on
@@ -2123,16 +2225,28 @@ extern "C" int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, c
   hipStream_t st = mde_stream(stream);
   const int64_t N = o->N;
   double* partial = work + MDE_SMALL_DOUBLES;
-  if (N <= MDE_LB_FUSED_MAXN && o->history < MDE_LB_FUSED_LD && !getenv("MDE_LB_UNFUSED")) {
+  // (environment knobs are read once: MDE_LB_UNFUSED forces the four-launch path; MDE_LB_DEBUG =
+  // "blocks,spins,lds_bytes" lets a test launch more workgroups than can be resident and watch the
+  // rescue kernel take over)
+  const LbKnobs& knobs = lb_knobs();
+  if (N <= MDE_LB_FUSED_MAXN && o->history < MDE_LB_FUSED_LD && !knobs.unfused) {
     // At most 128 workgroups: the arrival points need every workgroup of the launch resident at once.
     // The kernel fits two workgroups per CU (198 VGPRs), i.e. 512 on the chip -- 128 leaves room for
-    // whatever else is resident, e.g. the same kernel of other processes sharing the GPU (two ranks of
-    // a test on one device: 469 workgroups each deadlocked until the spin limit).
-    const int nbf = mde_grid(N, MDE_BLOCK * 2, 128);
+    // whatever else is resident, e.g. the same kernel of other processes sharing the GPU.  Residency
+    // is still not GUARANTEED by an ordinary launch: a workgroup that waits longer than the spin limit
+    // gives up, and k_lb_rescue (always queued behind) redoes the step -- see k_lb_fused.
+    int nbf = mde_grid(N, MDE_BLOCK * 2, 128);
+    if (knobs.blocks > 0) nbf = std::min(knobs.blocks, MDE_LB_FUSED_MAXBLOCKS);
+    const unsigned int spin_limit = knobs.spins > 0 ? (unsigned int)knobs.spins : (1u << 20);
     static std::atomic<unsigned int> launches{0};  // one epoch per launch, shared by every solver object
     const unsigned int epoch = 4u * (launches.fetch_add(1u) + 1u);
-    hipLaunchKernelGGL(k_lb_fused, dim3(nbf), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t, o->buf, o->dev, o->history,
-                       d_out, partial, stats, work_lb_flags(work), epoch);
+    if (knobs.lds > 0)
+      MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lb_fused), hipFuncAttributeMaxDynamicSharedMemorySize, knobs.lds));
+    hipLaunchKernelGGL(k_lb_fused, dim3(nbf), dim3(MDE_BLOCK), (size_t)std::max(knobs.lds, 0), st, N, g, g_prev, d, t, o->buf,
+                       o->dev, o->history, d_out, partial, stats, work_lb_flags(work), epoch, spin_limit);
+    MDE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_lb_rescue, dim3(1), dim3(MDE_BLOCK), 0, st, N, g, o->buf, o->dev, o->history, d_out, nbf, partial, stats,
+                       work_lb_flags(work), epoch);
     MDE_LAUNCH_CHECK();
     return MDE_OK;
   }

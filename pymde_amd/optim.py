@@ -39,7 +39,7 @@ class SolveStats(object):
     """
 
     def __init__(self, average_distortions, residual_norms, step_size_percents, solve_time, times,
-                 snapshots, snapshot_every):
+                 snapshots, snapshot_every, evaluations=None):
         self.average_distortions = average_distortions
         self.residual_norms = residual_norms
         self.step_size_percents = step_size_percents
@@ -48,6 +48,7 @@ class SolveStats(object):
         self.times = times
         self.snapshots = snapshots
         self.snapshot_every = snapshot_every
+        self.evaluations = evaluations  # objective evaluations of the solve (not in the reference's record)
 
     def __str__(self):
         return ("SolveStats:\n\taverage distortion {0:.3g}\n\tresidual norm {1:.3g}\n"
@@ -368,6 +369,7 @@ def lbfgs(X, objective_fn, constraint, eps, max_iter, memory_size, use_line_sear
     """
     start_time = time.time()
     average_distortions, grad_norms, step_size_percents, times, snapshots = [], [], [], [], []
+    n_evals = [0]
 
     # (Replaying the usual iteration as one HIP graph was built in round 2 and measured SLOWER than the
     # launches it replaces on ROCm 7.2 -- config 2: 0.249 vs 0.178 ms per iteration -- and was removed in
@@ -381,7 +383,7 @@ def lbfgs(X, objective_fn, constraint, eps, max_iter, memory_size, use_line_sear
                 problem = _make_problem(engine, objective_fn, constraint)
                 _solve(engine, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
                        print_every, snapshot_every, logger, average_distortions, grad_norms,
-                       step_size_percents, times, snapshots)
+                       step_size_percents, times, snapshots, n_evals)
             X_final = engine.X
         finally:
             engine._stream_obj.synchronize()
@@ -391,13 +393,13 @@ def lbfgs(X, objective_fn, constraint, eps, max_iter, memory_size, use_line_sear
         X.copy_(X_final)  # the reference updates the caller's tensor in place
         X_final = X
     stats = SolveStats(average_distortions, grad_norms, step_size_percents,
-                       time.time() - start_time, times, snapshots, snapshot_every)
+                       time.time() - start_time, times, snapshots, snapshot_every, evaluations=n_evals[0])
     return X_final, stats
 
 
 def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose, print_every,
            snapshot_every, logger, average_distortions, grad_norms, step_size_percents, times,
-           snapshots):
+           snapshots, n_evals):
     digits = len(str(max_iter))
     start = time.time()
 
@@ -410,6 +412,7 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
     def evaluate_at_current():
         """closure() at X: no move, no retraction (lbfgs.py:426)."""
         problem.value_and_grad(e.X)
+        n_evals[0] += 1
         e.stats(e.g, None, e.X)
         vals, loss = e.read_board(8)
         return loss, vals
@@ -419,6 +422,7 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
     def enqueue_trial(tt):
         problem.retract_step(tt, e.X_trial)
         problem.value_grad_stats(e.X_trial)
+        n_evals[0] += 1
 
     def finish_trial(tt, extra=0):
         v, f = e.finish_read(8 + extra)
@@ -491,6 +495,7 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
                 _lib.check(e.lib.mde_turn_wait(turn_ref, cur, float(loss), 1 if go_on else 0, 1e-4, 0.9,
                                                turn_out_ptr, e._stream))
                 o = turn_out
+                n_evals[0] += 1 if o[2] != 0.0 else 0  # (the next iteration's first trial, launched inside mde_turn_wait)
                 tv = o[4:12]
                 last_eval["t"], last_eval["gg"], last_eval["xx"] = t, tv[_GG], tv[_XX]
                 first = (float(o[0]), tv[_GD], tv[_NONFINITE] == 0)
@@ -561,6 +566,7 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
                     and not (snapshot_every is not None and (iteration + 1) % snapshot_every == 0)):
                 if turn is not None:
                     _lib.check(e.lib.mde_turn_enqueue(turn_ref, 0 if e.X is turn_bufs[0] else 1, float(t), e._stream))
+                    n_evals[0] += 1
                 else:
                     e.update_direction(t)
                     enqueue_trial(1.0)

@@ -267,18 +267,34 @@ def test_spectral_initialiser(golden_spectral):
     assert float(mde.average_distortion(emb)) == pytest.approx(float(g["mid_value"]), rel=1e-3)
 
 
-@pytest.mark.parametrize("N,unfused", [(3001, False), (3001, True), (70001, False), (70001, True)])
-def test_device_driven_lbfgs_step_matches_explicit_two_loop(monkeypatch, N, unfused):
+@pytest.fixture
+def lb_knobs():
+    """Sets the process-wide form of mde_lbfgs_dev_step for one test and restores the defaults."""
+    from pymde_amd import _lib
+    lib = _lib.load()
+    yield lambda unfused=0, blocks=0, spins=0, lds=0: _lib.check(lib.mde_lbfgs_debug_knobs(unfused, blocks, spins, lds))
+    _lib.check(lib.mde_lbfgs_debug_knobs(0, 0, 0, 0))
+
+
+@pytest.mark.parametrize("N,unfused", [(3001, "fused"), (3001, "unfused"), (70001, "fused"), (70001, "unfused"),
+                                       (3001, "rescue"), (70001, "rescue")])
+def test_device_driven_lbfgs_step_matches_explicit_two_loop(lb_knobs, N, unfused):
     """mde_lbfgs_dev_step (history update, acceptance test and two-loop recursion all on the
     device) against the explicit recursion of lbfgs.py:468-507 in float64, incl. the history
     wrap-around (more than 8 pairs: two kernel groups) and a rejected pair (y.s <= 1e-10).  Both
-    forms: the single launch with a grid-wide arrival counter that small vectors take (one / many
-    workgroups), and the four launches of large vectors (forced with MDE_LB_UNFUSED)."""
+    forms: the single launch with grid-wide arrival points that small vectors take (one / many
+    workgroups), and the four launches of large vectors (forced through mde_lbfgs_debug_knobs).
+    "rescue": the single launch with 512 workgroups of 100 KB of LDS each -- one per CU, i.e. at most
+    256 of them resident on the chip -- and a spin limit of 2000 polls: the resident workgroups wait
+    for the others at the first arrival point, give up, and the rescue kernel queued behind the
+    launch redoes the step.  The direction must be the same (never a silently wrong one)."""
     import ctypes
     from pymde_amd import _lib, util
     lib = _lib.load()
-    if unfused:
-        monkeypatch.setenv("MDE_LB_UNFUSED", "1")
+    if unfused == "unfused":
+        lb_knobs(unfused=1)
+    elif unfused == "rescue":
+        lb_knobs(blocks=512, spins=2000, lds=100 * 1024)
     rng = np.random.default_rng(0)
     A = rng.standard_normal((60, N))
     diag = rng.uniform(0.5, 2.0, N)
@@ -292,6 +308,7 @@ def test_device_driven_lbfgs_step_matches_explicit_two_loop(monkeypatch, N, unfu
         st = _lib.stream_ptr(torch.device(DEV))
         _lib.check(lib.mde_lbfgs_dev_reset(h, st))
         work = util.work_buffer(torch.device(DEV), 2)
+        work.view(torch.int32)[2 * 2304 + 3 * 512 + 2] = 0
         board = torch.zeros(64, dtype=torch.float64, device=DEV)
         x = rng.standard_normal(N)
         g_prev_np = grad(x)
@@ -339,6 +356,10 @@ def test_device_driven_lbfgs_step_matches_explicit_two_loop(monkeypatch, N, unfu
             b = board.cpu().numpy()
             assert b[0] == pytest.approx(float(np.dot(g_np.astype(np.float64), got)), rel=1e-6)   # g.d
             assert b[5] == pytest.approx(float(np.dot(got, got)), rel=1e-6)                       # d.d
+        if hist < 16 and unfused != "unfused":
+            # (the work buffer's flag area: 3 x 512 arrival flags, then gave-up / done / rescue count)
+            rescues = int(work.view(torch.int32)[2 * 2304 + 3 * 512 + 2])
+            assert (rescues > 0) == (unfused == "rescue"), rescues
         _lib.check(lib.mde_lbfgs_destroy(h))
 
 
