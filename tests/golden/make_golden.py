@@ -14,6 +14,7 @@ Fixtures
                     incl. coincident points (d_k = 0)         -> pins average_distortion.py:62-106
   constraints.npz   Centered / Standardized / Anchored maps   -> pins constraints.py, util.py:129-171
   trajectories.npz  per-iteration SolveStats of short embed() runs (optim.py / lbfgs.py)
+  trajectories_mid.npz  the same at n = 20k, p ~ 300k (two problems x 4 perturbation levels, 8 iterations)
   spectral.npz      quadratic.spectral on small graphs         -> pins quadratic.py
   preprocess.npz    deduplicate_edges / sample_edges of the reference
   cycle.npz         BASELINE config 1 scaled down: preserve_distances on a cycle graph,
@@ -285,6 +286,70 @@ def gen_trajectories(pymde, torch):
     print("trajectories.npz:", names)
 
 
+def mid_problem_arrays(which):
+    """Numpy-seeded inputs of the two mid-size trajectory cases (the test regenerates them with the same
+    calls; the fixture stores only X0, the reference's statistics and a checksum of the edges).
+    'neighbors': the config-2 stand-in scaled to n = 20k -- 10 'neighbour' edges (weights 1 / 2) and 5
+    'dissimilar' edges (weight -1) per item, PushAndPull(Log1p, Log), Standardized.  'distances': a
+    preserve_distances-shaped problem, 300k random pairs with target distances, losses.Huber(0.5),
+    Centered."""
+    n = 20000
+    rng = np.random.default_rng(4242 if which == "neighbors" else 4343)
+    deg = 15
+    src = np.repeat(np.arange(n), deg)
+    dst = rng.integers(0, n - 1, n * deg)
+    dst += dst >= src
+    e = np.stack([np.minimum(src, dst), np.maximum(src, dst)], 1)
+    key = np.unique(e[:, 0].astype(np.int64) * n + e[:, 1])
+    edges = np.stack([key // n, key % n], 1)
+    p = len(edges)
+    if which == "neighbors":
+        w = np.where(rng.random(p) < 2.0 / 3.0, 1.0 + (rng.random(p) < 0.3), -1.0).astype(np.float32)
+        return n, edges, w
+    dev = rng.uniform(0.5, 3.0, p).astype(np.float32)
+    return n, edges, dev
+
+
+def gen_trajectories_mid(pymde, torch):
+    """First 8 iterations of the reference's embed() on two problems of realistic size (n = 20k,
+    p ~ 300k), from X0 and from X0 perturbed by 1e-7 / 1e-6 / 1e-5 (relative): SURVEY 8c's
+    "first iterations within rtol 1e-3 of the oracle run with identical init" at scale."""
+    torch.set_num_threads(8)  # (the summation order of scatter_add_ on 300k edges is thread-count dependent only in the last bits)
+    out = {}
+    NOISE = [0.0, 1e-7, 1e-6, 1e-5]
+    for which in ("neighbors", "distances"):
+        n, edges, par = mid_problem_arrays(which)
+        out[which + "__edge_checksum"] = np.array([int(edges[:, 0].sum()), int(edges[:, 1].sum()), len(edges)])
+        out[which + "__param_checksum"] = np.array([float(np.abs(par).astype(np.float64).sum())])
+        torch.manual_seed(0)
+        if which == "neighbors":
+            c = pymde.Standardized()
+            make_f = lambda: pymde.penalties.PushAndPull(torch.tensor(par), pymde.penalties.Log1p, pymde.penalties.Log)
+        else:
+            c = pymde.Centered()
+            make_f = lambda: pymde.losses.Huber(torch.tensor(par), 0.5)
+        X0 = c.initialization(n, 2)
+        out[which + "__X0"] = X0.numpy()
+        E, R, S = [], [], []
+        for trial, noise in enumerate(NOISE):
+            gen = torch.Generator().manual_seed(200 + trial)
+            Xs = X0 * (1 + noise * torch.randn(X0.shape, generator=gen))
+            mde = pymde.MDE(n, 2, torch.tensor(edges), make_f(), constraint=c)
+            mde.embed(X=Xs, max_iter=8, eps=1e-12, memory_size=10)
+            st = mde.solve_stats
+            pad = lambda v: np.pad(np.array(v, dtype=np.float64), (0, 8 - len(v)), constant_values=np.nan)
+            E.append(pad(st.average_distortions))
+            R.append(pad(st.residual_norms))
+            S.append(pad(st.step_size_percents))
+            print(which, "noise", noise, E[-1][:4])
+        out[which + "__distortions"] = np.stack(E)
+        out[which + "__residuals"] = np.stack(R)
+        out[which + "__steps"] = np.stack(S)
+    out["noise"] = np.array(NOISE)
+    np.savez_compressed(os.path.join(HERE, "trajectories_mid.npz"), **out)
+    print("trajectories_mid.npz written")
+
+
 def gen_spectral(pymde, torch):
     from pymde import quadratic
     out = {}
@@ -502,6 +567,7 @@ def main():
     gen_linesearch(pymde, torch)
     gen_constraints(pymde, torch)
     gen_trajectories(pymde, torch)
+    gen_trajectories_mid(pymde, torch)
     gen_spectral(pymde, torch)
     gen_cycle(pymde, torch)
     gen_preprocess(pymde, torch)
