@@ -366,10 +366,21 @@ struct FnPushPull {
   static constexpr float kParamScale = 1.0f;
   MdeFuncArgs A;
   MDE_DEV void eval(float ss, float a0, float a1, float& f, float& gd) const {
+#ifndef MDE_PUSHPULL_SELECT
     if (a0 >= 0.0f)
       mde_eval<KA, EA>(ss, a0, a1, A.S, f, gd);
     else
       mde_eval<KR, ER>(ss, a0, a1, A.N, f, gd);
+#else
+    // (round 4: both branches + a select measured SLOWER on the ring kernel than the divergent
+    // if / else -- config 4b 0.295 vs 0.267 ms -- kept for reference)
+    float fa, ga, fr, gr;
+    mde_eval<KA, EA>(ss, a0, a1, A.S, fa, ga);
+    mde_eval<KR, ER>(ss, a0, a1, A.N, fr, gr);
+    const bool att = a0 >= 0.0f;  // [ref: penalties.py:390 -- zero weight is attractive]
+    f = att ? fa : fr;
+    gd = att ? ga : gr;
+#endif
   }
 };
 
