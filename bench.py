@@ -260,6 +260,23 @@ def run_config4(args, world, rank, device):
         w[(2 * p) // 3:] = -1.0
         f = pymde_amd.penalties.PushAndPull(w, pymde_amd.penalties.Log1p, pymde_amd.penalties.Log)
         fname = "PushAndPull(Log1p(1.5), Log(1)), weights {1,2} on the first 2/3 of the edges, -1 on the last third"
+    elif args.function != "log1p":
+        # secondary records: what another distortion function costs on the same kernel (compile-time
+        # functors for the common kinds, the run-time functor for the rest)
+        pen, los = pymde_amd.penalties, pymde_amd.losses
+        dev = 0.5 + w  # deviations in {1.5, 2.5} for the losses
+        f, fname = {
+            "quadratic": lambda: (pen.Quadratic(w), "penalties.Quadratic"),
+            "linear": lambda: (pen.Linear(w), "penalties.Linear"),
+            "cubic": lambda: (pen.Cubic(w), "penalties.Cubic"),
+            "huber": lambda: (pen.Huber(w, 0.5), "penalties.Huber(0.5)"),
+            "log": lambda: (pen.Log(-w), "penalties.Log(1), weights in {-1,-2}"),
+            "log1p2": lambda: (pen.Log1p(w, exponent=2.0), "penalties.Log1p(2)"),
+            "l_huber": lambda: (los.Huber(dev, 0.5), "losses.Huber(0.5), deviations in {1.5,2.5}"),
+            "l_quadratic": lambda: (los.Quadratic(dev), "losses.Quadratic, deviations in {1.5,2.5}"),
+            "logistic": lambda: (pen.Logistic(w), "penalties.Logistic (run-time functor on the ring kernel)"),
+            "power": lambda: (pen.Power(w, 2.5), "penalties.Power(2.5) (run-time functor on the ring kernel)"),
+        }[args.function]()
     else:
         f = pymde_amd.penalties.Log1p(w)
         fname = "penalties.Log1p(1.5), weights in {1,2}"
@@ -320,13 +337,13 @@ def run_config4(args, world, rank, device):
     alg_bytes = ALG_BYTES_PER_EDGE * edges_local + 2.0 * 4.0 * d * (plan.row_hi - plan.row_lo)
     achieved = alg_bytes / (k_ms * 1e-3)
     layout = int(binding.struct(d).layout)
-    fn_name = "Log1p" if args.variant == "4a" else "PushPull<Log1p,Log>"
+    fn_name = ("Log1p" if args.function == "log1p" else args.function) if args.variant == "4a" else "PushPull<Log1p,Log>"
     kernel = ("k_fused_ring<2,%s,%s> (LDS-resident rows, chunk ring filled through the producers' VGPRs, loss reduced in "
               "the same launch) + k_ring_combine (adds the column groups' partial rows)"
               % (fn_name, "codebook" if binding.codebook else "fp32 stream")) if layout == 1 \
         else "k_fused_small<2,G,%s> (CSR) + 1-block loss finalize" % fn_name
     traffic, traffic_src = (None, None)
-    if world == 1 and args.emulate_world <= 1 and n == N_ITEMS and args.variant == "4a":
+    if world == 1 and args.emulate_world <= 1 and n == N_ITEMS and args.variant == "4a" and args.function == "log1p":
         traffic, traffic_src = pmc_traffic("ring_codebook" if binding.codebook else "ring_fp32" if layout == 1 else "csr")
 
     if rank != 0:
@@ -358,7 +375,7 @@ def run_config4(args, world, rank, device):
                      "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": k_ms,
                      "kernel_ms_mean": k_mean, "alg_bytes_per_launch": alg_bytes},
     }
-    if world == 1 and binding.codebook and not args.no_codebook and args.variant == "4a":
+    if world == 1 and binding.codebook and not args.no_codebook and args.variant == "4a" and args.function == "log1p":
         # secondary: the general case (continuous per-edge parameters, configs 2 / 3) streams an
         # fp32 parameter per half-edge
         os.environ["MDE_CODEBOOK"] = "0"
@@ -369,7 +386,7 @@ def run_config4(args, world, rank, device):
         out["config"]["fp32_parameter_stream"] = {
             "kernel_ms": k2, "value": p / (k2 * 1e-3), "unit": "edges/s/iter (kernel time)",
             "roofline_frac": alg_bytes / (k2 * 1e-3) / HBM_PEAK_BPS}
-    if world == 1 and args.emulate_world <= 1 and not args.no_cpu_baseline and args.variant == "4a":
+    if world == 1 and args.emulate_world <= 1 and not args.no_cpu_baseline and args.variant == "4a" and args.function == "log1p":
         cb, cpu_loss = cpu_baseline(edges, w, X, p)
         out["cpu_baseline"] = cb
         out["config"]["oracle_loss"] = cpu_loss
@@ -711,6 +728,10 @@ def main():
     ap.add_argument("--config", type=int, default=4, choices=(2, 3, 4, 5))
     ap.add_argument("--variant", default="4a", choices=("4a", "4b"),
                     help="config 4 only: 4a Log1p (the headline), 4b PushAndPull(Log1p, Log) with 1/3 repulsive edges")
+    ap.add_argument("--function", default="log1p",
+                    choices=("log1p", "quadratic", "linear", "cubic", "huber", "log", "log1p2", "l_huber", "l_quadratic",
+                             "logistic", "power"),
+                    help="config 4 only: another distortion function on the same graph (secondary records)")
     ap.add_argument("--embed", action="store_true", help="configs 4 and 5: a full embed() at that shape (s/iter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-codebook", action="store_true",

@@ -1927,22 +1927,50 @@ int mde_ring_try(mde_plan* plan, const float* X, int d, const mde_func* f, float
   }
   return 0;
 #else
+  // compile-time functors (the run-time one is ~6x the code per entry, and this kernel is bound by the
+  // instructions it issues) for d = 2 and 3, the dimensions embeddings are drawn in; d = 1 and 4 take
+  // the run-time functor.  LIN: a padding lane's parameter 0 gives f = 0 whatever its distance is.
+#define RING23(FN, LIN)                                        \
+  do {                                                         \
+    FN fn{a};                                                  \
+    if (d == 2)                                                \
+      rc = launch_ring<2, FN, LIN>(A, fn, nblocks);            \
+    else                                                       \
+      rc = launch_ring<3, FN, LIN>(A, fn, nblocks);            \
+    return rc == MDE_OK ? 1 : rc;                              \
+  } while (0)
   if (d == 2 || d == 3) {
     if (f->kind_neg == MDE_F_NONE) {
-      if (f->kind == MDE_F_LOG1P && ea == 2) RING(FnSingle<MDE_F_LOG1P COMMA 2>, true);
-      if (f->kind == MDE_F_QUADRATIC) RING(FnSingle<MDE_F_QUADRATIC COMMA 0>, true);
-      // the losses preserve_distances uses (deviations are per-edge targets, not weights: padding
-      // lanes are masked, LIN = false); the run-time functor is 6x the code of these
-      if (f->kind == MDE_F_L_QUADRATIC) RING(FnSingle<MDE_F_L_QUADRATIC COMMA 0>, false);
-      if (f->kind == MDE_F_L_ABSOLUTE) RING(FnSingle<MDE_F_L_ABSOLUTE COMMA 0>, false);
-      if (f->kind == MDE_F_L_HUBER) RING(FnSingle<MDE_F_L_HUBER COMMA 0>, false);
+      switch (f->kind) {
+        case MDE_F_LOG1P:  // [ref: penalties.py:310-321]
+          if (ea == 2) RING23(FnSingle<MDE_F_LOG1P COMMA 2>, true);
+          if (ea == 1) RING23(FnSingle<MDE_F_LOG1P COMMA 1>, true);
+          if (ea == 3) RING23(FnSingle<MDE_F_LOG1P COMMA 3>, true);
+          break;
+        case MDE_F_QUADRATIC: RING23(FnSingle<MDE_F_QUADRATIC COMMA 0>, true);   // penalties.py:123-131
+        case MDE_F_LINEAR: RING23(FnSingle<MDE_F_LINEAR COMMA 0>, true);         // penalties.py:112-120
+        case MDE_F_CUBIC: RING23(FnSingle<MDE_F_CUBIC COMMA 0>, true);           // penalties.py:163-171
+        case MDE_F_HUBER: RING23(FnSingle<MDE_F_HUBER COMMA 0>, true);           // penalties.py:205-243
+        case MDE_F_LOG:  // [ref: penalties.py:324-337]; w log(-expm1(-0)) = 0 x -inf on a padding lane: masked
+          if (ea == 1) RING23(FnSingle<MDE_F_LOG COMMA 1>, false);
+          if (ea == 3) RING23(FnSingle<MDE_F_LOG COMMA 3>, false);
+          break;
+        // the losses preserve_distances uses (deviations are per-edge targets, not weights: padding
+        // lanes are masked, LIN = false)
+        case MDE_F_L_QUADRATIC: RING23(FnSingle<MDE_F_L_QUADRATIC COMMA 0>, false);                    // losses.py:61-69
+        case MDE_F_L_WEIGHTED_QUADRATIC: RING23(FnSingle<MDE_F_L_WEIGHTED_QUADRATIC COMMA 0>, false);  // losses.py:72-87
+        case MDE_F_L_ABSOLUTE: RING23(FnSingle<MDE_F_L_ABSOLUTE COMMA 0>, false);                      // losses.py:166-174
+        case MDE_F_L_HUBER: RING23(FnSingle<MDE_F_L_HUBER COMMA 0>, false);                            // losses.py:101-125
+        default: break;
+      }
     } else if (f->kind == MDE_F_LOG1P && ea == 2) {
       if (f->kind_neg == MDE_F_LOG && en == 1)
-        RING(FnPushPull<MDE_F_LOG1P COMMA 2 COMMA MDE_F_LOG COMMA 1>, true);
+        RING23(FnPushPull<MDE_F_LOG1P COMMA 2 COMMA MDE_F_LOG COMMA 1>, true);
       if (f->kind_neg == MDE_F_LOGRATIO && en == 3)
-        RING(FnPushPull<MDE_F_LOG1P COMMA 2 COMMA MDE_F_LOGRATIO COMMA 3>, true);
+        RING23(FnPushPull<MDE_F_LOG1P COMMA 2 COMMA MDE_F_LOGRATIO COMMA 3>, true);
     }
   }
+#undef RING23
   RING(FnRuntime, false);
 #endif
 #undef RING
