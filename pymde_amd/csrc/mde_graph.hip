@@ -110,6 +110,52 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_sp_unpack(int64_t n, int64_t m, c
   }
 }
 
+// ---- unit lengths: bit-parallel multi-source BFS [ref: pymde/preprocess/_graph.pyx:10-52, one BFS per
+// source there].  64 sources share a machine word: per vertex v and word wi, frontier / visited hold
+// which of the sources 64 wi .. 64 wi + 63 have v on their current level / have reached v at all.  One
+// level for ALL sources of a batch is
+//      next[v] = (OR over neighbours u of frontier[u]) & ~visited[v];  visited[v] |= next[v]
+// i.e. O(half-edges x words) word operations instead of the O(half-edges x sources) relaxations of
+// the Bellman-Ford sweep above (config 3's 40k-node graph: 72 sweeps x 38 ms -> see DESIGN.md section 6).
+// A source's newly reached vertices get their hop count written into the same dist[b][v] matrix the
+// emit / top-k kernels read.
+__global__ __launch_bounds__(MDE_BLOCK) void k_bfs_seed(int64_t Bc, int W, int64_t src0, uint64_t* __restrict__ visited,
+                                                        uint64_t* __restrict__ frontier) {
+  const int64_t b = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x;
+  if (b >= Bc) return;
+  // (source b IS vertex src0 + b: no two sources share a word of one vertex)
+  const int64_t at = (src0 + b) * W + (b >> 6);
+  visited[at] = 1ull << (b & 63);
+  frontier[at] = 1ull << (b & 63);
+}
+
+__global__ __launch_bounds__(MDE_BLOCK) void k_bfs_level(int64_t n, int W, int64_t Bc, const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ nbr,
+                                                         const uint64_t* __restrict__ frontier,
+                                                         uint64_t* __restrict__ visited, uint64_t* __restrict__ next,
+                                                         float* __restrict__ dist, float level, int* __restrict__ changed) {
+  bool any = false;
+  for (int64_t t = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; t < n * W; t += (int64_t)gridDim.x * MDE_BLOCK) {
+    const int64_t v = t / W;
+    const int wi = (int)(t - v * W);
+    uint64_t acc = 0;
+    for (int h = rowptr[v]; h < rowptr[v + 1]; ++h) acc |= frontier[(int64_t)nbr[h] * W + wi];
+    uint64_t nx = acc & ~visited[t];
+    next[t] = nx;
+    if (nx) {
+      visited[t] |= nx;
+      any = true;
+      while (nx) {
+        const int bit = __ffsll((long long)nx) - 1;
+        nx &= nx - 1;
+        const int64_t b = (int64_t)wi * 64 + bit;
+        if (b < Bc) dist[b * n + v] = level;
+      }
+    }
+  }
+  if (__any(any) && (threadIdx.x & 63) == 0) *changed = 1;
+}
+
 struct GBuf {
   void* p = nullptr;
   ~GBuf() {
@@ -215,11 +261,40 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_sp_topk(int64_t n, int64_t src0, 
 
 // dist[b][.] = shortest-path lengths from source src0 + b, b < Bc (relaxed to the fixed point).
 // direct != 0: one-hop lengths only (the graph's own edge lengths; everything else stays INF).
+// masks: 3 x n x ceil(B / 64) words for the unit-length BFS (NULL: always the Bellman-Ford sweeps).
 static int sp_solve_batch(const mde_plan* plan, const float* w, float max_length, int direct, int64_t src0,
-                          int64_t Bc, float* dist, int* changed, int nblk, hipStream_t st) {
+                          int64_t Bc, float* dist, int* changed, int nblk, hipStream_t st, uint64_t* masks = nullptr,
+                          int W = 0) {
   const int64_t n = plan->n;
   hipLaunchKernelGGL(k_sp_init, dim3(nblk), dim3(MDE_BLOCK), 0, st, Bc, n, src0, dist);
   MDE_LAUNCH_CHECK();
+  if (!direct && !w && masks && W > 0) {
+    const size_t words = (size_t)n * W;
+    uint64_t *visited = masks, *fr = masks + words, *nx = masks + 2 * words;
+    MDE_HIP(hipMemsetAsync(visited, 0, 2 * words * sizeof(uint64_t), st));
+    hipLaunchKernelGGL(k_bfs_seed, dim3((unsigned)((Bc + MDE_BLOCK - 1) / MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, Bc, W, src0, visited,
+                       fr);
+    MDE_LAUNCH_CHECK();
+    const int nb = mde_grid((int64_t)words, MDE_BLOCK, 16384);
+    float level = 1.0f;
+    for (int64_t it = 0; it < n + 8 && level <= max_length; it += 4) {
+      MDE_HIP(hipMemsetAsync(changed, 0, sizeof(int), st));
+      for (int s4 = 0; s4 < 4 && level <= max_length; ++s4) {
+        hipLaunchKernelGGL(k_bfs_level, dim3(nb), dim3(MDE_BLOCK), 0, st, n, W, Bc, plan->rowptr, plan->nbr, fr, visited, nx, dist,
+                           level, changed);
+        MDE_LAUNCH_CHECK();
+        uint64_t* t = fr;
+        fr = nx;
+        nx = t;
+        level += 1.0f;
+      }
+      int h = 0;
+      MDE_HIP(hipMemcpyAsync(&h, changed, sizeof(int), hipMemcpyDeviceToHost, st));
+      MDE_HIP(hipStreamSynchronize(st));
+      if (!h) break;
+    }
+    return MDE_OK;
+  }
   if (direct) {
     hipLaunchKernelGGL(k_sp_direct, dim3(mde_grid(Bc * 64, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st, Bc, n,
                        src0, plan->rowptr, plan->nbr, w, max_length, dist);
@@ -269,7 +344,9 @@ extern "C" int mde_graph_shortest_paths(const mde_plan* plan, const float* w, fl
   int64_t B = ((int64_t)1 << 28) / (n > 0 ? n : 1);
   if (B < 1) B = 1;
   if (B > n) B = n;
-  GBuf dist, keys, vals, counter, changed;
+  GBuf dist, keys, vals, counter, changed, masks;
+  const int W = (int)((B + 63) / 64);
+  if (!w) MDE_HIP(masks.alloc(3 * (size_t)n * W * sizeof(uint64_t)));
   MDE_HIP(dist.alloc((size_t)B * n * sizeof(float)));
   MDE_HIP(keys.alloc((size_t)(capacity + 1) * sizeof(uint64_t)));
   MDE_HIP(vals.alloc((size_t)(capacity + 1) * sizeof(float)));
@@ -279,7 +356,8 @@ extern "C" int mde_graph_shortest_paths(const mde_plan* plan, const float* w, fl
   const int nblk = mde_grid(B * n, MDE_BLOCK, 8192);
   for (int64_t src0 = 0; src0 < n; src0 += B) {
     const int64_t Bc = (src0 + B <= n) ? B : n - src0;
-    const int rc = sp_solve_batch(plan, w, max_length, 0, src0, Bc, dist.as<float>(), changed.as<int>(), nblk, st);
+    const int rc = sp_solve_batch(plan, w, max_length, 0, src0, Bc, dist.as<float>(), changed.as<int>(), nblk, st,
+                                  w ? nullptr : masks.as<uint64_t>(), W);
     if (rc != MDE_OK) return rc;
     hipLaunchKernelGGL(k_sp_emit, dim3(nblk), dim3(MDE_BLOCK), 0, st, Bc, n, src0, dist.as<float>(), seed, threshold,
                        keep_all, capacity, counter.as<unsigned long long>(), keys.as<uint64_t>(), vals.as<float>());
@@ -331,13 +409,16 @@ extern "C" int mde_graph_knn(const mde_plan* plan, const float* w, float max_len
   int64_t B = ((int64_t)1 << 28) / (n > 0 ? n : 1);
   if (B < 1) B = 1;
   if (B > n) B = n;
-  GBuf dist, changed;
+  GBuf dist, changed, masks;
+  const int W = (int)((B + 63) / 64);
+  if (!w && !direct) MDE_HIP(masks.alloc(3 * (size_t)n * W * sizeof(uint64_t)));
   MDE_HIP(dist.alloc((size_t)B * n * sizeof(float)));
   MDE_HIP(changed.alloc(sizeof(int)));
   const int nblk = mde_grid(B * n, MDE_BLOCK, 8192);
   for (int64_t src0 = 0; src0 < n; src0 += B) {
     const int64_t Bc = (src0 + B <= n) ? B : n - src0;
-    const int rc = sp_solve_batch(plan, w, max_length, direct, src0, Bc, dist.as<float>(), changed.as<int>(), nblk, st);
+    const int rc = sp_solve_batch(plan, w, max_length, direct, src0, Bc, dist.as<float>(), changed.as<int>(), nblk, st,
+                                  (!w && !direct) ? masks.as<uint64_t>() : nullptr, W);
     if (rc != MDE_OK) return rc;
     hipLaunchKernelGGL(k_sp_topk, dim3((unsigned)Bc), dim3(MDE_BLOCK), 0, st, n, src0, dist.as<float>(), k, idx_out,
                        dist_out);
