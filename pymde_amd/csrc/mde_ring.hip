@@ -76,6 +76,9 @@ __host__ __device__ constexpr int ring_gr_off(int d) { return ring_ctrl_off(d) +
 #ifndef MDE_RING_CSLEEP
 #define MDE_RING_CSLEEP 1          // s_sleep argument of a consumer waiting for a chunk (x 64 clocks)
 #endif
+#ifndef MDE_RING_PSLEEP
+#define MDE_RING_PSLEEP 1          // s_sleep argument of a producer waiting for a slot
+#endif
 #ifndef MDE_RING_PRODPRIO
 #define MDE_RING_PRODPRIO 0        // (round 3's LDS-DMA producers ran at priority 3; the VGPR-staged ones take issue slots from the consumers: 0.208 -> 0.192 ms at 0)
 #endif
@@ -220,7 +223,12 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_seg(int64_t H, uint32_t nseg
 #ifndef MDE_RING_FORCE
 #define MDE_RING_FORCE 3
 #endif
+#ifndef MDE_RING_CARRY
 #define MDE_RING_CARRY 256  // waiting entries a stream can hold
+#endif
+#ifndef MDE_RING_ROUNDS
+#define MDE_RING_ROUNDS 6    // batches of new entries offered per iteration
+#endif
 __host__ __device__ constexpr int ring_cls_shift(int d) { return d == 2 ? 3 : (d == 4 ? 4 : 2); }
 __host__ __device__ constexpr int ring_cls_mask(int d) { return d == 4 ? 15 : 31; }
 // meta[pos] for every sorted position: local row (bits 15:0) | row bank class (23:16) | column bank
@@ -349,7 +357,7 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
     }
     // then new entries while lanes are free and the window allows (a few rounds: entries that
     // have to wait leave their lane to the next ones)
-    for (int round = 0; round < 6 && nem < 64 && next < end && nnew + 64 <= MDE_RING_CARRY; ++round) {
+    for (int round = 0; round < MDE_RING_ROUNDS && nem < 64 && next < end && nnew + 64 <= MDE_RING_CARRY; ++round) {
       const int want = 64 - nem;
       const int cand = next + lane;
       const bool in = lane < want && cand < end;
@@ -1355,12 +1363,20 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     constexpr int DEPTH = MDE_RING_DEPTH;
     ring_f4 buf[DEPTH][PIECES];
     auto fetch = [&](int k, int j) __attribute__((always_inline)) {
-      // (a chunk past the end of this producer's range: clamped, harmless, never written)
-      const size_t off0 = (size_t)min(j, NC - 1) * CBYTES + (size_t)lane * 16;
+      if (j < NC - 1) {
+        // a chunk that lies wholly inside the table: one base address, the pieces at immediate offsets
+        // (the producers share their SIMDs' issue slots with the consumers: every instruction here counts)
+        const ring_f4* src = reinterpret_cast<const ring_f4*>(Xb + (size_t)j * CBYTES + (size_t)lane * 16);
 #pragma unroll
-      for (int i = 0; i < PIECES; ++i) {
-        const size_t off = off0 + (size_t)i * 1024;
-        buf[k][i] = *reinterpret_cast<const ring_f4*>(Xb + (off < last16 ? off : last16));
+        for (int i = 0; i < PIECES; ++i) buf[k][i] = src[i * 64];
+      } else {
+        // the table's last chunk, or a prefetch past the end of the table (clamped, never written)
+        const size_t off0 = (size_t)min(j, NC - 1) * CBYTES + (size_t)lane * 16;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+          const size_t off = off0 + (size_t)i * 1024;
+          buf[k][i] = *reinterpret_cast<const ring_f4*>(Xb + (off < last16 ? off : last16));
+        }
       }
     };
     int minprog = j_lo;
@@ -1387,7 +1403,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
 #pragma unroll
             for (int w = 1; w < NCW; ++w) mn = min(mn, __builtin_amdgcn_readlane(v, w));
             minprog = mn;
-            if (j - S >= minprog) __builtin_amdgcn_s_sleep(1);
+            if (j - S >= minprog) __builtin_amdgcn_s_sleep(MDE_RING_PSLEEP);
 #if MDE_RING_ABLATE
             pr_blocked += RING_CLK() - tb0;
             if (pr_polls > MDE_RING_SPINMAX) {
@@ -1430,7 +1446,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           ring_ctrl_store_counted(L, CTRL_F + 4u * (uint32_t)p, j + NPROD);
           fetch(k, j + DEPTH * NPROD);
           slot += NPROD;
-          while (slot >= S) slot -= S;
+          if (slot >= S) slot -= S;  // (S >= 6 > NPROD: choose_sizes)
         }
       }
     }

@@ -63,7 +63,8 @@ class GradExchange(object):
         h2 = dist.all_gather_into_tensor(self._losses, buf[N:N + 1], group=self.group, async_op=True)
         h1.wait()
         h2.wait()
-        buf[N] = self._losses.sum()
+        # (one launch: the sum of the N loss shares straight into the buffer's loss slot)
+        torch.sum(self._losses, dim=0, keepdim=True, out=buf[N:N + 1])
         return buf
 
     def needs_zero(self):
@@ -154,7 +155,9 @@ class _ShardedAverageDistortion(torch.autograd.Function):
             raise NotImplementedError("sharded evaluation needs a built-in distortion function")
         Xc = X.detach().contiguous()
         n, d = Xc.shape
-        buf = torch.zeros(n * d + 1, dtype=torch.float32, device=X.device)
+        # (the all-gather exchange overwrites the other ranks' rows: nothing to zero then)
+        alloc = torch.zeros if reducer.needs_zero() else torch.empty
+        buf = alloc(n * d + 1, dtype=torch.float32, device=X.device)
         grad = buf[:n * d].view(n, d) if X.requires_grad else None
         _ad.fused_evaluate(binding, Xc, grad, buf[n * d:])
         reducer(buf)
