@@ -181,10 +181,10 @@ int mde_plan_layout(mde_plan* plan, int32_t d, void* stream);
  * iterations, padded where a stream ends or its chunk window closes, so it is larger than
  * mde_plan_half_edges). */
 int64_t mde_plan_layout_half_edges(const mde_plan* plan, int32_t layout);
-/* Parameter codebook for layout 1 at d = 2: when `in_edge` [p] holds at most 7 distinct values
- * (k-NN weights 1 / 2, -1 for repulsive pairs, ...) write to out_half
- * [mde_plan_layout_half_edges(plan, 1)] the packed half-edge words with the value index in their 3
- * low bits, followed by the 8-entry value table (entry 0 = 0.0, the weight of padding lanes;
+/* Parameter codebook for layout 1 at d = 2 and d = 3: when `in_edge` [p] holds at most 7 (d = 2) / 3
+ * (d = 3) distinct values (k-NN weights 1 / 2, -1 for repulsive pairs, ...) write to out_half
+ * [mde_plan_layout_half_edges(plan, 1)] the packed half-edge words with the value index in the low
+ * bits their row address leaves free (3 / 2), followed by the 8-entry value table (entry 0 = 0.0, the weight of padding lanes;
  * entries 1..7 the values in ascending bit order), and set *n_values_host to the number of values;
  * the fused kernel then streams 4 instead of 8 bytes per half-edge (mde_func.a0 = out_half,
  * a0_scalar = 2).  *n_values_host = 0: not applicable, nothing written -- use

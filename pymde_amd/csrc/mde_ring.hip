@@ -437,7 +437,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_caps(int nseg, const int32_t
 // Packed word of an entry (absolute LDS byte addresses, fixed when the layout is built):
 //   d = 2:  [2:0] parameter codebook index (0 when the parameters stream as fp32)
 //           [15:3] x_v address / 8 (the accumulator sits GR_OFF above it)   [30:16] x_u address / 8
-//   else:   [15:0] x_v address (a multiple of 4)                            [31:16] x_u address / 4
+//   else:   [15:2] x_v address / 4, [1:0] codebook index (d = 3 only)       [31:16] x_u address / 4
 __host__ __device__ inline uint32_t ring_pack_word(int d, uint32_t rowaddr, uint32_t coladdr) {
   return d == 2 ? (rowaddr | ((coladdr >> 3) << 16)) : (rowaddr | ((coladdr >> 2) << 16));
 }
@@ -1120,16 +1120,19 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_codebook_pack(int64_t H, const ui
 }
 
 // Try to put a per-edge parameter array into codebook form for layout 1.  On success
-// (*n_values_host in 1..7) out_half holds the H packed words with the value index in their 3 low
-// bits, followed by the 8-entry value table; pass it as mde_func.a0 with a0_scalar = 2.
-// *n_values_host = 0: not applicable (d != 2, more than 8 distinct values, NaNs) -- nothing is
+// (*n_values_host in 1..7 at d = 2, 1..3 at d = 3) out_half holds the H packed words with the value index
+// in their low bits, followed by the 8-entry value table; pass it as mde_func.a0 with a0_scalar = 2.
+// *n_values_host = 0: not applicable (another d, too many distinct values, NaNs) -- nothing is
 // written and the caller uses mde_plan_expand_layout.  SYNC.
 extern "C" int mde_plan_expand_codebook(const mde_plan* plan, const float* in_edge, float* out_half,
                                         int32_t* n_values_host, void* stream) {
   if (!plan || !in_edge || !out_half || !n_values_host) return MDE_E_INVALID;
   *n_values_host = 0;
   const mde_ring_layout& L = plan->ring;
-  if (!L.packed || L.d != 2 || L.H == 0 || plan->p == 0) return MDE_OK;
+  // (the index rides in the bits the row address leaves free: 3 at d = 2 -- up to 7 values --, 2 at d = 3 --
+  // up to 3, enough for a neighbour graph's {1, 2, -1})
+  if (!L.packed || (L.d != 2 && L.d != 3) || L.H == 0 || plan->p == 0) return MDE_OK;
+  const int max_values = L.d == 2 ? 7 : 3;
   const char* e = getenv("MDE_CODEBOOK");
   if (e && atoi(e) == 0) return MDE_OK;
   hipStream_t st = mde_stream(stream);
@@ -1156,7 +1159,7 @@ extern "C" int mde_plan_expand_codebook(const mde_plan* plan, const float* in_ed
   vals[0] = 0u;  // +0.0f: the padding lanes' weight
   for (int s = 1; s < MDE_RING_CB_VALUES; ++s)
     if (host_tb[s] != MDE_CB_EMPTY) vals[1 + nv++] = host_tb[s];
-  if (nv == 0) return MDE_OK;
+  if (nv == 0 || nv > max_values) return MDE_OK;
   // (finite values only: the kernel skips the NaN/Inf fix-up of f'/d for codebook streams)
   for (int s = 1; s <= nv; ++s) {
     float fv;
@@ -1505,13 +1508,14 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         float xr[D], xc[D], p0;
       };
       // packed word -> LDS byte addresses (ring_pack_word)
-      auto row_of = [&](uint32_t w) __attribute__((always_inline)) { return D == 2 ? (w & 0xfff8u) : (w & 0xffffu); };
+      auto row_of = [&](uint32_t w) __attribute__((always_inline)) { return D == 2 ? (w & 0xfff8u) : (w & 0xfffcu); };
       auto col_of = [&](uint32_t w) __attribute__((always_inline)) {
         return D == 2 ? ((w >> 13) & 0x3fff8u) : ((w >> 14) & 0x3fffcu);
       };
       auto issue_x = [&](uint32_t w, float p0) __attribute__((always_inline)) {
         Pre r;
-        r.p0 = CB ? *reinterpret_cast<const float*>(L + CTRL_CB + ((w & 7u) << 2)) : p0 * Fn::kParamScale;
+        // (codebook index: the bits the row address leaves free -- 3 at d = 2, 2 at d = 3)
+        r.p0 = CB ? *reinterpret_cast<const float*>(L + CTRL_CB + ((w & (D == 2 ? 7u : 3u)) << 2)) : p0 * Fn::kParamScale;
         ring_ld<D>(L + row_of(w), r.xr);
         ring_ld<D>(L + col_of(w), r.xc);
         return r;
@@ -1806,8 +1810,8 @@ template <int D, class Fn, bool LIN>
 static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
   const mde_ring_layout& L = A.plan->ring;
   const bool cb = A.a0_scalar == 2;
-  if (cb && D != 2) {
-    mde_set_error("codebook parameter streams exist for d = 2 only");
+  if (cb && D != 2 && D != 3) {
+    mde_set_error("codebook parameter streams exist for d = 2 and d = 3 only");
     return MDE_E_INVALID;
   }
   if (reinterpret_cast<uintptr_t>(A.X) & 15) {
@@ -1819,7 +1823,7 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
     if (A.a0_scalar == 1) return launch_ring<D, Fn, false>(A, fn, nblocks);
   }
   auto kern = A.grad ? k_fused_ring<D, Fn, true, false, LIN> : k_fused_ring<D, Fn, false, false, LIN>;
-  if constexpr (D == 2) {
+  if constexpr (D == 2 || D == 3) {
     if (cb) kern = A.grad ? k_fused_ring<D, Fn, true, true, LIN> : k_fused_ring<D, Fn, false, true, LIN>;
   }
   // codebook form: a0 = [H packed words | 8 values]
