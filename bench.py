@@ -577,6 +577,12 @@ def run_config4_embed(args, device):
         _, dt = timed(lambda: mde.embed(X=X0.clone(), max_iter=iters, eps=0.0))
         st = mde.solve_stats
         n_it = max(int(st.iterations), 1)
+        # the same solve continued: iterations 6 .. 5 + iters of ONE embed() (SolveStats.times), i.e. without
+        # the first steps from a random start, whose line searches need several trials each
+        _, _ = timed(lambda: mde.embed(X=X0.clone(), max_iter=iters + 5, eps=0.0))
+        st2 = mde.solve_stats
+        tt = list(st2.times)
+        late = (tt[-1] - tt[4]) / max(len(tt) - 5, 1) if len(tt) > 5 else float("nan")
         X = mde.X.detach().contiguous()
         buf = torch.zeros(n * d + 1, dtype=torch.float32, device=device)
         grad, loss = buf[:n * d].view(n, d), buf[n * d:]
@@ -588,6 +594,8 @@ def run_config4_embed(args, device):
         t_ret, _ = time_launches(lambda: c.project_onto_constraint(Y, inplace=True), 20, device)
         records[cname] = {
             "s_per_iter": dt / n_it, "ms_per_iter": 1e3 * dt / n_it, "iterations": n_it,
+            "ms_per_iter_after_5_iterations": 1e3 * late, "evaluations_of_the_longer_solve": st2.evaluations,
+            "iterations_of_the_longer_solve": int(st2.iterations),
             "evaluations": st.evaluations, "evaluations_per_iteration": (st.evaluations or 0) / n_it,
             "first_embed_5_iterations_s": t_first, "mde_constructor_s": t_mde,
             "average_distortions": [float(v) for v in st.average_distortions[:8]],
