@@ -56,7 +56,9 @@ REFERENCE_TORCH_CPU = {"value": 5.57e6, "unit": "edges/s/iter", "cores": 8,
                        "source": "tools/ref_cpu_time.py, round 2 (the survey session's container measured 9.3e6)"}
 # the files that define the measured kernel (k_fused_ring, its layout and its functors); the CSR
 # kernels of mde_distortion.hip are not what the PMC passes measure
-KERNEL_SOURCES = ["pymde_amd/csrc/mde_ring.hip", "pymde_amd/csrc/mde_functions.h"]
+KERNEL_SOURCES = ["pymde_amd/csrc/mde_ring.h", "pymde_amd/csrc/mde_ring_kernel.h", "pymde_amd/csrc/mde_ring.hip",
+                  "pymde_amd/csrc/mde_ring_k_log1p.hip", "pymde_amd/csrc/mde_ring_k_pushpull.hip",
+                  "pymde_amd/csrc/mde_functions.h"]
 
 
 def source_sha():

@@ -43,3 +43,9 @@ struct mde_plan {
 #define MDE_FLAT_U 4                    // wave iterations per tile
 #define MDE_FLAT_T (64 * MDE_FLAT_U)    // half-edge positions per tile (one wave)
 int mde_plan_flat(mde_plan* plan, hipStream_t st);  // mde_plan.hip
+
+// device-wide sort / scan shared by the plan and layout builders (defined in mde_plan.hip)
+hipError_t mde_sort_pairs_u32(void* tmp, size_t& tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                              const uint32_t* vals_in, uint32_t* vals_out, int n, int begin_bit, int end_bit,
+                              hipStream_t st);
+hipError_t mde_exclusive_sum_i32(void* tmp, size_t& tmp_bytes, const int32_t* in, int32_t* out, int n, hipStream_t st);

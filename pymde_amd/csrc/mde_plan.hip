@@ -47,6 +47,18 @@ extern "C" const int32_t* mde_plan_eid(const mde_plan* p) { return p ? p->eid : 
 // internal accessor used by the kernel translation unit
 double* mde_plan_partials(mde_plan* p) { return p->partials; }
 void mde_ring_release(mde_plan* plan);  // mde_ring.hip
+
+// The device-wide sort and scan of this unit, shared with the layout builder of mde_ring.hip: a plan is
+// created before its layout is built, so the builder finds this unit's code object loaded (its own stays a
+// few hundred KB: HIP loads a unit's code object on the first launch from it, ~1.5 ms per MB).
+hipError_t mde_sort_pairs_u32(void* tmp, size_t& tmp_bytes, const uint32_t* keys_in, uint32_t* keys_out,
+                              const uint32_t* vals_in, uint32_t* vals_out, int n, int begin_bit, int end_bit,
+                              hipStream_t st) {
+  return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys_in, keys_out, vals_in, vals_out, n, begin_bit, end_bit, st);
+}
+hipError_t mde_exclusive_sum_i32(void* tmp, size_t& tmp_bytes, const int32_t* in, int32_t* out, int n, hipStream_t st) {
+  return hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, in, out, n, st);
+}
 float mde_plan_avg_degree(const mde_plan* p) { return p->avg_degree; }
 
 extern "C" int mde_plan_destroy(mde_plan* plan) {
@@ -324,11 +336,9 @@ extern "C" int mde_plan_create(int64_t n, int64_t p, const int64_t* edges, int64
     PLAN_HIP(hipGetLastError());
     size_t tmp_bytes = 0;
     const int end_bit = bits_for((uint64_t)nloc);
-    PLAN_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)H2,
-                                                0, end_bit, st));
+    PLAN_HIP(mde_sort_pairs_u32(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)H2, 0, end_bit, st));
     PLAN_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
-    PLAN_HIP(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)H2, 0,
-                                                end_bit, st));
+    PLAN_HIP(mde_sort_pairs_u32(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)H2, 0, end_bit, st));
     hipLaunchKernelGGL(k_rowptr, dim3(mde_grid(H2 + 1, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, H2,
                        (uint32_t)nloc, keys2, plan->rowptr);
     PLAN_HIP(hipGetLastError());

@@ -1,0 +1,718 @@
+// mde_ring_kernel.h -- the LDS-ring kernel template and its launcher (included by mde_ring_k_*.hip only).
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include <type_traits>
+#include <vector>
+
+#include "mde_ring.h"
+#define COMMA ,
+
+// compile-time functors for d = 2 and 3, the dimensions embeddings are drawn in (the run-time functor is
+// ~6x the code per entry, and this kernel is bound by the instructions it issues); d = 1 and 4 take the
+// run-time functor (mde_ring_k_runtime.hip)
+#define MDE_RING23(FN, LIN)                                    \
+  do {                                                         \
+    FN fn{a};                                                  \
+    int rc;                                                    \
+    if (A.d == 2)                                              \
+      rc = launch_ring<2, FN, LIN>(A, fn, nblocks);            \
+    else                                                       \
+      rc = launch_ring<3, FN, LIN>(A, fn, nblocks);            \
+    return rc == MDE_OK ? 1 : rc;                              \
+  } while (0)
+
+// ---------------------------------------------------------------- the kernel
+typedef uint32_t ring_u4 __attribute__((ext_vector_type(4)));
+typedef float ring_f4 __attribute__((ext_vector_type(4)));
+
+template <int D>
+struct RingVec;
+template <>
+struct RingVec<1> {
+  typedef float T;
+};
+template <>
+struct RingVec<2> {
+  typedef float2 T;
+};
+template <>
+struct RingVec<4> {
+  typedef float4 T;
+};
+// D floats at an LDS byte address (aligned to the vector size for D = 1, 2, 4)
+template <int D>
+__device__ __forceinline__ void ring_ld(const char* p, float (&v)[D]) {
+  if constexpr (D == 3) {
+    const float* q = reinterpret_cast<const float*>(p);
+    v[0] = q[0];
+    v[1] = q[1];
+    v[2] = q[2];
+  } else {
+    const typename RingVec<D>::T t = *reinterpret_cast<const typename RingVec<D>::T*>(p);
+    const float* q = reinterpret_cast<const float*>(&t);
+#pragma unroll
+    for (int c = 0; c < D; ++c) v[c] = q[c];
+  }
+}
+template <int D>
+__device__ __forceinline__ void ring_st(char* p, const float (&v)[D]) {
+  if constexpr (D == 3) {
+    float* q = reinterpret_cast<float*>(p);
+    q[0] = v[0];
+    q[1] = v[1];
+    q[2] = v[2];
+  } else {
+    typename RingVec<D>::T t;
+    float* q = reinterpret_cast<float*>(&t);
+#pragma unroll
+    for (int c = 0; c < D; ++c) q[c] = v[c];
+    *reinterpret_cast<typename RingVec<D>::T*>(p) = t;
+  }
+}
+
+// control words: explicit LDS instructions on absolute addresses (a `volatile` generic pointer
+// would turn into flat loads / stores and drag vmcnt(0) waits into the stream pipeline)
+__device__ __forceinline__ void ring_ctrl_store(uint32_t addr, int v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// the same as a compiler-counted LDS instruction (its lgkmcnt bookkeeping stays exact)
+__device__ __forceinline__ void ring_ctrl_store_counted(char* lds_base, uint32_t addr, int v) {
+  typedef __attribute__((address_space(3))) volatile int* lds_vint;
+  *(lds_vint)(lds_base + addr) = v;
+}
+__device__ __forceinline__ int ring_ctrl_load(uint32_t addr) {
+  int v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+#if MDE_RING_ABLATE
+// timing probes (MDE_RING_DBG & 512): per workgroup, shader clocks summed over its waves
+//   [0] consumer loop, [1] of it inside the chunk poll, [2] poll trips, [3] producer loop,
+//   [4] of it blocked on a slot, [6] slot polls
+static __device__ unsigned long long g_ring_probe[8][1024];
+// hang diagnosis: a poll that spins longer than MDE_RING_SPINMAX trips leaves a record and gives up
+static __device__ int g_ring_diag[64][8];
+static __device__ int g_ring_ndiag;
+#ifndef MDE_RING_SPINMAX
+#define MDE_RING_SPINMAX 100000
+#endif
+#define RING_CLK() __builtin_readcyclecounter()
+#endif
+// CB: the first parameter comes from a codebook -- `packed` is the stream with value indices in its
+// 3 low bits (mde_plan_expand_codebook), a0 the 8-entry value table; no parameter stream is read.
+// LIN: f(0) = 0 whatever the lane's parameter is once that parameter is 0 (the functors
+// instantiated below): padding lanes carry parameter 0, sit on a dummy row and need no masking.
+// The loss term of an edge is added on ONE of its two entries (the one whose row is the smaller
+// vertex; the header says, per block of four iterations, none / all / test per lane), so half of the
+// blocks skip the loss arithmetic altogether; the gradient is owner-computes as before.
+template <int D, class Fn, bool HAS_GRAD, bool CB, bool LIN>
+__global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
+    int nloc, int row_lo, int n, int R, int Q, int NC, int ring_off, int S, const int32_t* __restrict__ wave_iter,
+    const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ packed, const float* __restrict__ a0,
+    const float* __restrict__ a1, int a0_scalar, int a1_scalar, const float* __restrict__ X,
+    float* __restrict__ grad, float* __restrict__ partial, double* __restrict__ loss_partials, Fn fn,
+    float fix_value, float grad_scale, float* __restrict__ loss_out, double loss_scale, int dbg_arg) {
+#if MDE_RING_ABLATE
+#ifndef MDE_RING_ABLATE_MASK
+#define MDE_RING_ABLATE_MASK (~0)  // (a narrower mask lets hipcc fold the other probes away)
+#endif
+  const int dbg = dbg_arg & (MDE_RING_ABLATE_MASK);  // timing probes: 1 consumers never wait, 8 producers never wait, 64 / 128 a role skips its loop, 512 clocks
+#else
+  constexpr int dbg = 0;
+#endif
+  constexpr int BS = MDE_RING_BS, NCW = MDE_RING_NCW, NPROD = MDE_RING_NPROD;
+  constexpr int GR_OFF = ring_gr_off(D), CTRL_PROG = MDE_RING_CTRL_PROG(D), CTRL_F = MDE_RING_CTRL_F(D), CTRL_CB = MDE_RING_CTRL_CB(D);
+  constexpr int C = ring_chunk_cols(D), CBYTES = ring_chunk_bytes(D), PIECES = CBYTES / 1024;
+  static_assert(GR_OFF + (ring_row_cap(D) + 32) * 4 * D <= 65536 + GR_OFF && GR_OFF < 65536 && CTRL_CB + 32 < 65536,
+                "region bases must fit the 16-bit offset of the LDS instructions");
+  static_assert(NPROD <= 8 && NCW <= 16, "control-word layout");
+  // statically sized: the LDS addresses unpacked from the stream are absolute
+  __shared__ __attribute__((aligned(16))) char L[MDE_RING_LDS_BYTES];
+  float* XR = reinterpret_cast<float*>(L);           // x_v of the block's rows
+  float* GR = reinterpret_cast<float*>(L + GR_OFF);  // gradient accumulators (same slots)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: keep it scalar
+  // block b = rb * Q + qg: row block rb, column group qg owns chunks [j_lo, j_hi)
+  const int rb = blockIdx.x / Q, qg = blockIdx.x % Q;
+  const int j_lo = (int)(((int64_t)qg * NC + Q - 1) / Q), j_hi = (int)(((int64_t)(qg + 1) * NC + Q - 1) / Q);
+  const int r0 = rb * R;
+  const int nr = min(R, nloc - r0);
+  const uint32_t dummy_row = (uint32_t)R * 4u * (uint32_t)D;  // the padding lanes' row slots start here
+  const float a0s = (a0_scalar && !CB) ? a0[0] : 1.0f;
+  const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
+  const bool a1_arr = a1 && !a1_scalar;
+  // ---- prologue: accumulators, x_v, control words
+  {
+    float4* z = reinterpret_cast<float4*>(L + GR_OFF);
+    const int nz = ((R + 32) * 4 * D + 15) / 16;
+    for (int i = tid; i < nz; i += BS) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* Xrow = X + (size_t)(row_lo + r0) * D;
+    if ((reinterpret_cast<uintptr_t>(Xrow) & 15) == 0) {
+      // 16-byte loads, eight in flight per thread
+      const ring_f4* X4 = reinterpret_cast<const ring_f4*>(Xrow);
+      ring_f4* XR4 = reinterpret_cast<ring_f4*>(L);
+      const int n4 = (nr * D) >> 2;
+      for (int i0 = 0; i0 < n4; i0 += 8 * BS) {
+        ring_f4 t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = X4[min(i0 + tid + k * BS, max(n4 - 1, 0))];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (i0 + tid + k * BS < n4) XR4[i0 + tid + k * BS] = t[k];
+      }
+      for (int i = (n4 << 2) + tid; i < nr * D; i += BS) XR[i] = Xrow[i];
+    } else {
+      for (int i = tid; i < nr * D; i += BS) XR[i] = Xrow[i];
+    }
+    if (tid < 32 * D) XR[R * D + tid] = 0.0f;  // the dummy rows
+    int* prog = reinterpret_cast<int*>(L + CTRL_PROG);
+    int* F = reinterpret_cast<int*>(L + CTRL_F);
+    if (tid < 16) prog[tid] = (tid < NCW) ? j_lo : MDE_RING_DONE;
+    if (tid >= 16 && tid < 16 + NPROD) F[tid - 16] = j_lo + (tid - 16);
+    if (CB && tid >= 32 && tid < 32 + MDE_RING_CB_VALUES)
+      reinterpret_cast<float*>(L + CTRL_CB)[tid - 32] = a0[tid - 32] * Fn::kParamScale;
+  }
+  __syncthreads();
+  float loss = 0.0f, loss2 = 0.0f;  // (the fused Log1p path keeps the log2 terms and the corrections apart)
+
+  if (wave >= NCW) {
+    if (MDE_RING_PRODPRIO) __builtin_amdgcn_s_setprio(MDE_RING_PRODPRIO);
+    // ---------------- producer p: chunks j_lo + p, j_lo + p + NPROD, ...  staged through VGPRs:
+    // DEPTH chunks are in flight as plain 16-byte global loads (compiler-counted), the oldest one is
+    // written into its ring slot (ds_write_b128) once every consumer is past the chunk that slot
+    // held, and published.  The chunks in flight need no ring slot (round 3's LDS-DMA parked every
+    // chunk in flight in a slot: with row blocks twice as tall the ring is too small for that).
+    const int p = wave - NCW;
+    const char* Xb = reinterpret_cast<const char*>(X);
+    const size_t nbytes = (size_t)n * D * 4;
+    const size_t last16 = nbytes - 16;  // (X is 16-byte aligned, n * D * 4 >= 16: checked by the launcher)
+    constexpr int DEPTH = MDE_RING_DEPTH;
+    ring_f4 buf[DEPTH][PIECES];
+    auto fetch = [&](int k, int j) __attribute__((always_inline)) {
+      if (j < NC - 1) {
+        // a chunk that lies wholly inside the table: one base address, the pieces at immediate offsets
+        // (the producers share their SIMDs' issue slots with the consumers: every instruction here counts)
+        const ring_f4* src = reinterpret_cast<const ring_f4*>(Xb + (size_t)j * CBYTES + (size_t)lane * 16);
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) buf[k][i] = src[i * 64];
+      } else {
+        // the table's last chunk, or a prefetch past the end of the table (clamped, never written)
+        const size_t off0 = (size_t)min(j, NC - 1) * CBYTES + (size_t)lane * 16;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+          const size_t off = off0 + (size_t)i * 1024;
+          buf[k][i] = *reinterpret_cast<const ring_f4*>(Xb + (off < last16 ? off : last16));
+        }
+      }
+    };
+    int minprog = j_lo;
+#if MDE_RING_ABLATE
+    unsigned long long pr_t0 = RING_CLK(), pr_blocked = 0, pr_polls = 0;
+#endif
+#pragma unroll
+    for (int k = 0; k < DEPTH; ++k) fetch(k, j_lo + p + k * NPROD);
+    int slot = (j_lo + p) % S;
+    for (int j0 = j_lo + p; j0 < j_hi && !(dbg & 128); j0 += DEPTH * NPROD) {
+#pragma unroll
+      for (int k = 0; k < DEPTH; ++k) {
+        const int j = j0 + k * NPROD;
+        if (j < j_hi) {
+          // slot j % S still holds chunk j - S until every consumer is past it
+          while (j - S >= minprog && !(dbg & 8)) {
+#if MDE_RING_ABLATE
+            const unsigned long long tb0 = RING_CLK();
+            ++pr_polls;
+#endif
+            // one LDS read (lane w = consumer w), then a scalar minimum over the consumers' lanes
+            const int v = ring_ctrl_load(CTRL_PROG + 4u * (uint32_t)(lane & 15));
+            int mn = __builtin_amdgcn_readlane(v, 0);
+#pragma unroll
+            for (int w = 1; w < NCW; ++w) mn = min(mn, __builtin_amdgcn_readlane(v, w));
+            minprog = mn;
+            if (j - S >= minprog) __builtin_amdgcn_s_sleep(MDE_RING_PSLEEP);
+#if MDE_RING_ABLATE
+            pr_blocked += RING_CLK() - tb0;
+            if (pr_polls > MDE_RING_SPINMAX) {
+              if (lane == 0) {
+                const int kk = atomicAdd(&g_ring_ndiag, 1);
+                if (kk < 64) {
+                  int* r = g_ring_diag[kk];
+                  r[0] = 2; r[1] = blockIdx.x; r[2] = p; r[3] = j; r[4] = minprog; r[5] = S; r[6] = j_lo; r[7] = j_hi;
+                }
+              }
+              pr_polls = 0;
+              minprog = j;  // (give up: overwrite the slot)
+            }
+#endif
+          }
+          char* dst = L + (uint32_t)__builtin_amdgcn_readfirstlane(ring_off + slot * CBYTES) + lane * 16;
+          if (j != NC - 1 || (nbytes & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) *reinterpret_cast<ring_f4*>(dst + i * 1024) = buf[k][i];
+          } else {
+            // the table's last chunk when the table is not a multiple of 16 bytes: the lane whose 16
+            // bytes straddle the end loaded the LAST 16 bytes instead -- shift them into place
+            const size_t off0 = (size_t)j * CBYTES + (size_t)lane * 16;
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+              const size_t off = off0 + (size_t)i * 1024;
+              ring_f4 v = buf[k][i];
+              if (off > last16 && off < nbytes) {
+                const int sh4 = (int)((off - last16) >> 2);  // 1..3 floats
+                const float t1 = v[1], t2 = v[2], t3 = v[3];
+                v[0] = sh4 == 1 ? t1 : (sh4 == 2 ? t2 : t3);
+                v[1] = sh4 == 1 ? t2 : (sh4 == 2 ? t3 : 0.0f);
+                v[2] = sh4 == 1 ? t3 : 0.0f;
+                v[3] = 0.0f;
+              }
+              *reinterpret_cast<ring_f4*>(dst + i * 1024) = v;
+            }
+          }
+          // (the LDS executes a wave's accesses in order: whoever sees the new F sees the chunk)
+          ring_ctrl_store_counted(L, CTRL_F + 4u * (uint32_t)p, j + NPROD);
+          fetch(k, j + DEPTH * NPROD);
+          slot += NPROD;
+          if (slot >= S) slot -= S;  // (S >= 6 > NPROD: choose_sizes)
+        }
+      }
+    }
+    ring_ctrl_store_counted(L, CTRL_F + 4u * (uint32_t)p, MDE_RING_DONE);
+#if MDE_RING_ABLATE
+    if ((dbg & 512) && lane == 0 && blockIdx.x < 1024) {
+      atomicAdd(&g_ring_probe[3][blockIdx.x], RING_CLK() - pr_t0);
+      atomicAdd(&g_ring_probe[4][blockIdx.x], pr_blocked);
+      atomicAdd(&g_ring_probe[6][blockIdx.x], pr_polls);
+    }
+#endif
+  } else {
+    // ---------------- consumer: my contiguous stream of wave iterations, 4 per block
+    if (MDE_RING_CONSPRIO) __builtin_amdgcn_s_setprio(MDE_RING_CONSPRIO);
+    const int ib = __builtin_amdgcn_readfirstlane(wave_iter[blockIdx.x * NCW + wave]);
+    const int NB = (__builtin_amdgcn_readfirstlane(wave_iter[blockIdx.x * NCW + wave + 1]) - ib) >> 2;
+    if (NB > 0 && !(dbg & 64)) {
+      const bool a0_arr = !a0_scalar && !CB;
+      const ring_u4* sp = reinterpret_cast<const ring_u4*>(packed) + (size_t)(ib >> 2) * 64 + lane;
+      const ring_f4* ap = reinterpret_cast<const ring_f4*>(a0_arr ? a0 : reinterpret_cast<const float*>(packed)) +
+                          (size_t)(ib >> 2) * 64 + lane;
+      const int lastb = NB - 1;
+      // PFB blocks (4 iterations each) of packed words, parameters and headers in flight.  All
+      // stream loads are issued from ONE place (the refill after a block is consumed),
+      // unconditional and clamped, never predicated: on every path the same loads are in flight
+      // when a block is consumed, so the compiler's vmcnt counts are exact and nothing waits for a
+      // load just issued.
+      // The 16 header words of a block come with ONE vector load: lane l holds word l & 15, i.e. every
+      // row of 16 lanes holds the whole header, and a word reaches all lanes with a DPP row broadcast
+      // (one VALU instruction, no round trip through the scalar unit).  Round 3 fetched the headers
+      // with s_load_dwordx16: scalar loads share lgkmcnt with the LDS instructions and return out of
+      // order, so the first LDS wait after a refill drained the header load just issued.
+      constexpr int PFB = MDE_RING_PFB;
+      ring_u4 pq[PFB] = {};
+      uint32_t hv[PFB] = {};
+      ring_f4 wq[PFB] = {};
+      const uint32_t* hvp = hdr + (size_t)ib * MDE_RING_HW + (lane & 15);
+      auto load_block = [&](int u, int b) __attribute__((always_inline)) {
+        const int bc = min(b, lastb);
+#if defined(MDE_RING_STREAM_L2)  // (design probe, wrong results: the packed words of 8 blocks over and over -- an L2-resident stream)
+        pq[u] = sp[(size_t)(bc & 7) * 64];
+#elif defined(MDE_RING_STREAM_NT)
+        pq[u] = __builtin_nontemporal_load(&sp[(size_t)bc * 64]);
+#else
+        pq[u] = sp[(size_t)bc * 64];
+#endif
+        hv[u] = hvp[(size_t)bc * 16];
+        if (!CB) wq[u] = ap[(size_t)bc * 64];
+      };
+#if MDE_RING_ABLATE
+      unsigned long long cs_t0 = RING_CLK(), cs_poll = 0, cs_trips = 0;
+#endif
+
+      // the LDS operands of an entry: x_v, x_u, the parameter
+      struct Pre {
+        float xr[D], xc[D], p0;
+      };
+      // packed word -> LDS byte addresses (ring_pack_word)
+      auto row_of = [&](uint32_t w) __attribute__((always_inline)) { return D == 2 ? (w & 0xfff8u) : (w & 0xfffcu); };
+      auto col_of = [&](uint32_t w) __attribute__((always_inline)) {
+        return D == 2 ? ((w >> 13) & 0x3fff8u) : ((w >> 14) & 0x3fffcu);
+      };
+      auto issue_x = [&](uint32_t w, float p0) __attribute__((always_inline)) {
+        Pre r;
+        // (codebook index: the bits the row address leaves free -- 3 at d = 2, 2 at d = 3)
+        r.p0 = CB ? *reinterpret_cast<const float*>(L + CTRL_CB + ((w & (D == 2 ? 7u : 3u)) << 2)) : p0 * Fn::kParamScale;
+        ring_ld<D>(L + row_of(w), r.xr);
+        ring_ld<D>(L + col_of(w), r.xc);
+        return r;
+      };
+      // this entry adds the loss term iff its row is the smaller vertex (blocks around the diagonal)
+      auto counts_here = [&](uint32_t w, uint32_t hm) __attribute__((always_inline)) {
+        const uint32_t off = col_of(w) - (uint32_t)ring_off;
+        const uint32_t slot = off / (uint32_t)CBYTES, cidx = (off - slot * (uint32_t)CBYTES) / (4u * (uint32_t)D);
+        const uint32_t ms = hm % (uint32_t)S;
+        const uint32_t j = hm + (slot >= ms ? slot - ms : slot + (uint32_t)S - ms);
+        const uint32_t u = j * (uint32_t)C + cidx;
+        const uint32_t vv = (uint32_t)(row_lo + r0) + row_of(w) / (4u * (uint32_t)D);
+        return vv < u;
+      };
+      // evaluate the entry and add its gradient term to the row's accumulator (read earlier).  LC is
+      // the loss class of the BLOCK (compile time: no branch per iteration): 0 no entry adds its loss
+      // term here, 1 every entry does, 2 test per lane.
+      auto finish = [&](auto lc_tag, uint32_t w, const Pre& x, float (&acc)[D], float p1, uint32_t hm)
+          __attribute__((always_inline)) {
+        constexpr int LC = decltype(lc_tag)::value;
+        const uint32_t rowaddr = row_of(w);
+        float v[D], ss = 0.0f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+          v[c] = x.xr[c] - x.xc[c];
+          ss = fmaf(v[c], v[c], ss);
+        }
+        float gd;
+        if constexpr (Fn::kRingFused) {
+          // Log1p, exponent 1.5 (mde_functions.h, MDE_F_LOG1P): x.p0 = 1.5 w.  Two square roots and
+          // one reciprocal; r stays finite at d = 0, where v = 0 anyway.
+          const float d = mde_sqrt(ss), sd = mde_sqrt(d);
+          const float t = fmaf(d, sd, 1.0f);
+          const float r = mde_rcp(fmaf(sd, t, 1.0e-30f));
+          gd = x.p0 * r;
+          if constexpr (LC != 0) {
+            // w log1p(u) = w ln2 log2(t) + (w / t) (u - (t - 1)), 1 / t = sqrt(d) r: the two sums are
+            // kept apart and combined (with 1 / 1.5) once per wave
+            const float c = d * sd - (t - 1.0f);
+            float wl = x.p0, gc = gd;
+            if (!LIN) {
+              // (one scalar parameter for every lane: the padding lanes carry it too)
+              const bool real = rowaddr < dummy_row;
+              wl = real ? wl : 0.0f;
+              gc = real ? gc : 0.0f;
+            }
+            if constexpr (LC == 2) {
+              const bool here = counts_here(w, hm);
+              wl = here ? wl : 0.0f;
+              gc = here ? gc : 0.0f;
+            }
+            loss = fmaf(wl, mde_log2(t), loss);
+            loss2 = fmaf(gc, sd * c, loss2);
+          }
+        } else {
+          float f;  // (dead code when LC == 0)
+          fn.eval(ss, x.p0, p1, f, gd);
+          if constexpr (LC != 0) {
+            if (!LIN) f = (rowaddr < dummy_row) ? f : 0.0f;
+            if constexpr (LC == 2) f = counts_here(w, hm) ? f : 0.0f;
+            loss += f;
+          }
+        }
+        if (!HAS_GRAD) return;
+        // (codebook values are finite -- mde_plan_expand_codebook refuses others)
+        const float g = (Fn::kFiniteG && CB) ? gd : mde_fix_g_to(gd, fix_value);
+#pragma unroll
+        for (int c = 0; c < D; ++c) acc[c] = fmaf(v[c], g, acc[c]);
+        ring_st<D>(L + GR_OFF + rowaddr, acc);
+      };
+      // Hand-shake, once per PAIR of iterations (q = 0 or 2 of block u; header words at lanes 4 q ..).
+      // A wave needs its chunks resident only at the moment it ISSUES the LDS reads of a pair (the LDS
+      // executes in order: whatever lands later lands behind them): wait_pair() waits until the newest
+      // chunk of the pair has landed, then the reads go out, then release_to() publishes the oldest
+      // chunk of the NEXT pair -- between two hand-shakes the wave holds nothing, so the slots it is
+      // done with are free a whole pair earlier than with "publish, wait, read".  The layout anchors
+      // the chunk window of a pair at its first iteration (k_ring_schedule), so one test covers both.
+      const uint32_t prog_addr = CTRL_PROG + 4u * (uint32_t)wave;
+      int ready = j_lo;  // chunks below this have landed
+      auto wait_pair = [&](int u, int q) __attribute__((always_inline)) {
+        const int need = __builtin_amdgcn_readlane((int)hv[u], 4 * q + 1);
+        if (__builtin_expect(need >= ready && !(dbg & 1), 0)) {
+#if MDE_RING_ABLATE
+          const unsigned long long tp0 = RING_CLK();
+#endif
+          for (;;) {
+            const int fl = ring_ctrl_load(CTRL_F + 4u * (uint32_t)min(lane, NPROD - 1));
+            ready = __builtin_amdgcn_readlane(fl, 0);
+#pragma unroll
+            for (int pp = 1; pp < NPROD; ++pp) ready = min(ready, __builtin_amdgcn_readlane(fl, pp));
+#if MDE_RING_ABLATE
+            ++cs_trips;
+            if (cs_trips > MDE_RING_SPINMAX) {
+              if (lane == 0) {
+                const int k = atomicAdd(&g_ring_ndiag, 1);
+                if (k < 64) {
+                  int* r = g_ring_diag[k];
+                  r[0] = 1; r[1] = blockIdx.x; r[2] = wave; r[3] = need; r[4] = ready; r[5] = 0; r[6] = u * 4 + q; r[7] = NB;
+                }
+              }
+              cs_trips = 0;
+              ready = need + 1;
+              break;
+            }
+#endif
+            if (need < ready) break;
+            __builtin_amdgcn_s_sleep(MDE_RING_CSLEEP);
+          }
+#if MDE_RING_ABLATE
+          cs_poll += RING_CLK() - tp0;
+#endif
+          asm volatile("" ::: "memory");
+        }
+      };
+      // (m never decreases along a stream; past its end the headers are copies of the last block and
+      // the value published is merely too old)
+      auto release_to = [&](int u, int q) __attribute__((always_inline)) {
+        ring_ctrl_store_counted(L, prog_addr, __builtin_amdgcn_readlane((int)hv[u], 4 * q));
+      };
+
+      // Software pipeline over PAIRS of iterations.  In the region of pair p the wave (after the
+      // hand-shake for the chunks of pair p + 1) issues the LDS reads of the operands of pair p + 1
+      // (x_v, x_u, parameter), then evaluates the two iterations of pair p (operands read one pair
+      // ago): accumulator write of k and, right behind it, the accumulator read of k + 1 (the LDS
+      // executes a wave's accesses in order, so a row shared by consecutive iterations sees the
+      // update).  Every LDS access of the loop is a compiler-counted instruction (the control-word
+      // store included: round 3 issued it from inline asm, which put hipcc's lgkmcnt counts off by
+      // one), and the region of a pair is ONE basic block: hipcc's scheduler interleaves the two
+      // evaluations and places the waits.
+      // What bounds this loop is instruction issue, not LDS or HBM (round 4, tools/r4_run.sh:
+      // the consumers alone take 0.15 ms with a test + branch per iteration and 0.10 ms as
+      // straight-line code; LDS conflicts and the accumulator chain cost nothing): hence one
+      // hand-shake branch per pair, one loss-class branch per block of four (three copies of the
+      // block body), and no header word through an SGPR.
+      Pre xa, xb;  // operands of the pair being evaluated
+      float acc[D];
+      auto block_body = [&](auto lc_tag, int u, int b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = 2 * h;
+          // the pair after this one (block and slot); past the end of the stream it is a copy of
+          // the last block: resident chunks, harmless reads, nothing new published
+          const int un = h == 0 ? u : (u + 1) % PFB, qn = (q + 2) & 3;
+          wait_pair(un, qn);
+          const Pre xna = issue_x(pq[un][qn], (a0_scalar || CB) ? a0s : wq[un][qn]);
+          const Pre xnb = issue_x(pq[un][qn + 1], (a0_scalar || CB) ? a0s : wq[un][qn + 1]);
+          release_to((u + 1) % PFB, q);  // (the pair after that one: next block, same slot)
+          const float p1a = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q] : a1s;
+          const float p1b = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q + 1] : a1s;
+          const bool lc2 = decltype(lc_tag)::value == 2;
+          const uint32_t hma = lc2 ? (uint32_t)__builtin_amdgcn_readlane((int)hv[u], 4 * q) : 0u;
+          const uint32_t hmb = lc2 ? (uint32_t)__builtin_amdgcn_readlane((int)hv[u], 4 * q + 4) : 0u;
+          finish(lc_tag, pq[u][q], xa, acc, p1a, hma);
+          if (HAS_GRAD) ring_ld<D>(L + GR_OFF + row_of(pq[u][q + 1]), acc);
+          finish(lc_tag, pq[u][q + 1], xb, acc, p1b, hmb);
+          if (HAS_GRAD) ring_ld<D>(L + GR_OFF + row_of(pq[un][qn]), acc);
+          xa = xna;
+          xb = xnb;
+        }
+      };
+#pragma unroll
+      for (int u = 0; u < PFB; ++u) load_block(u, u);
+      release_to(0, 0);  // (a sparse stream may begin chunks after j_lo: the producers must know before this wave waits)
+      wait_pair(0, 0);
+      xa = issue_x(pq[0][0], (a0_scalar || CB) ? a0s : wq[0][0]);
+      xb = issue_x(pq[0][1], (a0_scalar || CB) ? a0s : wq[0][1]);
+      release_to(0, 2);
+      if (HAS_GRAD) ring_ld<D>(L + GR_OFF + row_of(pq[0][0]), acc);
+      for (int base = 0; base < NB; base += PFB) {
+#pragma unroll
+        for (int u = 0; u < PFB; ++u) {
+          const int b = base + u;
+          if (b < NB) {
+            // loss class of the block: header word 3 of its first iteration
+            const int bcls = __builtin_amdgcn_readlane((int)hv[u], 3) & 3;
+            if (bcls == 0)
+              block_body(std::integral_constant<int, 0>(), u, b);
+            else if (bcls == 1)
+              block_body(std::integral_constant<int, 1>(), u, b);
+            else
+              block_body(std::integral_constant<int, 2>(), u, b);
+          }
+          load_block(u, b + PFB);
+        }
+      }
+#if MDE_RING_ABLATE
+      if ((dbg & 512) && lane == 0 && blockIdx.x < 1024) {
+        atomicAdd(&g_ring_probe[0][blockIdx.x], RING_CLK() - cs_t0);
+        atomicAdd(&g_ring_probe[1][blockIdx.x], cs_poll);
+        atomicAdd(&g_ring_probe[2][blockIdx.x], cs_trips);
+      }
+#endif
+    }
+    if constexpr (Fn::kRingFused) loss = fmaf(loss, 0.6931471805599453f, loss2) * (1.0f / Fn::kParamScale);
+    ring_ctrl_store_counted(L, CTRL_PROG + 4u * (uint32_t)wave, MDE_RING_DONE);
+    // (the two roles are laid out one after the other: leave no counted load pending here, or
+    // hipcc carries the stream prefetches into the producer code as waits -- see above)
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+  }
+  __syncthreads();
+  if (HAS_GRAD) {
+    // Q == 1: the rows are final.  Q > 1: unscaled per-group partials, summed by k_ring_combine
+    float* grow = (Q == 1) ? grad + (size_t)(row_lo + r0) * D : partial + ((size_t)qg * nloc + r0) * D;
+    const float sc = (Q == 1) ? grad_scale : 1.0f;
+    for (int i = tid; i < nr * D; i += BS) grow[i] = GR[i] * sc;
+  }
+  // block-wide loss partial (the x_v region is free now), then the loss itself: the last
+  // workgroup to arrive adds the partials of all of them in a fixed order (no second launch).  The
+  // partials travel as relaxed device-scope atomic stores / loads (mde_common.h: a device-scope fence
+  // here writes the whole L2 back -- it cost 5 us of the 230 at config 4 and 8 of the 64 us of an
+  // 8-way shard's evaluation).
+  double* red = reinterpret_cast<double*>(L);
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(loss_partials + MDE_MAX_PARTIALS);
+  const double v = mde_wave_sum((double)loss);
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int i = 0; i < NCW; ++i) s += red[i];
+    mde_st_partial(loss_partials + blockIdx.x, s);
+  }
+  // (mde_last_block's logic with the flag inside L: this kernel's LDS is full)
+  int* last_flag = reinterpret_cast<int*>(L + 256);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the partial store has completed
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned int k = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *last_flag = (k == gridDim.x - 1u) ? 1 : 0;
+    if (*last_flag) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!*last_flag) return;
+  double t = 0.0;
+  for (int i = tid; i < (int)gridDim.x; i += BS) t += mde_ld_partial(loss_partials + i);
+  t = mde_wave_sum(t);
+  __syncthreads();
+  if (lane == 0) red[wave] = t;
+  __syncthreads();
+  if (tid == 0) {
+    double s = 0.0;
+    for (int i = 0; i < BS / 64; ++i) s += red[i];
+    *loss_out = (float)(s * loss_scale);
+  }
+}
+
+// grad[row] = scale * sum_q partial[q][row]  (q ascending).  V = float4 / float: one element per
+// thread, the first eight group loads in flight together
+template <class V>
+__global__ __launch_bounds__(MDE_BLOCK) void k_ring_combine(int64_t m, int Q, const V* __restrict__ partial,
+                                                            float scale, V* __restrict__ out) {
+  constexpr int W = sizeof(V) / sizeof(float);
+  const int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x;
+  if (i >= m) return;
+  V a[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+    if (q < Q) a[q] = partial[(size_t)q * m + i];
+  float s[W];
+#pragma unroll
+  for (int k = 0; k < W; ++k) s[k] = reinterpret_cast<const float*>(&a[0])[k];
+#pragma unroll
+  for (int q = 1; q < 8; ++q)
+    if (q < Q) {
+#pragma unroll
+      for (int k = 0; k < W; ++k) s[k] += reinterpret_cast<const float*>(&a[q])[k];
+    }
+  for (int q = 8; q < Q; ++q) {
+    const V t = partial[(size_t)q * m + i];
+#pragma unroll
+    for (int k = 0; k < W; ++k) s[k] += reinterpret_cast<const float*>(&t)[k];
+  }
+  V r;
+#pragma unroll
+  for (int k = 0; k < W; ++k) reinterpret_cast<float*>(&r)[k] = s[k] * scale;
+  out[i] = r;
+}
+
+
+template <int D, class Fn, bool LIN>
+static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
+  const mde_ring_layout& L = A.plan->ring;
+  const bool cb = A.a0_scalar == 2;
+  if (cb && D != 2 && D != 3) {
+    mde_set_error("codebook parameter streams exist for d = 2 and d = 3 only");
+    return MDE_E_INVALID;
+  }
+  if (reinterpret_cast<uintptr_t>(A.X) & 15) {
+    mde_set_error("the LDS-ring kernel needs a 16-byte aligned embedding matrix");
+    return MDE_E_INVALID;
+  }
+  if constexpr (LIN) {
+    // one scalar parameter for every edge: padding lanes would carry it too -- mask them instead
+    if (A.a0_scalar == 1) return launch_ring<D, Fn, false>(A, fn, nblocks);
+  }
+  auto kern = A.grad ? k_fused_ring<D, Fn, true, false, LIN> : k_fused_ring<D, Fn, false, false, LIN>;
+  if constexpr (D == 2 || D == 3) {
+    if (cb) kern = A.grad ? k_fused_ring<D, Fn, true, true, LIN> : k_fused_ring<D, Fn, false, true, LIN>;
+  }
+  // codebook form: a0 = [H packed words | 8 values]
+  const uint32_t* stream = cb ? reinterpret_cast<const uint32_t*>(A.a0) : L.packed;
+  const float* a0 = cb ? A.a0 + L.H : A.a0;
+  const int Q = L.col_groups;
+  *nblocks = L.n_row_blocks * Q;
+  // the accumulators hold sum f'/d (x_v - x_u); 1/p is applied with the output scale (the
+  // NaN/Inf -> 1 rule of the reference then reads "-> p")
+  const float out_scale = A.grad_scale * A.inv_p;
+  const float fix_value = A.inv_p > 0.0f ? 1.0f / A.inv_p : 1.0f;
+#if MDE_RING_ABLATE
+  const int dbg = getenv("MDE_RING_DBG") ? atoi(getenv("MDE_RING_DBG")) : 0;
+#else
+  const int dbg = 0;
+#endif
+  // (every edge adds its loss term once here, not once per endpoint: twice the caller's scale)
+  hipLaunchKernelGGL(kern, dim3(L.n_row_blocks * Q), dim3(MDE_RING_BS), 0, A.st,
+                     (int)(A.plan->row_hi - A.plan->row_lo), (int)A.plan->row_lo, (int)A.plan->n,
+                     L.rows_per_block, Q, L.n_chunks, L.ring_off, L.slots, L.wave_iter, L.hdr, stream, a0, A.a1, A.a0_scalar,
+                     A.a1_scalar, A.X, A.grad, L.partial, A.plan->partials, fn, fix_value, out_scale,
+                     A.loss_out, 2.0 * A.loss_scale, dbg);
+  MDE_LAUNCH_CHECK();
+#if MDE_RING_ABLATE
+  {
+    static int dl = 0;
+    if (++dl == 3) {
+      int nd = 0;
+      int hd[64][8];
+      (void)hipStreamSynchronize(A.st);
+      (void)hipMemcpyFromSymbol(&nd, HIP_SYMBOL(g_ring_ndiag), sizeof(int));
+      (void)hipMemcpyFromSymbol(hd, HIP_SYMBOL(g_ring_diag), sizeof(hd));
+      fprintf(stderr, "[mde ring diag] %d give-ups in the first launches\n", nd);
+      for (int k = 0; k < nd && k < 24; ++k)
+        fprintf(stderr, hd[k][0] == 1 ? "[mde ring diag] consumer wg %d wave %d: need %d ready %d m %d slot %d NB %d\n"
+                                      : "[mde ring diag] producer wg %d p %d: j %d minprog %d infl %d oldest %d j_hi %d\n",
+                hd[k][1], hd[k][2], hd[k][3], hd[k][4], hd[k][5], hd[k][6], hd[k][7]);
+    }
+  }
+  if (dbg & 512) {
+    static int launches = 0;
+    if (++launches == 8) {
+      std::vector<unsigned long long> h(8 * 1024);
+      (void)hipStreamSynchronize(A.st);
+      (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_ring_probe), sizeof(unsigned long long) * 8 * 1024);
+      const int nb = std::min(1024, L.n_row_blocks * Q);
+      double s[8] = {0};
+      for (int k = 0; k < 8; ++k)
+        for (int i = 0; i < nb; ++i) s[k] += (double)h[k * 1024 + i];
+      const double L8 = 8.0 * nb;  // launches x workgroups
+      fprintf(stderr, "[mde ring probe] per consumer wave and launch: loop %.0f clk, in chunk polls %.0f clk (%.1f%%), %.0f poll trips | "
+              "per producer wave: loop %.0f clk, blocked on a slot %.0f (%.1f%%), waiting for pieces %.0f (%.1f%%), %.0f slot polls\n",
+              s[0] / L8 / MDE_RING_NCW, s[1] / L8 / MDE_RING_NCW, 100.0 * s[1] / s[0], s[2] / L8 / MDE_RING_NCW,
+              s[3] / L8 / MDE_RING_NPROD, s[4] / L8 / MDE_RING_NPROD, 100.0 * s[4] / s[3], s[5] / L8 / MDE_RING_NPROD,
+              100.0 * s[5] / s[3], s[6] / L8 / MDE_RING_NPROD);
+    }
+  }
+#endif
+  // Q column groups per row block (sharded plans): the per-group partials are added by a second, 6 us
+  // launch.  Folding that into the ring kernel (the last group of a row block to arrive adds the Q
+  // partials) was built twice -- round 2 with a fence, round 3 with write-through stores and relaxed
+  // loads -- and measured slower both times (8-way shard: 77 vs 57 us per evaluation): 8 x 32 KB of
+  // partials per row block are an order of magnitude more than an in-launch reducer reads for free.
+  if (Q > 1 && A.grad) {
+    const int64_t nlocD = (A.plan->row_hi - A.plan->row_lo) * (int64_t)D;
+    float* out = A.grad + (size_t)A.plan->row_lo * D;
+    if (nlocD % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+      const int64_t m = nlocD / 4;
+      hipLaunchKernelGGL(k_ring_combine<float4>, dim3((unsigned)((m + MDE_BLOCK - 1) / MDE_BLOCK)), dim3(MDE_BLOCK),
+                         0, A.st, m, Q, reinterpret_cast<const float4*>(L.partial), out_scale,
+                         reinterpret_cast<float4*>(out));
+    } else {
+      hipLaunchKernelGGL(k_ring_combine<float>, dim3((unsigned)((nlocD + MDE_BLOCK - 1) / MDE_BLOCK)),
+                         dim3(MDE_BLOCK), 0, A.st, nlocD, Q, L.partial, out_scale, out);
+    }
+    MDE_LAUNCH_CHECK();
+  }
+  return MDE_OK;
+}

@@ -1,9 +1,15 @@
 #!/bin/bash
-# build_variant.sh NAME "extra flags": a copy of libmde_hip.so with other compile-time knobs of mde_ring.hip
+# build_variant.sh NAME "extra flags": a copy of libmde_hip.so with other compile-time knobs of the LDS-ring
+# kernel (layout builder, dispatcher and the Log1p / PushAndPull units are recompiled with the flags)
 # (design experiments on the GPU box: LD_LIBRARY_PATH=tools/variants/NAME ./tools/kbench ...)
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/variants/$1
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -Wno-unused-result -ffp-contract=fast $2 -c pymde_amd/csrc/mde_ring.hip -o tools/variants/$1/mde_ring.o
-objs=$(ls pymde_amd/csrc/build/*.o | grep -v mde_ring.o)
-hipcc --offload-arch=gfx950 -shared -fPIC -o tools/variants/$1/libmde_hip.so $objs tools/variants/$1/mde_ring.o
+units="mde_ring mde_ring_k_log1p mde_ring_k_pushpull"
+for u in $units; do
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -Wno-unused-result -ffp-contract=fast $2 -c pymde_amd/csrc/$u.hip -o tools/variants/$1/$u.o &
+done
+wait
+objs=$(ls pymde_amd/csrc/build/*.o | grep -v -e "mde_ring.o" -e "mde_ring_k_log1p.o" -e "mde_ring_k_pushpull.o")
+vobjs=$(for u in $units; do echo tools/variants/$1/$u.o; done)
+hipcc --offload-arch=gfx950 -shared -fPIC -o tools/variants/$1/libmde_hip.so $objs $vobjs
