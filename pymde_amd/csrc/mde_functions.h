@@ -366,6 +366,30 @@ struct FnPushPull {
   static constexpr float kParamScale = 1.0f;
   MdeFuncArgs A;
   MDE_DEV void eval(float ss, float a0, float a1, float& f, float& gd) const {
+#ifndef MDE_PUSHPULL_DIVERGENT
+    if constexpr (KA == MDE_F_LOG1P && EA == 2 && KR == MDE_F_LOG && ER == 1) {
+      // preserve_neighbors' pair (Log1p with exponent 1.5 pulls, Log with exponent 1 pushes) in ONE
+      // instruction stream: a wave of a random graph holds both signs, so the divergent if / else below
+      // issues both branches -- 6 quarter-rate instructions per entry for the gradient, 10 with the loss
+      // term.  Here the branches share sqrt(ss) and meet in ONE reciprocal and ONE logarithm whose
+      // ARGUMENTS are selected per lane: 4 and 5.  Attractive lanes compute exactly what
+      // mde_eval<LOG1P, 2> does; repulsive lanes what mde_eval<LOG, 1> does except that the 1 / (1 - em)
+      // of its log1p correction (|correction| <= 3e-8, d > 1 only) is the series 1 + em.
+      const bool att = a0 >= 0.0f;  // [ref: penalties.py:390 -- zero weight is attractive]
+      const float d = mde_sqrt(ss);
+      const float sd = mde_sqrt(d);
+      const float pe = d * sd;
+      const float t = 1.0f + pe;
+      float em;
+      const float A = mde_one_minus_expneg(d, em);  // -expm1(-d)
+      const float r = mde_rcp(att ? fmaf(sd, t, 1.0e-30f) : A * ss);
+      gd = (att ? 1.5f * a0 : a0 * d * em) * r;
+      const float t2 = 1.0f - em;
+      const float corr = att ? (pe - (t - 1.0f)) * sd * r : (d > 1.0f ? (-em - (t2 - 1.0f)) * (1.0f + em) : 0.0f);
+      f = a0 * (mde_log(att ? t : A) + corr);
+      return;
+    }
+#endif
 #ifndef MDE_PUSHPULL_SELECT
     if (a0 >= 0.0f)
       mde_eval<KA, EA>(ss, a0, a1, A.S, f, gd);

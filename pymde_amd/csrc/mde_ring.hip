@@ -953,8 +953,12 @@ extern "C" int64_t mde_plan_layout_half_edges(const mde_plan* plan, int32_t layo
 // weight 0 of padding lanes, entries 1..7 the (at most 7) distinct values of the array.
 #define MDE_CB_EMPTY 0xFFFFFFFFu  // (a NaN pattern: NaN parameters simply disable the codebook)
 
-// distinct bit patterns of in[0..p): inserted into table[0..8) with compare-and-swap; *overflow is
-// set when a 9th value (or the EMPTY pattern) shows up
+// distinct bit patterns of in[0..p): inserted into table[1..8) with compare-and-swap; *overflow is
+// set when an 8th value (or the EMPTY pattern) shows up.  A value goes through the workgroup's own
+// table first (LDS compare-and-swap) and only the thread that put it THERE carries it to the global
+// one: <= 8 global atomics per workgroup.  (Round 4 until then: every thread met an empty table at
+// its first element and went to the global one -- half a million compare-and-swaps on one address,
+// 9.4 ms for a scan that reads 200 MB.)
 __global__ __launch_bounds__(MDE_BLOCK) void k_codebook_scan(int64_t p, const float* __restrict__ in,
                                                              unsigned int* __restrict__ table,
                                                              int* __restrict__ overflow) {
@@ -962,32 +966,42 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_codebook_scan(int64_t p, const fl
   if (threadIdx.x < MDE_RING_CB_VALUES) stb[threadIdx.x] = MDE_CB_EMPTY;
   __syncthreads();
   unsigned int last0 = MDE_CB_EMPTY, last1 = MDE_CB_EMPTY;
-  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < p;
-       i += (int64_t)gridDim.x * MDE_BLOCK) {
-    const unsigned int v = __float_as_uint(in[i]);
-    if (v == last0 || v == last1) continue;
-    last1 = last0;
-    last0 = v;
-    bool known = false;
+  const int64_t stride = (int64_t)gridDim.x * MDE_BLOCK;
+  constexpr int U = 4;  // independent loads in flight per thread
+  for (int64_t i0 = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i0 < p; i0 += U * stride) {
+    unsigned int vv[U];
 #pragma unroll
-    for (int s = 0; s < MDE_RING_CB_VALUES; ++s) known |= (stb[s] == v);
-    if (known) continue;
-    if (v == MDE_CB_EMPTY || *reinterpret_cast<volatile int*>(overflow)) {
-      *overflow = 1;
-      return;
+    for (int k = 0; k < U; ++k) {
+      const int64_t i = i0 + k * stride;
+      vv[k] = i < p ? __float_as_uint(in[i]) : last0;
     }
-    bool placed = false;
-    for (int s = 1; s < MDE_RING_CB_VALUES && !placed; ++s) {
-      const unsigned int old = atomicCAS(&table[s], MDE_CB_EMPTY, v);
-      placed = (old == MDE_CB_EMPTY || old == v);
-    }
-    if (!placed) {
-      *overflow = 1;
-      return;
-    }
-    for (int s = 0; s < MDE_RING_CB_VALUES; ++s) {  // remember it block-wide
-      const unsigned int old = atomicCAS(&stb[s], MDE_CB_EMPTY, v);
-      if (old == MDE_CB_EMPTY || old == v) break;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const unsigned int v = vv[k];
+      if (v == last0 || v == last1) continue;
+      last1 = last0;
+      last0 = v;
+      if (v == MDE_CB_EMPTY) {
+        *overflow = 1;
+        return;
+      }
+      bool placed = false, mine = false;
+      for (int s = 0; s < MDE_RING_CB_VALUES && !placed; ++s) {
+        const unsigned int old = atomicCAS(&stb[s], MDE_CB_EMPTY, v);
+        mine = (old == MDE_CB_EMPTY);
+        placed = mine || old == v;
+      }
+      if (placed && !mine) continue;  // some thread of this workgroup has carried it already
+      placed = false;
+      for (int s = 1; s < MDE_RING_CB_VALUES && !placed; ++s) {
+        unsigned int cur = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == MDE_CB_EMPTY) cur = atomicCAS(&table[s], MDE_CB_EMPTY, v);
+        placed = (cur == MDE_CB_EMPTY || cur == v);
+      }
+      if (!placed) {
+        *overflow = 1;
+        return;
+      }
     }
   }
 }
