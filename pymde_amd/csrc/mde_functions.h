@@ -381,30 +381,21 @@ struct FnPushPull {
       const float pe = d * sd;
       const float t = 1.0f + pe;
       float em;
-      const float A = mde_one_minus_expneg(d, em);  // -expm1(-d)
-      const float r = mde_rcp(att ? fmaf(sd, t, 1.0e-30f) : A * ss);
+      const float om = mde_one_minus_expneg(d, em);  // -expm1(-d)
+      const float r = mde_rcp(att ? fmaf(sd, t, 1.0e-30f) : om * ss);
       gd = (att ? 1.5f * a0 : a0 * d * em) * r;
       const float t2 = 1.0f - em;
       const float corr = att ? (pe - (t - 1.0f)) * sd * r : (d > 1.0f ? (-em - (t2 - 1.0f)) * (1.0f + em) : 0.0f);
-      f = a0 * (mde_log(att ? t : A) + corr);
+      f = a0 * (mde_log(att ? t : om) + corr);
       return;
     }
 #endif
-#ifndef MDE_PUSHPULL_SELECT
-    if (a0 >= 0.0f)
+    // other pairs: a divergent if / else (both branches + a select measured SLOWER on the ring kernel:
+    // config 4b 0.295 vs 0.267 ms, round 4)
+    if (a0 >= 0.0f)  // [ref: penalties.py:390 -- zero weight is attractive]
       mde_eval<KA, EA>(ss, a0, a1, A.S, f, gd);
     else
       mde_eval<KR, ER>(ss, a0, a1, A.N, f, gd);
-#else
-    // (round 4: both branches + a select measured SLOWER on the ring kernel than the divergent
-    // if / else -- config 4b 0.295 vs 0.267 ms -- kept for reference)
-    float fa, ga, fr, gr;
-    mde_eval<KA, EA>(ss, a0, a1, A.S, fa, ga);
-    mde_eval<KR, ER>(ss, a0, a1, A.N, fr, gr);
-    const bool att = a0 >= 0.0f;  // [ref: penalties.py:390 -- zero weight is attractive]
-    f = att ? fa : fr;
-    gd = att ? ga : gr;
-#endif
   }
 };
 
