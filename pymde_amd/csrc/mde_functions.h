@@ -361,13 +361,21 @@ struct FnSingle {
 // PushAndPull with both branches fixed at compile time
 template <int KA, int EA, int KR, int ER>
 struct FnPushPull {
-  static constexpr bool kFiniteG = false;
+  static constexpr bool kMerged =
+#ifndef MDE_PUSHPULL_DIVERGENT
+      (KA == MDE_F_LOG1P && EA == 2 && KR == MDE_F_LOG && ER == 1);
+#else
+      false;
+#endif
+  // (the merged pair keeps f'/d finite at d = 0 the way Log1p does: a term far below one ulp of the
+  // reciprocal's argument for every d >= 1e-11; at d = 0 the reference's NaN / Inf -> 1 rule multiplies
+  // x_v - x_u = 0 and so does this 0)
+  static constexpr bool kFiniteG = kMerged;
   static constexpr bool kRingFused = false;
   static constexpr float kParamScale = 1.0f;
   MdeFuncArgs A;
   MDE_DEV void eval(float ss, float a0, float a1, float& f, float& gd) const {
-#ifndef MDE_PUSHPULL_DIVERGENT
-    if constexpr (KA == MDE_F_LOG1P && EA == 2 && KR == MDE_F_LOG && ER == 1) {
+    if constexpr (kMerged) {
       // preserve_neighbors' pair (Log1p with exponent 1.5 pulls, Log with exponent 1 pushes) in ONE
       // instruction stream: a wave of a random graph holds both signs, so the divergent if / else below
       // issues both branches -- 6 quarter-rate instructions per entry for the gradient, 10 with the loss
@@ -382,14 +390,13 @@ struct FnPushPull {
       const float t = 1.0f + pe;
       float em;
       const float om = mde_one_minus_expneg(d, em);  // -expm1(-d)
-      const float r = mde_rcp(att ? fmaf(sd, t, 1.0e-30f) : om * ss);
-      gd = (att ? 1.5f * a0 : a0 * d * em) * r;
+      const float r = mde_rcp(att ? fmaf(sd, t, 1.0e-30f) : fmaf(om, ss, 1.0e-36f));
+      gd = a0 * ((att ? 1.5f : d * em) * r);
       const float t2 = 1.0f - em;
       const float corr = att ? (pe - (t - 1.0f)) * sd * r : (d > 1.0f ? (-em - (t2 - 1.0f)) * (1.0f + em) : 0.0f);
       f = a0 * (mde_log(att ? t : om) + corr);
       return;
     }
-#endif
     // other pairs: a divergent if / else (both branches + a select measured SLOWER on the ring kernel:
     // config 4b 0.295 vs 0.267 ms, round 4)
     if (a0 >= 0.0f)  // [ref: penalties.py:390 -- zero weight is attractive]
