@@ -970,21 +970,24 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_codebook_scan(int64_t p, const fl
   constexpr int U = 4;  // independent loads in flight per thread
   for (int64_t i0 = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i0 < p; i0 += U * stride) {
     unsigned int vv[U];
+    bool in_range[U];
 #pragma unroll
     for (int k = 0; k < U; ++k) {
       const int64_t i = i0 + k * stride;
-      vv[k] = i < p ? __float_as_uint(in[i]) : last0;
+      in_range[k] = i < p;
+      vv[k] = in_range[k] ? __float_as_uint(in[i]) : 0u;
     }
 #pragma unroll
     for (int k = 0; k < U; ++k) {
       const unsigned int v = vv[k];
-      if (v == last0 || v == last1) continue;
-      last1 = last0;
-      last0 = v;
-      if (v == MDE_CB_EMPTY) {
+      if (!in_range[k]) continue;
+      if (v == MDE_CB_EMPTY) {  // (the pattern that marks a free slot: a NaN, no codebook)
         *overflow = 1;
         return;
       }
+      if (v == last0 || v == last1) continue;
+      last1 = last0;
+      last0 = v;
       bool placed = false, mine = false;
       for (int s = 0; s < MDE_RING_CB_VALUES && !placed; ++s) {
         const unsigned int old = atomicCAS(&stb[s], MDE_CB_EMPTY, v);

@@ -1889,6 +1889,16 @@ __global__ __launch_bounds__(64) void k_lbfgs_direction(LbDev* __restrict__ dv, 
 // the flag words of the fused kernel: doubles [2304, 3072) of the work buffer's small area (nothing
 // else is kept there; zero or an older epoch between launches)
 static inline unsigned int* work_lb_flags(double* work) { return reinterpret_cast<unsigned int*>(work + 2304); }
+// (design probe, -DMDE_LB_PROBE: workgroup 0 leaves wall-clock stamps -- 100 MHz -- of its phases behind the
+// verdict words; tools/lbfused_probe.py prints them)
+#ifdef MDE_LB_PROBE
+#define LB_STAMP(k)                                                                                    \
+  do {                                                                                                 \
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(verdict + 8)[k] = wall_clock64(); \
+  } while (0)
+#else
+#define LB_STAMP(k) ((void)0)
+#endif
 __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* __restrict__ g, float* __restrict__ g_prev,
                                                         const float* d, float t, float* __restrict__ buf,
                                                         LbDev* __restrict__ dv, int history, float* out,  // (out may be d)
@@ -1908,8 +1918,10 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* 
   const int count = dv->count;
   const int wave = threadIdx.x >> 6;
   const int nb = gridDim.x, b = blockIdx.x;
+  LB_STAMP(0);
   // ---- phase 1
   lb_stage_phase<true>(N, g, g_prev, d, t, buf, dv, partial, sm);
+  LB_STAMP(1);
   // Arrival point `which`: every workgroup raises its own flag word to this launch's epoch (plain
   // device-scope stores to distinct addresses; an arrival COUNTER costs ~20 ns per workgroup because
   // same-address atomics are executed one after the other at the memory side -- 5.6 us for 274
@@ -1940,6 +1952,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* 
     return __hip_atomic_load(verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch;
   };
   if (!grid_arrive(0, true)) return;
+  LB_STAMP(2);
   // ---- phase 2a: workgroup q adds row q of the partials (k_lb_reduce: same order of additions)
   const int nrows = 4 + 5 * count;
   double* dots_g = partial + (int64_t)(4 + 5 * LD + 8) * nb;  // behind the dot-product and statistics rows
@@ -1950,12 +1963,15 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* 
     if (threadIdx.x == 0) mde_st_partial(dots_g + q, tot);
     __syncthreads();
   }
+  LB_STAMP(3);
   if (!grid_arrive(1, true)) return;
+  LB_STAMP(4);
   // ---- phase 2b: every workgroup runs the direction step on the same numbers
   for (int q = threadIdx.x; q < nrows; q += MDE_BLOCK) s_dots[q] = mde_ld_partial(dots_g + q);
   __syncthreads();
   if (wave == 0) lb_direction_core<LD>(dv, s_dots, history, s_SY, s_YY, &s_out);
   __syncthreads();
+  LB_STAMP(5);
   // ---- phase 3 (k_lb_combine_all), with the coefficients and the slot order of s_out
   const int m = s_out.m;
   const float c_g = s_out.c_g;
@@ -1991,15 +2007,18 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* 
   const double v8[8] = {gd, gg, g1, gm, nf, dd, dm, 0.0};
   double* spart = partial + (int64_t)(4 + 5 * LD) * nb;  // behind the dot-product rows
   mde_publish8(v8, (1u << 3) | (1u << 6), spart, nb, b);
+  LB_STAMP(6);
   // workgroup 0 finishes: the statistics rows, and the bookkeeping back to LbDev (everyone has
   // finished reading it when the third flag is up)
   if (!grid_arrive(2, b == 0)) return;
   if (b != 0) return;
+  LB_STAMP(7);
   mde_final_rows(8, nb, spart, stats, (1ull << 3) | (1ull << 6));
   if (wave == 0) lb_write_back<LD>(dv, history, s_SY, s_YY, &s_out);
   __builtin_amdgcn_s_waitcnt(0x0F70);
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(verdict + 1, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  LB_STAMP(8);
 }
 
 // Queued behind every k_lb_fused launch: nothing to do when that launch completed (verdict[1] ==
@@ -2198,8 +2217,10 @@ extern "C" int mde_lbfgs_dev_reset(mde_lbfgs* o, void* stream) {
 struct LbKnobs {
   bool unfused;
   int blocks, spins, lds;
-  LbKnobs() : unfused(getenv("MDE_LB_UNFUSED") != nullptr), blocks(0), spins(0), lds(0) {
+  int max_blocks;  // workgroups of the one-launch step (MDE_LB_MAXBLOCKS: design probe)
+  LbKnobs() : unfused(getenv("MDE_LB_UNFUSED") != nullptr), blocks(0), spins(0), lds(0), max_blocks(256) {
     if (const char* e = getenv("MDE_LB_DEBUG")) sscanf(e, "%d,%d,%d", &blocks, &spins, &lds);
+    if (const char* e = getenv("MDE_LB_MAXBLOCKS")) max_blocks = std::min(std::max(atoi(e), 1), MDE_LB_FUSED_MAXBLOCKS);
   }
 };
 static LbKnobs& lb_knobs() {
@@ -2230,12 +2251,14 @@ extern "C" int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, c
   // rescue kernel take over)
   const LbKnobs& knobs = lb_knobs();
   if (N <= MDE_LB_FUSED_MAXN && o->history < MDE_LB_FUSED_LD && !knobs.unfused) {
-    // At most 128 workgroups: the arrival points need every workgroup of the launch resident at once.
-    // The kernel fits two workgroups per CU (198 VGPRs), i.e. 512 on the chip -- 128 leaves room for
-    // whatever else is resident, e.g. the same kernel of other processes sharing the GPU.  Residency
-    // is still not GUARANTEED by an ordinary launch: a workgroup that waits longer than the spin limit
-    // gives up, and k_lb_rescue (always queued behind) redoes the step -- see k_lb_fused.
-    int nbf = mde_grid(N, MDE_BLOCK * 2, 128);
+    // At most 256 workgroups: the arrival points need every workgroup of the launch resident at once.
+    // The kernel fits two workgroups per CU (198 VGPRs), i.e. 512 on the chip -- 256 leaves half of that
+    // to whatever else is resident, e.g. the same kernel of another process sharing the GPU.  (Round 4:
+    // 128 until the phase stamps of tools/lbfused_probe.py showed the two streaming phases at 11.6 us
+    // each at N = 140k -- five dependent trips per thread, nothing to hide their latency behind.)
+    // Residency is still not GUARANTEED by an ordinary launch: a workgroup that waits longer than the
+    // spin limit gives up, and k_lb_rescue (always queued behind) redoes the step -- see k_lb_fused.
+    int nbf = mde_grid(N, MDE_BLOCK, knobs.max_blocks);
     if (knobs.blocks > 0) nbf = std::min(knobs.blocks, MDE_LB_FUSED_MAXBLOCKS);
     const unsigned int spin_limit = knobs.spins > 0 ? (unsigned int)knobs.spins : (1u << 20);
     static std::atomic<unsigned int> launches{0};  // one epoch per launch, shared by every solver object
