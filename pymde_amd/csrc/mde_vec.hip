@@ -1899,6 +1899,9 @@ static inline unsigned int* work_lb_flags(double* work) { return reinterpret_cas
 #else
 #define LB_STAMP(k) ((void)0)
 #endif
+// G: history pairs per pass over the vectors (8, or 12 when the history has 9 .. 12 pairs: ONE pass in both
+// streaming phases instead of two -- the phases are bound by the latency of their dependent trips)
+template <int G>
 __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* __restrict__ g, float* __restrict__ g_prev,
                                                         const float* d, float t, float* __restrict__ buf,
                                                         LbDev* __restrict__ dv, int history, float* out,  // (out may be d)
@@ -1911,7 +1914,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* 
   // words behind the three flag rows: [0] = epoch once some workgroup gave up waiting, [1] = epoch once
   // the step is complete (k_lb_rescue redoes the step from the staged sums when it is not)
   unsigned int* verdict = flags + 3 * MDE_LB_FUSED_MAXBLOCKS;
-  __shared__ double sm[MDE_BLOCK / 64][MDE_LB_NVAL];
+  __shared__ double sm[MDE_BLOCK / 64][4 + 5 * G];
   __shared__ double s_dots[4 + 5 * LD];
   __shared__ double s_SY[LD * LD], s_YY[LD * LD];
   __shared__ LbOut s_out;
@@ -1920,7 +1923,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* 
   const int nb = gridDim.x, b = blockIdx.x;
   LB_STAMP(0);
   // ---- phase 1
-  lb_stage_phase<true>(N, g, g_prev, d, t, buf, dv, partial, sm);
+  lb_stage_phase<true, G>(N, g, g_prev, d, t, buf, dv, partial, sm);
   LB_STAMP(1);
   // Arrival point `which`: every workgroup raises its own flag word to this launch's epoch (plain
   // device-scope stores to distinct addresses; an arrival COUNTER costs ~20 ns per workgroup because
@@ -1979,17 +1982,17 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* 
   for (int64_t i = (int64_t)b * MDE_BLOCK + threadIdx.x; i < N; i += (int64_t)nb * MDE_BLOCK) {
     const float gv = g[i];
     float v = c_g * gv;
-    for (int j0 = 0; j0 < m; j0 += MDE_LB_GROUP) {
-      float sv[MDE_LB_GROUP], yv[MDE_LB_GROUP];
+    for (int j0 = 0; j0 < m; j0 += G) {
+      float sv[G], yv[G];
 #pragma unroll
-      for (int j = 0; j < MDE_LB_GROUP; ++j) {
+      for (int j = 0; j < G; ++j) {
         const int jj = (j0 + j < m) ? j0 + j : 0;
         const float* sp = buf + (int64_t)(2 * s_out.order[jj]) * N;
         sv[j] = sp[i];
         yv[j] = sp[N + i];
       }
 #pragma unroll
-      for (int j = 0; j < MDE_LB_GROUP; ++j)
+      for (int j = 0; j < G; ++j)
         if (j0 + j < m) v = fmaf(s_out.cy[j0 + j], yv[j], fmaf(s_out.cs[j0 + j], sv[j], v));
     }
     out[i] = v;
@@ -2263,9 +2266,10 @@ extern "C" int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, c
     const unsigned int spin_limit = knobs.spins > 0 ? (unsigned int)knobs.spins : (1u << 20);
     static std::atomic<unsigned int> launches{0};  // one epoch per launch, shared by every solver object
     const unsigned int epoch = 4u * (launches.fetch_add(1u) + 1u);
+    auto kern = (o->history > MDE_LB_GROUP && o->history <= 12) ? k_lb_fused<12> : k_lb_fused<MDE_LB_GROUP>;
     if (knobs.lds > 0)
-      MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lb_fused), hipFuncAttributeMaxDynamicSharedMemorySize, knobs.lds));
-    hipLaunchKernelGGL(k_lb_fused, dim3(nbf), dim3(MDE_BLOCK), (size_t)std::max(knobs.lds, 0), st, N, g, g_prev, d, t, o->buf,
+      MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, knobs.lds));
+    hipLaunchKernelGGL(kern, dim3(nbf), dim3(MDE_BLOCK), (size_t)std::max(knobs.lds, 0), st, N, g, g_prev, d, t, o->buf,
                        o->dev, o->history, d_out, partial, stats, work_lb_flags(work), epoch, spin_limit);
     MDE_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_lb_rescue, dim3(1), dim3(MDE_BLOCK), 0, st, N, g, o->buf, o->dev, o->history, d_out, nbf, partial, stats,
