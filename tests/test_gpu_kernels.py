@@ -388,9 +388,10 @@ def test_constraints_against_reference_golden(golden_constraints):
 
 
 @pytest.mark.parametrize("n,d", [(2, 2), (10, 3), (100, 3), (1000, 2), (1000, 3), (1000, 250), (5000, 128),
-                                 (3000, 64), (777, 96)])
+                                 (3000, 64), (777, 96), (600000, 2), (350001, 3)])
 def test_proj_standardized_property(n, d):
-    # pymde/test_util.py:20-71 (shapes incl. (1000, 250)); d = 64/96/128 take the f32 MFMA Gram
+    # pymde/test_util.py:20-71 (shapes incl. (1000, 250)); d = 64/96/128 take the f32 MFMA Gram; the two
+    # tall shapes are vectors of more than 2^20 floats (many trips per thread of the reducing kernels)
     from pymde_amd import util
     torch.manual_seed(0)
     X = torch.randn((n, d), device=DEV)
@@ -401,6 +402,40 @@ def test_proj_standardized_property(n, d):
         np.testing.assert_allclose(P.mean(0), 0, atol=1e-5)
         want = oracle.proj_standardized(X.cpu().numpy(), demean=True)
         np.testing.assert_allclose(P, want, rtol=2e-3, atol=5e-4)
+
+
+@pytest.mark.parametrize("n,d", [(1000, 2), (600000, 2), (350001, 3), (300000, 4)])
+def test_centering_and_vector_statistics_on_long_vectors(n, d):
+    """The reducing kernels on short and on long vectors (many trips per thread, 16-byte and tail loads)
+    against float64 torch: Centered retraction of a line-search trial point, and the solver's statistics."""
+    import ctypes
+    import pymde_amd
+    from pymde_amd import _lib, util
+    lib = _lib.load()
+    torch.manual_seed(3)
+    X = torch.randn((n, d), device=DEV) + 0.25
+    D = torch.randn((n, d), device=DEV)
+    c = pymde_amd.Centered()
+    Z = c.project_onto_constraint(X.clone(), inplace=True)
+    want = (X.double() - X.double().mean(0)).float()
+    assert float((Z - want).abs().max()) <= 2e-7 * float(X.abs().max())
+    assert float(Z.double().mean(0).abs().max()) < 1e-7
+    work = util.work_buffer(torch.device(DEV), d)
+    out = torch.empty_like(X)
+    _lib.check(lib.mde_center_step(n, d, _lib.ptr(X), _lib.ptr(D), ctypes.c_float(0.375), _lib.ptr(out), _lib.ptr(work),
+                                   _lib.stream_ptr()))
+    step = torch.addcmul(X, D, torch.tensor(0.375, device=DEV))  # fl(X + t D), as the kernel rounds it
+    want = (step.double() - step.double().mean(0)).float()
+    assert float((out - want).abs().max()) <= 2e-7 * float(step.abs().max())
+    board = torch.zeros(64, dtype=torch.float64, device=DEV)
+    g, dd, x = X.reshape(-1), D.reshape(-1), out.reshape(-1)
+    _lib.check(lib.mde_vec_stats(n * d, _lib.ptr(g), _lib.ptr(dd), _lib.ptr(x), _lib.ptr(board), _lib.ptr(work),
+                                 _lib.stream_ptr()))
+    b = board.cpu().numpy()
+    g64, d64, x64 = g.double(), dd.double(), x.double()
+    ref = [float((g64 * d64).sum()), float((g64 * g64).sum()), float(g64.abs().sum()), float(g64.abs().max()), 0.0,
+           float((d64 * d64).sum()), float(d64.abs().max()), float((x64 * x64).sum())]
+    np.testing.assert_allclose(b[:8], ref, rtol=1e-12, atol=1e-9)
 
 
 def test_standardized_initialization():
