@@ -35,7 +35,8 @@ class MdeTurnDesc(ctypes.Structure):
                 ("X", c_vp * 2), ("g", c_vp), ("g_prev", c_vp), ("dir", c_vp), ("loss_dev", c_vp),
                 ("board", c_vp), ("work", c_vp), ("status", c_vp), ("lbfgs", c_vp),
                 ("host_dst", c_vp), ("tail_src", c_vp), ("read_bytes", c_i64),
-                ("host_loss", c_vp), ("host_status", c_vp), ("host_board", c_vp), ("seq", ctypes.c_double)]
+                ("host_loss", c_vp), ("host_status", c_vp), ("host_board", c_vp), ("seq", ctypes.c_double),
+                ("pre_id", ctypes.c_double)]
 
 
 # every exported symbol of include/mde_hip.h: name -> (restype, argtypes)
@@ -104,8 +105,9 @@ SYMBOLS = {
     "mde_lbfgs_combine": (c_i32, [c_vp, c_vp, c_f32, ctypes.POINTER(c_f32),
                                   ctypes.POINTER(c_f32), c_vp, c_vp, c_vp, c_vp]),
     "mde_copy_to_host": (c_i32, [c_vp, c_vp, c_i64, c_vp]),
-    "mde_turn_enqueue": (c_i32, [c_vp, c_i32, c_f32, c_vp]),
-    "mde_turn_wait": (c_i32, [c_vp, c_i32, ctypes.c_double, c_i32, ctypes.c_double, ctypes.c_double, c_vp, c_vp]),
+    "mde_turn_enqueue": (c_i32, [c_vp, c_i32, c_f32, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_i32, c_vp]),
+    "mde_turn_wait": (c_i32, [c_vp, c_i32, ctypes.c_double, c_i32, ctypes.c_double, ctypes.c_double, ctypes.c_double,
+                             c_vp, c_vp]),
 }
 
 _lib = None

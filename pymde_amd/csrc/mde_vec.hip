@@ -136,19 +136,53 @@ struct MdeMirror {
   char* host;
   int head_bytes;        // bytes of [loss | status | pad] in front of the board
   double seq;            // written behind the 24 board entries once they are out (polled by the host)
+  // mde_turn_*: the first pass of the line search at t = 1 decided HERE (the host reads the verdict in
+  // mirrored board slot 8 and does not test again), and a word that opens or closes the L-BFGS step of
+  // the next iteration, which is queued right behind this kernel (see MdeGate).  gate == nullptr: none.
+  unsigned int* gate;
+  unsigned int gate_value;
+  double f0, c1, c2;
 };
+// A launch that runs only when the iteration before it accepted its first trial point: the kernels of
+// the next L-BFGS direction update are enqueued BEHIND an iteration's last kernel, before the host has
+// seen its result (the host's turn-around -- mirror write, poll, test, launch -- was 15 us in which the
+// GPU idled, `tools/iter_trace.sh`); that last kernel writes `value` to the word when the trial is
+// accepted, anything else when it is not, and the gated kernels leave at once unless they find `value`.
+// word == nullptr: an ordinary launch.
+struct MdeGate {
+  const unsigned int* word;
+  unsigned int value;
+};
+__device__ __forceinline__ bool mde_gate_closed(const MdeGate& g) {
+  return g.word != nullptr && __hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.value;
+}
 __device__ __forceinline__ void mde_mirror_write(const MdeMirror& m) {
   if (!m.host) return;
   __threadfence_block();
   __syncthreads();  // the statistics rows written by this block are visible to it
   double* hb = reinterpret_cast<double*>(m.host + m.head_bytes);
-  if (threadIdx.x < 24) {
+  if (threadIdx.x < 24 && !(m.gate && threadIdx.x == 8)) {  // (slot 8: the verdict below, when there is one)
     const volatile double* b = m.board;
     hb[threadIdx.x] = b[threadIdx.x];
   }
   if (threadIdx.x == 32) *reinterpret_cast<float*>(m.host) = *reinterpret_cast<const volatile float*>(m.loss_dev);
   if (threadIdx.x == 33)
     *reinterpret_cast<int32_t*>(m.host + 4) = m.status ? *reinterpret_cast<const volatile int32_t*>(m.status) : 0;
+  if (m.gate && threadIdx.x == 34) {
+    // [ref: lbfgs.py:88-110, first pass of the bracketing loop at t = 1: finite, Armijo, curvature]
+    // (separately rounded product and sum: the value the host-side search computes)
+    // (five independent loads in flight at once: relaxed device-scope loads, not `volatile` ones, which
+    // the compiler keeps apart -- a memory latency each, in the last kernel of every iteration)
+    const double gtd_new = __hip_atomic_load(m.board + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double gtd0 = __hip_atomic_load(m.board + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double nonfinite = __hip_atomic_load(m.board + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double f_new = (double)__hip_atomic_load(m.loss_dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int st = m.status ? __hip_atomic_load(m.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    const bool bad = !(fabs(f_new) <= 1.7976931348623157e308) || nonfinite != 0.0;
+    const bool accept = !bad && !(f_new > __dadd_rn(m.f0, __dmul_rn(m.c1, gtd0))) && (fabs(gtd_new) <= -__dmul_rn(m.c2, gtd0));
+    hb[8] = accept ? 1.0 : 0.0;
+    *m.gate = (accept && st == 0) ? m.gate_value : 0u;
+  }
   // the sequence word goes out behind the data: every writer fences to system scope, then one thread
   // publishes (the host polls it instead of waiting for the stream's completion signal)
   __threadfence_system();
@@ -238,7 +272,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_vec_stats(int64_t N, const float*
 }
 
 static int vec_stats_impl(int64_t N, const float* g, const float* d, const float* x, double* stats,
-                          double* work, hipStream_t st, MdeMirror mirror = MdeMirror{nullptr, nullptr, nullptr, nullptr, 0, 0.0}) {
+                          double* work, hipStream_t st, MdeMirror mirror = MdeMirror{}) {
   const int nb = mde_grid(N, MDE_BLOCK * 8, MDE_RED_BLOCKS);
   hipLaunchKernelGGL(k_vec_stats, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, d, x, work + MDE_SMALL_DOUBLES, stats,
                      work_ticket(work, TK_STATS), mirror);
@@ -814,7 +848,7 @@ static int std_tangent_stats_impl(int64_t n, int32_t d, const float* X, float* Z
 extern "C" int mde_std_tangent_stats(int64_t n, int32_t d, const float* X, float* Z, const float* dir, double* stats,
                                      double* work, void* stream) {
   if (n <= 0 || d <= 0 || d > 2048 || !X || !Z || !stats || !work) return MDE_E_INVALID;
-  return std_tangent_stats_impl(n, d, X, Z, dir, stats, work, stream, MdeMirror{nullptr, nullptr, nullptr, nullptr, 0, 0.0});
+  return std_tangent_stats_impl(n, d, X, Z, dir, stats, work, stream, MdeMirror{});
 }
 
 // ---------------------------------------------------------------- C^{-1/2} of a small SPD matrix
@@ -1862,7 +1896,8 @@ __device__ void lb_write_back(LbDev* __restrict__ dv, int history, const double*
 #define MDE_LB_DIR_LDS(LD) (2 * (LD) * (LD) * sizeof(double) + sizeof(LbOut))
 template <int LD>
 __global__ __launch_bounds__(64) void k_lbfgs_direction(LbDev* __restrict__ dv, const double* __restrict__ dots,
-                                                        int history) {
+                                                        int history, MdeGate gate) {
+  if (mde_gate_closed(gate)) return;
   extern __shared__ __attribute__((aligned(16))) char lb_lds[];
   double* SY = reinterpret_cast<double*>(lb_lds);
   double* YY = SY + LD * LD;
@@ -1907,7 +1942,8 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* 
                                                         LbDev* __restrict__ dv, int history, float* out,  // (out may be d)
                                                         double* __restrict__ partial, double* __restrict__ stats,
                                                         unsigned int* __restrict__ flags, unsigned int epoch,
-                                                        unsigned int spin_limit) {
+                                                        unsigned int spin_limit, MdeGate gate) {
+  if (mde_gate_closed(gate)) return;  // (every workgroup reads the same word: all of them leave, or none)
   constexpr int LD = MDE_LB_FUSED_LD;
   extern __shared__ char lb_debug_lds[];  // (only a test asks for dynamic LDS: it limits the workgroups per CU)
   (void)lb_debug_lds;
@@ -2033,8 +2069,9 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_fused(int64_t N, const float* 
 __global__ __launch_bounds__(MDE_BLOCK) void k_lb_rescue(int64_t N, const float* __restrict__ g, const float* __restrict__ buf,
                                                          LbDev* __restrict__ dv, int history, float* out, int nb,
                                                          double* __restrict__ partial, double* __restrict__ stats,
-                                                         unsigned int* __restrict__ flags, unsigned int epoch) {
+                                                         unsigned int* __restrict__ flags, unsigned int epoch, MdeGate gate) {
   constexpr int LD = MDE_LB_FUSED_LD;
+  if (mde_gate_closed(gate)) return;
   unsigned int* verdict = flags + 3 * MDE_LB_FUSED_MAXBLOCKS;
   if (__hip_atomic_load(verdict + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch) return;
   if (threadIdx.x == 0) verdict[2] += 1u;  // (how often the rescue had to run: tests read it from the work buffer)
@@ -2097,7 +2134,8 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_stage_all(int64_t N, const flo
                                                             const float* __restrict__ d, float t,
                                                             float* __restrict__ buf,
                                                             const LbDev* __restrict__ dv,
-                                                            double* __restrict__ partial) {
+                                                            double* __restrict__ partial, MdeGate gate) {
+  if (mde_gate_closed(gate)) return;
   __shared__ double sm[MDE_BLOCK / 64][4 + 5 * G];
   lb_stage_phase<false, G>(N, g, g_prev, d, t, buf, dv, partial, sm);
 }
@@ -2105,7 +2143,8 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_stage_all(int64_t N, const flo
 // dots[q] = sum_b partial[q * nb + b] for the 4 + 5 count rows that were written (one workgroup per
 // row: 54 rows of up to 1024 partials are too much for one last workgroup)
 __global__ void k_lb_reduce(int nb, const double* __restrict__ partial, const LbDev* __restrict__ dv,
-                            double* __restrict__ dots) {
+                            double* __restrict__ dots, MdeGate gate) {
+  if (mde_gate_closed(gate)) return;
   __shared__ double smem[8];
   const int q = blockIdx.x;
   if (q >= 4 + 5 * dv->count) return;
@@ -2122,7 +2161,8 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_lb_combine_all(int64_t N, const f
                                                               float* __restrict__ out,
                                                               double* __restrict__ partial,
                                                               double* __restrict__ stats,
-                                                              unsigned int* __restrict__ ticket) {
+                                                              unsigned int* __restrict__ ticket, MdeGate gate) {
+  if (mde_gate_closed(gate)) return;
   __shared__ double smem[8];
   __shared__ float s_cs[MDE_LB_LD + MDE_LB_GROUP], s_cy[MDE_LB_LD + MDE_LB_GROUP];
   __shared__ int s_slot[MDE_LB_LD + MDE_LB_GROUP];
@@ -2243,8 +2283,8 @@ extern "C" int mde_lbfgs_debug_knobs(int32_t unfused, int32_t blocks, int32_t sp
 // g_prev <- g), accept / reject, two-loop recursion, d_out = the new direction, stats as
 // mde_vec_stats(g, d_out, NULL).  ASYNC.  (The host-driven mde_lbfgs_stage / commit / combine act on
 // the host-side bookkeeping and must not be mixed with this on one object.)
-extern "C" int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, const float* d, float t,
-                                  float* d_out, double* stats, double* work, void* stream) {
+static int lbfgs_dev_step_impl(mde_lbfgs* o, const float* g, float* g_prev, const float* d, float t,
+                               float* d_out, double* stats, double* work, void* stream, MdeGate gate) {
   if (!o || !o->dev || !g || !g_prev || !d || !d_out || !stats || !work) return MDE_E_INVALID;
   hipStream_t st = mde_stream(stream);
   const int64_t N = o->N;
@@ -2270,25 +2310,25 @@ extern "C" int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, c
     if (knobs.lds > 0)
       MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, knobs.lds));
     hipLaunchKernelGGL(kern, dim3(nbf), dim3(MDE_BLOCK), (size_t)std::max(knobs.lds, 0), st, N, g, g_prev, d, t, o->buf,
-                       o->dev, o->history, d_out, partial, stats, work_lb_flags(work), epoch, spin_limit);
+                       o->dev, o->history, d_out, partial, stats, work_lb_flags(work), epoch, spin_limit, gate);
     MDE_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_lb_rescue, dim3(1), dim3(MDE_BLOCK), 0, st, N, g, o->buf, o->dev, o->history, d_out, nbf, partial, stats,
-                       work_lb_flags(work), epoch);
+                       work_lb_flags(work), epoch, gate);
     MDE_LAUNCH_CHECK();
     return MDE_OK;
   }
   const int nb = mde_grid(N, MDE_BLOCK * 2, 1024);
   double* dots = work;  // the small area: 4 + 5 * 63 doubles at most
   if (o->history > MDE_LB_GROUP && o->history <= 12)
-    hipLaunchKernelGGL(k_lb_stage_all<12>, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t, o->buf, o->dev, partial);
+    hipLaunchKernelGGL(k_lb_stage_all<12>, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t, o->buf, o->dev, partial, gate);
   else
     hipLaunchKernelGGL(k_lb_stage_all<MDE_LB_GROUP>, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t, o->buf,
-                       o->dev, partial);
+                       o->dev, partial, gate);
   MDE_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_lb_reduce, dim3(4 + 5 * o->history), dim3(MDE_BLOCK), 0, st, nb, partial, o->dev, dots);
+  hipLaunchKernelGGL(k_lb_reduce, dim3(4 + 5 * o->history), dim3(MDE_BLOCK), 0, st, nb, partial, o->dev, dots, gate);
   MDE_LAUNCH_CHECK();
   if (o->history < 16) {
-    hipLaunchKernelGGL(k_lbfgs_direction<16>, dim3(1), dim3(64), MDE_LB_DIR_LDS(16), st, o->dev, dots, o->history);
+    hipLaunchKernelGGL(k_lbfgs_direction<16>, dim3(1), dim3(64), MDE_LB_DIR_LDS(16), st, o->dev, dots, o->history, gate);
   } else {
     static bool dir_attr = false;
     if (!dir_attr) {
@@ -2297,14 +2337,18 @@ extern "C" int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, c
       dir_attr = true;
     }
     hipLaunchKernelGGL(k_lbfgs_direction<MDE_LB_LD>, dim3(1), dim3(64), MDE_LB_DIR_LDS(MDE_LB_LD), st, o->dev, dots,
-                       o->history);
+                       o->history, gate);
   }
   MDE_LAUNCH_CHECK();
   const int nbc = mde_grid(N, MDE_BLOCK * 2, MDE_RED_BLOCKS);  // (its last workgroup adds nbc partials per row)
   hipLaunchKernelGGL(k_lb_combine_all, dim3(nbc), dim3(MDE_BLOCK), 0, st, N, g, o->buf, o->dev, d_out, partial,
-                     stats, work_ticket(work, TK_LB_COMBINE));
+                     stats, work_ticket(work, TK_LB_COMBINE), gate);
   MDE_LAUNCH_CHECK();
   return MDE_OK;
+}
+extern "C" int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, const float* d, float t,
+                                  float* d_out, double* stats, double* work, void* stream) {
+  return lbfgs_dev_step_impl(o, g, g_prev, d, t, d_out, stats, work, stream, MdeGate{nullptr, 0u});
 }
 
 // copies of the device bookkeeping for tests: count, accepted
@@ -2367,13 +2411,29 @@ extern "C" int mde_lbfgs_combine(mde_lbfgs* o, const float* g, float c_g, const 
 }
 
 // ---------------------------------------------------------------- one solver iteration as two calls
-extern "C" int mde_turn_enqueue(mde_turn_desc* T, int32_t cur, float t_prev, void* stream) {
+// the gate word of the pre-enqueued L-BFGS step (MdeGate): a double of the work buffer's small area nobody
+// else uses
+static inline unsigned int* work_turn_gate(double* work) { return reinterpret_cast<unsigned int*>(work + 3200); }
+static bool turn_pre_enabled() {
+  static const bool on = getenv("MDE_TURN_NOPRE") == nullptr;  // (design probe: no look-ahead of the L-BFGS step)
+  return on;
+}
+
+// One iteration: [L-BFGS step unless step_done] retraction of X + dir, evaluation, statistics -- whose
+// kernel also DECIDES the first pass of the line search (f0, c1, c2: MdeMirror) -- and, with allow_pre, the
+// L-BFGS step of the iteration after this one behind a gate that opens iff this trial is accepted.
+static int turn_enqueue_impl(mde_turn_desc* T, int32_t cur, float t_prev, double f0, double c1, double c2,
+                             bool allow_pre, bool step_done, void* stream) {
   if (!T || (cur != 0 && cur != 1) || (T->kind != 0 && T->kind != 1)) return MDE_E_INVALID;
   const int64_t N = T->n * (int64_t)T->d;
   float* Xc = T->X[cur];
   float* Xt = T->X[1 - cur];
-  int rc = mde_lbfgs_dev_step(T->lbfgs, T->g, T->g_prev, T->dir, t_prev, T->dir, T->board + 16, T->work, stream);
-  if (rc != MDE_OK) return rc;
+  int rc = MDE_OK;
+  if (!step_done) {
+    rc = lbfgs_dev_step_impl(T->lbfgs, T->g, T->g_prev, T->dir, t_prev, T->dir, T->board + 16, T->work, stream,
+                             MdeGate{nullptr, 0u});
+    if (rc != MDE_OK) return rc;
+  }
   if (T->kind == 0)
     rc = mde_center_step(T->n, T->d, Xc, T->dir, 1.0f, Xt, T->work, stream);
   else
@@ -2383,16 +2443,35 @@ extern "C" int mde_turn_enqueue(mde_turn_desc* T, int32_t cur, float t_prev, voi
   if (rc != MDE_OK) return rc;
   // the last kernel writes [loss | status | board] into the pinned mirror itself (no copy behind it)
   static std::atomic<unsigned long long> turns{0};
-  T->seq = (double)(turns.fetch_add(1ull) + 1ull);  // (exact in a double for 2^53 iterations)
-  const MdeMirror mirror{T->loss_dev, T->status, T->board, reinterpret_cast<char*>(T->host_dst),
-                         (int)(T->read_bytes - 8 * 24), T->seq};
+  const unsigned long long id = turns.fetch_add(1ull) + 1ull;
+  T->seq = (double)id;  // (exact in a double for 2^53 iterations)
+  unsigned int gate_value = (unsigned int)(id & 0xffffffffull);
+  if (gate_value == 0u) gate_value = 1u;
+  MdeMirror mirror{T->loss_dev, T->status, T->board, reinterpret_cast<char*>(T->host_dst),
+                   (int)(T->read_bytes - 8 * 24), T->seq, work_turn_gate(T->work), gate_value, f0, c1, c2};
   if (T->kind == 0)
-    return vec_stats_impl(N, T->g, T->dir, Xt, T->board, T->work, mde_stream(stream), mirror);
-  return std_tangent_stats_impl(T->n, T->d, Xt, T->g, T->dir, T->board, T->work, stream, mirror);
+    rc = vec_stats_impl(N, T->g, T->dir, Xt, T->board, T->work, mde_stream(stream), mirror);
+  else
+    rc = std_tangent_stats_impl(T->n, T->d, Xt, T->g, T->dir, T->board, T->work, stream, mirror);
+  if (rc != MDE_OK) return rc;
+  T->pre_id = 0.0;
+  if (allow_pre && turn_pre_enabled()) {
+    // the direction update of the NEXT iteration (an accepted first trial is the step t = 1), gated
+    rc = lbfgs_dev_step_impl(T->lbfgs, T->g, T->g_prev, T->dir, 1.0f, T->dir, T->board + 16, T->work, stream,
+                             MdeGate{work_turn_gate(T->work), gate_value});
+    if (rc != MDE_OK) return rc;
+    T->pre_id = (double)gate_value;
+  }
+  return MDE_OK;
+}
+
+extern "C" int mde_turn_enqueue(mde_turn_desc* T, int32_t cur, float t_prev, double f0, double c1, double c2,
+                                int32_t allow_pre, void* stream) {
+  return turn_enqueue_impl(T, cur, t_prev, f0, c1, c2, allow_pre != 0, false, stream);
 }
 
 extern "C" int mde_turn_wait(mde_turn_desc* T, int32_t cur, double f0, int32_t allow_next, double c1, double c2,
-                             double* out, void* stream) {
+                             double eps_pre, double* out, void* stream) {
   if (!T || !out || (cur != 0 && cur != 1)) return MDE_E_INVALID;
   // Poll the sequence word the iteration's last kernel writes behind its data (a completion signal
   // takes microseconds longer to reach a waiting thread); the stream is queried now and then, so the
@@ -2418,14 +2497,19 @@ extern "C" int mde_turn_wait(mde_turn_desc* T, int32_t cur, double f0, int32_t a
   }
   out[0] = f_new;
   out[3] = (double)*T->host_status;
-  // the first pass of the bracketing loop at t = 1 (lbfgs.py:88-110): not bad, Armijo, curvature
-  const double gtd0 = hb[16 + 0], gtd_new = hb[0];
-  const bool bad = std::isnan(f_new) || std::isinf(f_new) || hb[4] != 0.0;
-  const bool accept = !bad && !(f_new > (f0 + c1 * 1.0 * gtd0)) && (std::fabs(gtd_new) <= -c2 * gtd0);
+  // the first pass of the bracketing loop at t = 1 (lbfgs.py:88-110): not bad, Armijo, curvature -- decided
+  // by the iteration's last kernel (mde_mirror_write) from f0 as passed when it was enqueued; the gate of a
+  // pre-enqueued L-BFGS step followed THAT verdict, so it is the one to go by
+  (void)f0;
+  const bool accept = hb[8] != 0.0;
   out[1] = accept ? 1.0 : 0.0;
   out[2] = 0.0;
+  const bool step_done = accept && *T->host_status == 0 && T->pre_id != 0.0;  // (its gate opened)
+  T->pre_id = 0.0;
   if (accept && allow_next && *T->host_status == 0) {
-    const int rc = mde_turn_enqueue(T, 1 - cur, 1.0f, stream);
+    // (hb[1]: |g|^2 at the accepted point -- the next iteration goes on to another one iff it is above eps)
+    const bool allow_pre = eps_pre >= 0.0 && std::sqrt(hb[1]) > eps_pre;
+    const int rc = turn_enqueue_impl(T, 1 - cur, 1.0f, f_new, c1, c2, allow_pre, step_done, stream);
     if (rc != MDE_OK) return rc;
     out[2] = 1.0;
   }

@@ -491,9 +491,13 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
                 # next iteration -- one call
                 go_on = (iteration + 1 < max_iter and math.sqrt(last_gg) > eps
                          and not (snapshot_every is not None and (iteration + 1) % snapshot_every == 0))
+                # (the iteration launched in there may carry the L-BFGS step of the one after it, behind a
+                # gate: only when that one is inside the loop too; its gradient test is made in the library)
+                pre_ok = (iteration + 2 < max_iter
+                          and not (snapshot_every is not None and (iteration + 2) % snapshot_every == 0))
                 cur = 0 if e.X is turn_bufs[0] else 1
                 _lib.check(e.lib.mde_turn_wait(turn_ref, cur, float(loss), 1 if go_on else 0, 1e-4, 0.9,
-                                               turn_out_ptr, e._stream))
+                                               float(eps) if pre_ok else -1.0, turn_out_ptr, e._stream))
                 o = turn_out
                 n_evals[0] += 1 if o[2] != 0.0 else 0  # (the next iteration's first trial, launched inside mde_turn_wait)
                 tv = o[4:12]
@@ -565,7 +569,10 @@ def _solve(e, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
                     and new_xx is not None
                     and not (snapshot_every is not None and (iteration + 1) % snapshot_every == 0)):
                 if turn is not None:
-                    _lib.check(e.lib.mde_turn_enqueue(turn_ref, 0 if e.X is turn_bufs[0] else 1, float(t), e._stream))
+                    pre_ok = (iteration + 2 < max_iter and math.sqrt(last_gg) > eps
+                              and not (snapshot_every is not None and (iteration + 2) % snapshot_every == 0))
+                    _lib.check(e.lib.mde_turn_enqueue(turn_ref, 0 if e.X is turn_bufs[0] else 1, float(t),
+                                                      float(cached_loss), 1e-4, 0.9, 1 if pre_ok else 0, e._stream))
                     n_evals[0] += 1
                 else:
                     e.update_direction(t)

@@ -517,15 +517,16 @@ def test_fused_trial_point_and_projection_entry_points(d):
             assert float(b_got[q]) == pytest.approx(float(b_want[q]), rel=1e-12, abs=1e-300), q
 
 
-@pytest.mark.parametrize("cname", ["centered", "standardized"])
-def test_turn_calls_follow_the_python_loop_bit_for_bit(monkeypatch, cname):
-    """mde_turn_enqueue / mde_turn_wait (wait, first-trial strong-Wolfe test and launch of the next
-    iteration inside the library, read-back written by the last kernel) against the same solve driven
-    call by call from Python (MDE_NO_TURN=1): identical iterates and statistics, on a problem whose
-    line search both accepts t = 1 at once and has to bracket / zoom."""
+@pytest.mark.parametrize("cname,n,p", [("centered", 6000, 60000), ("standardized", 6000, 60000),
+                                       ("centered", 140000, 700000), ("standardized", 140000, 700000)])
+def test_turn_calls_follow_the_python_loop_bit_for_bit(monkeypatch, cname, n, p):
+    """mde_turn_enqueue / mde_turn_wait (wait, launch of the next iteration inside the library, read-back and
+    first-trial strong-Wolfe test by the iteration's last kernel, the next L-BFGS step queued behind it and
+    gated on that test) against the same solve driven call by call from Python (MDE_NO_TURN=1): identical
+    iterates and statistics, on a problem whose line search both accepts t = 1 at once and has to bracket /
+    zoom.  n = 140k: vectors beyond the one-launch L-BFGS step (the gated kernels are the four-launch form)."""
     import pymde_amd
     rng = np.random.default_rng(17)
-    n, p = 6000, 60000
     i = rng.integers(0, n, p)
     j = (i + 1 + rng.integers(0, n - 1, p)) % n
     edges = torch.tensor(np.stack([i, j], 1), device=DEV)
