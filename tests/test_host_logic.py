@@ -35,6 +35,45 @@ def test_library_exports_every_declared_symbol():
     assert lib.mde_work_doubles(2) > 0
 
 
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every prototype of include/mde_hip.h against the ctypes table: same number of arguments, and for each
+    one the same kind (pointer / int32 / int64 / float / double) -- an argument added on one side only would
+    otherwise show up as a corrupted call, not as an error."""
+    text = open(os.path.join(ROOT, "include", "mde_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    protos = re.findall(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(mde_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", text)
+    assert len(protos) >= 60
+
+    def kind_c(t):
+        t = t.strip()
+        if "*" in t:
+            return "ptr"
+        base = re.sub(r"\b(const|unsigned|struct)\b", "", t).split()
+        base = base[0] if base else ""
+        return {"int64_t": "i64", "uint64_t": "u64", "int32_t": "i32", "int": "i32", "float": "f32", "double": "f64"}[base]
+
+    def kind_py(t):
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
+            return "ptr"
+        return {ctypes.c_int64: "i64", ctypes.c_uint64: "u64", ctypes.c_int32: "i32", ctypes.c_float: "f32",
+                ctypes.c_double: "f64"}[t]
+
+    seen = set()
+    for ret, name, params in protos:
+        params = params.strip()
+        plist = [] if params in ("", "void") else [q.strip() for q in params.split(",")]
+        # drop the parameter name: the type is everything up to the last identifier
+        kinds = [kind_c(re.sub(r"[A-Za-z_][A-Za-z0-9_]*(\[\d*\])?$", "", q) if not q.endswith("*") else q) for q in plist]
+        restype, argtypes = _lib.SYMBOLS[name]
+        assert [kind_py(t) for t in argtypes] == kinds, name
+        rk = "ptr" if "*" in ret else {"int64_t": "i64", "int32_t": "i32", "int": "i32", "void": "void"}[
+            re.sub(r"\b(const|extern)\b", "", ret).split()[-1]]
+        assert (kind_py(restype) if restype is not None else "void") == rk, name
+        seen.add(name)
+    assert seen == set(_lib.SYMBOLS)
+
+
 def test_mde_func_struct_layout_matches_header():
     # struct mde_func: 2 x int32, 2 x pointer, 2 x int32, 6 x float, int32 (+4 pad) (include/mde_hip.h)
     assert ctypes.sizeof(_lib.MdeFunc) == 8 + 16 + 8 + 24 + 4 + 4
