@@ -1073,11 +1073,14 @@ extern "C" int mde_plan_expand_codebook(const mde_plan* plan, const float* in_ed
   for (int s = 1; s < MDE_RING_CB_VALUES; ++s)
     if (host_tb[s] != MDE_CB_EMPTY) vals[1 + nv++] = host_tb[s];
   if (nv == 0 || nv > max_values) return MDE_OK;
-  // (finite values only: the kernel skips the NaN/Inf fix-up of f'/d for codebook streams)
+  // (finite values of ordinary size only: the kernel skips the NaN/Inf fix-up of f'/d for codebook
+  // streams -- the functors that keep f'/d finite at d = 0 do so with a reciprocal of up to 1e30, which a
+  // weight beyond 2e8 would carry to Inf (times x_v - x_u = 0: NaN where the reference has 0); weights
+  // beyond 1e6 stream as fp32 next to the packed word instead, with the fix-up)
   for (int s = 1; s <= nv; ++s) {
     float fv;
     memcpy(&fv, &vals[s], sizeof(float));
-    if (!std::isfinite(fv)) return MDE_OK;
+    if (!std::isfinite(fv) || std::fabs(fv) > 1.0e6f) return MDE_OK;
   }
   for (int a = 2; a <= nv; ++a)
     for (int b = a; b > 1 && vals[b - 1] > vals[b]; --b) {

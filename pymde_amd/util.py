@@ -106,22 +106,27 @@ def center(X):
     return constraints.Centered().project_onto_constraint(X, inplace=False)
 
 
-_WORK = {}
+_WORK = {}          # (device, stream handle) -> buffer, least recently used first
+_WORK_KEEP = 8      # streams whose scratch is kept (34 MB each at d <= 4): a program that solves on many
+                    # short-lived streams must not accumulate one buffer per stream it ever used
 
 
 def work_buffer(device, d):
     """Scratch (doubles) for the reduction / Gram kernels, one buffer per (device, current stream):
     the kernels that finish their reduction in the last workgroup keep arrival counters in it, so
-    two streams must never share one."""
+    two streams must never share one.  The buffers of the `_WORK_KEEP` most recently used streams are
+    kept; an evicted one stays alive as long as a solver object still holds it."""
     lib = _lib.load()
     need = int(lib.mde_work_doubles(int(d)))
     key = (str(device), int(torch.cuda.current_stream(device).cuda_stream))
-    buf = _WORK.get(key)
+    buf = _WORK.pop(key, None)
     if buf is None or buf.numel() < need:
         # zeroed once: the small area holds the arrival counters of the kernels that finish their
         # reduction in the last workgroup (they return to zero after every launch)
         buf = torch.zeros(need, dtype=torch.float64, device=device)
-        _WORK[key] = buf
+    _WORK[key] = buf  # (re-inserted: most recently used last)
+    while len(_WORK) > _WORK_KEEP:
+        _WORK.pop(next(iter(_WORK)))
     return buf
 
 
