@@ -55,6 +55,33 @@ __device__ __forceinline__ void ring_ld(const char* p, float (&v)[D]) {
     for (int c = 0; c < D; ++c) v[c] = q[c];
   }
 }
+// The same for the OPERANDS of an entry (x_v, x_u), as volatile LDS loads: the consumer publishes "my
+// slots are free" with a volatile LDS store right after ISSUING these reads (release_to), and a wave's LDS
+// instructions execute in the order they are issued -- so the compiler must keep every one of them in front
+// of that store, which it owes only to volatile accesses.  (Round 4: at d = 3 the three-word read was
+// split and two words of x_u were issued BEHIND the store; a producer refilled the slot in between a few
+// times per 10^8 entries -- found by the full-size d = 3 test, not reproducible below ~10^7 entries.)
+template <int D>
+__device__ __forceinline__ void ring_ld_operand(char* lds_base, uint32_t addr, float (&v)[D]) {
+  typedef __attribute__((address_space(3))) const volatile float* lds_vf;
+  typedef float ring_f2v __attribute__((ext_vector_type(2)));
+  typedef float ring_f4v __attribute__((ext_vector_type(4)));
+  if constexpr (D == 2) {
+    const ring_f2v t = *(__attribute__((address_space(3))) const volatile ring_f2v*)(lds_base + addr);
+    v[0] = t.x;
+    v[1] = t.y;
+  } else if constexpr (D == 4) {
+    const ring_f4v t = *(__attribute__((address_space(3))) const volatile ring_f4v*)(lds_base + addr);
+    v[0] = t.x;
+    v[1] = t.y;
+    v[2] = t.z;
+    v[3] = t.w;
+  } else {
+    lds_vf q = (lds_vf)(lds_base + addr);
+#pragma unroll
+    for (int c = 0; c < D; ++c) v[c] = q[c];
+  }
+}
 template <int D>
 __device__ __forceinline__ void ring_st(char* p, const float (&v)[D]) {
   if constexpr (D == 3) {
@@ -341,8 +368,8 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         Pre r;
         // (codebook index: the bits the row address leaves free -- 3 at d = 2, 2 at d = 3)
         r.p0 = CB ? *reinterpret_cast<const float*>(L + CTRL_CB + ((w & (D == 2 ? 7u : 3u)) << 2)) : p0 * Fn::kParamScale;
-        ring_ld<D>(L + row_of(w), r.xr);
-        ring_ld<D>(L + col_of(w), r.xc);
+        ring_ld_operand<D>(L, row_of(w), r.xr);
+        ring_ld_operand<D>(L, col_of(w), r.xc);
         return r;
       };
       // this entry adds the loss term iff its row is the smaller vertex (blocks around the diagonal)

@@ -189,6 +189,47 @@ def test_config4b_pushpull_full_size_against_oracle():
     assert_grad_close(total[:n * d].view(n, d).cpu().numpy(), wgrad)
 
 
+def test_config4_d3_codebook_and_fp32_streams_full_size_against_oracle():
+    """50M edges through the two parameter streams of the LDS-ring kernel the headline test does not take:
+    d = 3 with PushAndPull weights {1, 2, -1} (the codebook in the two spare bits of the packed word at d = 3;
+    n = 250k, out-degree 200 -- at n = 1M and d = 3 a pair of wave iterations does not fit the chunk window
+    and the CSR kernel runs), and the config-4 graph at d = 2 with continuous weights (4 bytes per half-edge
+    next to the packed word, NaN / Inf fix-up in the kernel) -- both against the OpenMP oracle."""
+    import bench
+    import pymde_amd
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    dev = torch.device(DEV, 0)
+    pen = pymde_amd.penalties
+    # d = 3, three distinct weights
+    edges3, w3, X3 = bench.make_workload(dev, n=250000, deg=200, d=3)
+    n3, p3 = X3.shape[0], edges3.shape[0]
+    w3 = w3.clone()
+    w3[(2 * p3) // 3:] = -1.0
+    b3 = Binding(EdgePlan(n3, edges3), pen.PushAndPull(w3, pen.Log1p, pen.Log))
+    buf = torch.zeros(n3 * 3 + 1, device=dev)
+    fused_evaluate(b3, X3, buf[:n3 * 3].view(n3, 3), buf[n3 * 3:])
+    assert b3.struct(3).layout == 1 and b3.codebook
+    wE, wgrad = oracle.average_distortion(edges3.cpu().numpy(), X3.cpu().numpy(),
+                                          oracle.func("LOG1P", w3.cpu().numpy(), None, (1.5,), "LOG", (1.0,)))
+    assert float(buf[n3 * 3]) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(buf[:n3 * 3].view(n3, 3).cpu().numpy(), wgrad)
+    del b3, buf, edges3, w3, X3
+    # d = 2, continuous weights: no codebook
+    edges, w, X2 = bench.make_workload(dev)
+    n, p = X2.shape[0], edges.shape[0]
+    plan = EdgePlan(n, edges)
+    e_np = edges.cpu().numpy()
+    g = torch.Generator(device=dev).manual_seed(5)
+    wc = torch.rand(p, device=dev, generator=g) * 1.5 + 0.25
+    b2 = Binding(plan, pen.Log1p(wc))
+    buf = torch.zeros(n * 2 + 1, device=dev)
+    fused_evaluate(b2, X2, buf[:n * 2].view(n, 2), buf[n * 2:])
+    assert b2.struct(2).layout == 1 and not b2.codebook
+    wE, wgrad = oracle.average_distortion(e_np, X2.cpu().numpy(), oracle.func("LOG1P", wc.cpu().numpy(), None, (1.5,)))
+    assert float(buf[n * 2]) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(buf[:n * 2].view(n, 2).cpu().numpy(), wgrad)
+
+
 def test_config5_high_dim_standardized():
     """configs[4]: n = 500k, |E| = 20M, d = 128, Standardized (f32 MFMA Gram + projection).
     The gradient is checked against the oracle on an edge sub-sample; the full-size evaluation
