@@ -297,7 +297,10 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
               *reinterpret_cast<ring_f4*>(dst + i * 1024) = v;
             }
           }
-          // (the LDS executes a wave's accesses in order: whoever sees the new F sees the chunk)
+          // (the LDS executes a wave's accesses in order: whoever sees the new F sees the chunk -- provided
+          // the chunk's stores are ISSUED in front of the publish: float stores against an int store, which
+          // type-based alias analysis would let the compiler swap)
+          asm volatile("" ::: "memory");
           ring_ctrl_store_counted(L, CTRL_F + 4u * (uint32_t)p, j + NPROD);
           fetch(k, j + DEPTH * NPROD);
           slot += NPROD;
