@@ -99,6 +99,48 @@ def test_turn_desc_layout_matches_header(tmp_path):
     assert got[1:] == [getattr(_lib.MdeTurnDesc, f).offset for f in fields]
 
 
+def test_ring_kernel_issues_its_lds_accesses_in_protocol_order(tmp_path):
+    """The hand-shake of the LDS-ring kernel (csrc/mde_ring_kernel.h) relies on the ORDER in which a wave
+    issues its LDS instructions: a consumer's operand reads in front of the store that releases the ring
+    slots, a producer's chunk stores in front of the store that publishes the chunk.  The source forces
+    both (volatile operand reads, a compiler barrier); this reads the gfx950 ISA of the headline unit and
+    checks that the build did what the source says (round 4: at d = 3 it had not)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    out = tmp_path / "k.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                    "-ffp-contract=fast", "-DMDE_RING_MINIMAL", "-S", "--cuda-device-only",
+                    os.path.join(ROOT, "pymde_amd", "csrc", "mde_ring_k_log1p.hip"), "-o", str(out)],
+                   check=True, capture_output=True)
+    lines = out.read_text().split("\n")
+    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z12k_fused_ringILi2E", l)]
+    assert len(starts) >= 4
+    ends = starts[1:] + [len(lines)]
+    ctrl = (7872 + 32) * 8                       # ring_ctrl_off(2): prog[] at +0, F[] at +64, accumulators at +256
+    prog, pub, acc = ctrl, ctrl + 64, ctrl + 256
+    releases = publishes = 0
+    for s0, e0 in zip(starts, ends):
+        after_release = after_publish = False
+        for l in lines[s0:e0]:
+            t = l.split(";")[0].strip()
+            if re.match(r"^\.LBB\d+_\d+:", t) or t.startswith("s_cbranch") or t.startswith("s_branch"):
+                after_release = after_publish = False   # (a basic block ends: the next one starts clean)
+                continue
+            if t.startswith("ds_write_b32") and ("offset:%d" % prog) in t:
+                after_release, releases = True, releases + 1
+            elif t.startswith("ds_write_b32") and ("offset:%d" % pub) in t:
+                after_publish, publishes = True, publishes + 1
+            elif t.startswith("ds_write_b128"):
+                assert not after_publish, "a chunk store behind the producer's publish: " + t
+            elif t.startswith("ds_read_b64") and after_release:
+                # behind a release only the accumulator of the next entry may be read (offset = accumulator base)
+                assert ("offset:%d" % acc) in t, "an operand read behind the consumer's release: " + t
+    assert releases >= 20 and publishes >= 8
+
+
 # ---------------------------------------------------------------- no GPU -> loud failure
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_no_gpu_fails_loudly():
