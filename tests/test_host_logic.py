@@ -116,29 +116,42 @@ def test_ring_kernel_issues_its_lds_accesses_in_protocol_order(tmp_path):
                     os.path.join(ROOT, "pymde_amd", "csrc", "mde_ring_k_log1p.hip"), "-o", str(out)],
                    check=True, capture_output=True)
     lines = out.read_text().split("\n")
-    starts = [i for i, l in enumerate(lines) if re.match(r"^_Z12k_fused_ringILi2E", l)]
-    assert len(starts) >= 4
-    ends = starts[1:] + [len(lines)]
-    ctrl = (7872 + 32) * 8                       # ring_ctrl_off(2): prog[] at +0, F[] at +64, accumulators at +256
-    prog, pub, acc = ctrl, ctrl + 64, ctrl + 256
-    releases = publishes = 0
-    for s0, e0 in zip(starts, ends):
-        after_release = after_publish = False
-        for l in lines[s0:e0]:
-            t = l.split(";")[0].strip()
-            if re.match(r"^\.LBB\d+_\d+:", t) or t.startswith("s_cbranch") or t.startswith("s_branch"):
-                after_release = after_publish = False   # (a basic block ends: the next one starts clean)
+    all_starts = [i for i, l in enumerate(lines) if re.match(r"^_Z12k_fused_ringILi\dE", l)]
+    all_ends = all_starts[1:] + [len(lines)]
+    # ring_ctrl_off(d) = (row cap + 32) * 4 d: prog[] at +0, F[] at +64, accumulators from +256
+    for dim, ctrl in ((2, (7872 + 32) * 8), (3, (5216 + 32) * 12)):
+        prog, pub, acc = ctrl, ctrl + 64, ctrl + 256
+        releases = publishes = kernels = 0
+        for s0, e0 in zip(all_starts, all_ends):
+            if not lines[s0].startswith("_Z12k_fused_ringILi%dE" % dim):
                 continue
-            if t.startswith("ds_write_b32") and ("offset:%d" % prog) in t:
-                after_release, releases = True, releases + 1
-            elif t.startswith("ds_write_b32") and ("offset:%d" % pub) in t:
-                after_publish, publishes = True, publishes + 1
-            elif t.startswith("ds_write_b128"):
-                assert not after_publish, "a chunk store behind the producer's publish: " + t
-            elif t.startswith("ds_read_b64") and after_release:
-                # behind a release only the accumulator of the next entry may be read (offset = accumulator base)
-                assert ("offset:%d" % acc) in t, "an operand read behind the consumer's release: " + t
-    assert releases >= 20 and publishes >= 8
+            kernels += 1
+            after_release = after_publish = False
+            words = 0
+            for l in lines[s0:e0]:
+                t = l.split(";")[0].strip()
+                if re.match(r"^\.LBB\d+_\d+:", t) or t.startswith("s_cbranch") or t.startswith("s_branch"):
+                    after_release = after_publish = False   # (a basic block ends: the next one starts clean)
+                    continue
+                if t.startswith("ds_write_b32") and ("offset:%d" % prog) in t:
+                    after_release, releases, words = True, releases + 1, 0
+                elif t.startswith("ds_write_b32") and ("offset:%d" % pub) in t:
+                    after_publish, publishes = True, publishes + 1
+                elif t.startswith("ds_write_b128"):
+                    assert not after_publish, "d = %d: a chunk store behind the producer's publish: %s" % (dim, t)
+                elif after_release and t.startswith("ds_read"):
+                    # behind a release the block may still read the accumulators of two entries (the pair's second
+                    # and the next pair's first: 2 x d words) -- never an operand.  Operand and accumulator reads
+                    # cannot be told apart by their address registers, so the WORDS read are counted (codebook
+                    # and control words, whose immediate offset lies between prog[] and the accumulators, apart):
+                    # the d = 3 kernel of round 4 read 10 where 6 are allowed.
+                    offs = [int(v) for v in re.findall(r"offset:(\d+)", t)]
+                    if offs and ctrl <= offs[0] < acc:
+                        continue
+                    words += {"ds_read_b32": 1, "ds_read2_b32": 2, "ds_read_b64": 2, "ds_read2_b64": 4,
+                              "ds_read_b128": 4}[t.split()[0]]
+                    assert words <= 2 * dim, "d = %d: an operand read behind the consumer's release: %s" % (dim, t)
+        assert kernels >= 4 and releases >= 20 and publishes >= 8, (dim, kernels, releases, publishes)
 
 
 # ---------------------------------------------------------------- no GPU -> loud failure
