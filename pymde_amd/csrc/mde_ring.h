@@ -34,7 +34,7 @@ __host__ __device__ constexpr int ring_gr_off(int d) { return ring_ctrl_off(d) +
 #define MDE_RING_PSLEEP 1          // s_sleep argument of a producer waiting for a slot
 #endif
 #ifndef MDE_RING_PRODPRIO
-#define MDE_RING_PRODPRIO 0        // (round 3's LDS-DMA producers ran at priority 3; the VGPR-staged ones take issue slots from the consumers: 0.208 -> 0.192 ms at 0)
+#define MDE_RING_PRODPRIO 2        // (round 4: 0.208 ms at priority 3 against 0.192 at 0 -- a producer poll was a dozen VALU instructions then and took the consumers' issue slots.  Round 5, with the one-word hand-shake: how fast a producer REACTS to a released slot is on the critical path -- 0.195 / 0.184 / 0.181 / 0.183 ms at priority 0 / 1 / 2 / 3, and 0.216 when a blocked producer sleeps 12 x 64 clocks instead of 1)
 #endif
 #ifndef MDE_RING_CONSPRIO
 #define MDE_RING_CONSPRIO 0

@@ -45,47 +45,139 @@
 #include "mde_ring.h"
 
 // ---------------------------------------------------------------- layout construction
-// bounds[rb * (NCW + 1) + w]: consumer wave w of row block rb owns local rows [bounds[w],
-// bounds[w + 1]) -- cut so that every wave gets the same number of half-edges
-__global__ __launch_bounds__(MDE_BLOCK) void k_ring_bounds(int nloc, int R, int NRB, const int32_t* __restrict__ rowptr,
-                                                           int32_t* __restrict__ bounds) {
-  const int i = blockIdx.x * MDE_BLOCK + threadIdx.x;
-  if (i >= NRB * (MDE_RING_NCW + 1)) return;
-  const int rb = i / (MDE_RING_NCW + 1), w = i % (MDE_RING_NCW + 1);
-  const int r0 = rb * R, r1 = min(nloc, r0 + R);
-  const int64_t lo = rowptr[r0], hi = rowptr[r1];
-  const int64_t target = lo + ((hi - lo) * w) / MDE_RING_NCW;
-  int a = r0, b = r1;  // smallest r in [r0, r1] with rowptr[r] >= target
-  while (a < b) {
-    const int mid = (a + b) >> 1;
-    if (rowptr[mid] >= target) b = mid; else a = mid + 1;
+// Row -> consumer wave map of a workgroup (row block rb, column group g).  A row has ONE wave (nobody else
+// touches its accumulator), but WHICH wave is free: the packed words carry absolute LDS addresses, so a
+// wave's ownership of a row exists only as "which stream its entries are in".  Rounds 2-4 cut the block into 8
+// contiguous row ranges of equal half-edge count.  On a random graph the entries a range finds in a chunk are
+// Poisson, the ranges' positions along the column sweep drift apart like random walks (at equal iteration
+// index the 8 waves of a config-4 workgroup are spread over 5 chunks on average, 8 at the 90th percentile),
+// and a ring slot is free only when ALL consumers are past it: with 9 slots and a 5-chunk pair window the
+// fast waves wait for the slow ones most of the time (a third of the consumer loop was polling).
+// Here the rows are dealt to the waves one by one, greedily: the column sweep of the group is cut into
+// MDE_RING_BUCKETS buckets, P_w[b] is the number of entries wave w holds in buckets <= b, and a row with
+// prefix counts c[b] goes to the wave that minimises sum_b (P_w[b] - mean_w P[b]) c[b] -- the steepest descent
+// of sum_w sum_b (P_w[b] - mean)^2.  Every wave then reaches every bucket boundary with (almost) the same
+// number of entries behind it: spread 1.9 chunks on average, 3 at the 90th percentile (simulation and
+// MDE_RING_STATS), which the ring's slack of 4 covers.  One wave per workgroup, rows in order.
+// wmap[(rb * Q + g) * R + local row] = wave | rank of the row inside its wave << 8; wrows[stream] = rows.
+#ifndef MDE_RING_BUCKETS
+#define MDE_RING_BUCKETS 32
+#endif
+__global__ __launch_bounds__(64) void k_ring_assign(int nloc, int R, int Q, int NC, int C, int contiguous,
+                                                    const int32_t* __restrict__ rowptr,
+                                                    const int32_t* __restrict__ nbr, uint32_t* __restrict__ wmap,
+                                                    int32_t* __restrict__ wrows) {
+  constexpr int B = MDE_RING_BUCKETS, NCWP = MDE_RING_NCW <= 8 ? 8 : 16, LPW = 64 / NCWP, BPL = B / LPW;
+  static_assert(MDE_RING_NCW <= 16 && B % LPW == 0 && B <= 64, "lane map of k_ring_assign");
+  __shared__ int hist[B];
+  __shared__ float cpre[B];
+  const int wg = blockIdx.x, rb = wg / Q, g = wg % Q, lane = threadIdx.x;
+  const int j_lo = (int)(((int64_t)g * NC + Q - 1) / Q), j_hi = (int)(((int64_t)(g + 1) * NC + Q - 1) / Q);
+  const int nj = max(1, j_hi - j_lo);
+  const int r0 = rb * R, nr = min(R, nloc - r0);
+  const int w = lane / LPW, bg = lane % LPW;
+  uint32_t* out = wmap + (size_t)wg * R;
+  if (contiguous) {
+    // (MDE_RING_ASSIGN=0, design comparison: the contiguous ranges of equal half-edge count of rounds 2-4)
+    const int64_t lo = rowptr[r0], hi = rowptr[r0 + nr];
+    int bd[MDE_RING_NCW + 1];
+    for (int t = 0; t <= MDE_RING_NCW; ++t) {
+      const int64_t target = lo + ((hi - lo) * t) / MDE_RING_NCW;
+      int a = r0, b = r0 + nr;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (rowptr[mid] >= target) b = mid; else a = mid + 1;
+      }
+      bd[t] = (t == MDE_RING_NCW) ? r0 + nr : a;
+    }
+    for (int r = lane; r < nr; r += 64) {
+      int ww = 0;
+      for (int t = 1; t < MDE_RING_NCW; ++t) ww += (bd[t] <= r0 + r);
+      out[r] = (uint32_t)ww | ((uint32_t)(r0 + r - bd[ww]) << 8);
+    }
+    if (lane < MDE_RING_NCW) wrows[wg * MDE_RING_NCW + lane] = bd[lane + 1] - bd[lane];
+    return;
   }
-  bounds[i] = (w == MDE_RING_NCW) ? r1 : a;
+  float P[BPL], T[BPL];
+#pragma unroll
+  for (int k = 0; k < BPL; ++k) P[k] = T[k] = 0.0f;
+  int myrows = 0;
+  for (int r = 0; r < nr; ++r) {
+    const int beg = rowptr[r0 + r], end = rowptr[r0 + r + 1];
+    if (lane < B) hist[lane] = 0;
+    __syncthreads();
+    for (int q = beg + lane; q < end; q += 64) {
+      const int j = nbr[q] / C;
+      if (j >= j_lo && j < j_hi) atomicAdd(&hist[(int)(((int64_t)(j - j_lo) * B) / nj)], 1);
+    }
+    __syncthreads();
+    int h = lane < B ? hist[lane] : 0;
+#pragma unroll
+    for (int o = 1; o < B; o <<= 1) {
+      const int t = __shfl_up(h, o, 64);
+      if (lane >= o) h += t;
+    }
+    if (lane < B) cpre[lane] = (float)h;
+    __syncthreads();
+    float c[BPL], cost = 0.0f;
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+      c[k] = cpre[bg * BPL + k];
+      cost = fmaf(P[k] - T[k] * (1.0f / MDE_RING_NCW), c[k], cost);
+    }
+#pragma unroll
+    for (int o = 1; o < LPW; o <<= 1) cost += __shfl_xor(cost, o, 64);
+    // the best wave: lowest cost, then fewest rows (rows without entries in this group are dealt evenly), then lowest id
+    float bc = w < MDE_RING_NCW ? cost : 3.0e38f;
+    int bn = myrows, bw = w;
+#pragma unroll
+    for (int o = LPW; o < 64; o <<= 1) {
+      const float oc = __shfl_xor(bc, o, 64);
+      const int on = __shfl_xor(bn, o, 64), ow = __shfl_xor(bw, o, 64);
+      const bool take = oc < bc || (oc == bc && (on < bn || (on == bn && ow < bw)));
+      bc = take ? oc : bc;
+      bn = take ? on : bn;
+      bw = take ? ow : bw;
+    }
+    if (lane == 0) out[r] = (uint32_t)bw | ((uint32_t)bn << 8);
+#pragma unroll
+    for (int k = 0; k < BPL; ++k) {
+      T[k] += c[k];
+      if (w == bw) P[k] += c[k];
+    }
+    myrows += (w == bw);
+  }
+  if (bg == 0 && w < MDE_RING_NCW) wrows[wg * MDE_RING_NCW + w] = myrows;
 }
 
 // key = ((rb * Q + column group) * NCW + wave) << JB | chunk; CSR order (row, edge id) is kept
 // inside equal keys by the stable sort
 __global__ __launch_bounds__(MDE_BLOCK) void k_ring_keys(int nrows, const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ nbr,
-                                                         const int32_t* __restrict__ bounds, int R, int Q,
+                                                         const uint32_t* __restrict__ wmap, int R, int Q,
                                                          int NC, int C, int JB, uint32_t* __restrict__ keys,
                                                          uint32_t* __restrict__ vals, int32_t* __restrict__ hrow) {
-  constexpr int G = 16;
+  constexpr int G = 16;  // (>= the largest Q: lane t of a group holds the row's wave in column group t)
   const int lig = threadIdx.x & (G - 1);
   const int group = (blockIdx.x * MDE_BLOCK + threadIdx.x) / G;
   const int ngroups = (gridDim.x * MDE_BLOCK) / G;
-  for (int r = group; r < nrows; r += ngroups) {
-    const int beg = rowptr[r], end = rowptr[r + 1];
-    const int rb = r / R;
-    const int32_t* bd = bounds + (size_t)rb * (MDE_RING_NCW + 1);
-    int w = 0;
-    for (int t = 1; t < MDE_RING_NCW; ++t) w += (bd[t] <= r);
-    for (int q = beg + lig; q < end; q += G) {
-      const uint32_t j = (uint32_t)(nbr[q] / C);
+  const int rmax = ((nrows + ngroups - 1) / ngroups) * ngroups;  // (every group runs the same trips: shuffles below)
+  for (int r = group; r < rmax; r += ngroups) {
+    const bool has = r < nrows;
+    const int beg = has ? rowptr[r] : 0, end = has ? rowptr[r + 1] : 0;
+    const int rb = has ? r / R : 0;
+    const uint32_t wv = (has && lig < Q) ? (wmap[((size_t)rb * Q + lig) * R + (r - rb * R)] & 0xffu) : 0u;
+    for (int q0 = beg; q0 < end; q0 += G) {
+      const int q = q0 + lig;
+      const bool in = q < end;
+      const uint32_t j = in ? (uint32_t)(nbr[q] / C) : 0u;
       const uint32_t g = (uint32_t)(((uint64_t)j * (uint64_t)Q) / (uint64_t)NC);
-      keys[q] = ((((uint32_t)rb * (uint32_t)Q + g) * MDE_RING_NCW + (uint32_t)w) << JB) | j;
-      vals[q] = (uint32_t)q;
-      hrow[q] = r;
+      const uint32_t w = (uint32_t)__shfl((int)wv, (int)g, G);
+      if (in) {
+        keys[q] = ((((uint32_t)rb * (uint32_t)Q + g) * MDE_RING_NCW + w) << JB) | j;
+        vals[q] = (uint32_t)q;
+        hrow[q] = r;
+      }
     }
   }
 }
@@ -148,29 +240,30 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_seg(int64_t H, uint32_t nseg
 #endif
 __host__ __device__ constexpr int ring_cls_shift(int d) { return d == 2 ? 3 : (d == 4 ? 4 : 2); }
 __host__ __device__ constexpr int ring_cls_mask(int d) { return d == 4 ? 15 : 31; }
-// meta[pos] for every sorted position: local row (bits 15:0) | row bank class (23:16) | column bank
+// meta[pos] for every sorted position: rank of the row inside its wave (bits 15:0) | row bank class (23:16) | column bank
 // class (31:24) -- everything the scheduler needs of an entry besides its chunk (keys[pos] & JM), in
 // stream order: the scheduler's loads are contiguous (round 3 chased pos -> vals -> hrow / nbr, three
 // dependent random loads per candidate: 2 x 43 ms at config 4)
 __global__ __launch_bounds__(MDE_BLOCK) void k_ring_meta(int64_t H, const uint32_t* __restrict__ keys,
                                                          const uint32_t* __restrict__ vals,
                                                          const int32_t* __restrict__ hrow,
-                                                         const int32_t* __restrict__ nbr, int JB, int R, int Q, int d,
+                                                         const int32_t* __restrict__ nbr,
+                                                         const uint32_t* __restrict__ wmap, int JB, int R, int Q, int d,
                                                          uint32_t* __restrict__ meta) {
   const int sh = ring_cls_shift(d), cm = ring_cls_mask(d), rowbytes = 4 * d;
   for (int64_t pos = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; pos < H; pos += (int64_t)gridDim.x * MDE_BLOCK) {
     const uint32_t q = vals[pos];
-    const int rb = (int)((keys[pos] >> JB) / MDE_RING_NCW) / Q;
+    const int wg = (int)((keys[pos] >> JB) / MDE_RING_NCW), rb = wg / Q;
     const uint32_t row = (uint32_t)(hrow[q] - rb * R);
     const uint32_t rc = ((row * (uint32_t)rowbytes) >> sh) & (uint32_t)cm;
     const uint32_t cc = (((uint32_t)nbr[q] * (uint32_t)rowbytes) >> sh) & (uint32_t)cm;  // (chunks start on class 0)
-    meta[pos] = row | (rc << 16) | (cc << 24);
+    meta[pos] = (wmap[(size_t)wg * R + row] >> 8) | (rc << 16) | (cc << 24);
   }
 }
 
 template <bool FILL>
 __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* __restrict__ seg,
-                                                      const int32_t* __restrict__ bounds,
+                                                      const int32_t* __restrict__ wrows,
                                                       const uint32_t* __restrict__ keys,
                                                       const uint32_t* __restrict__ meta, uint32_t JM, int SPAN,
                                                       int R, int Q, int NC, int d, int cap, int bail_factor,
@@ -191,15 +284,13 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
   for (int r = lane; r < flag_rows; r += 64) flag[r] = 0x7fffffff;
   __syncthreads();
   const int beg = seg[i], end = seg[i + 1];
-  const int rb = (i / MDE_RING_NCW) / Q;
-  const int row_base = bounds[rb * (MDE_RING_NCW + 1) + i % MDE_RING_NCW] - rb * R;  // first local row of this wave
+  constexpr int row_base = 0;  // (the meta words carry the rank of a row inside its wave)
   const int first = FILL ? iter_base[i] : 0;
   int out = first, next = beg, nc = 0, cur = 0;
   // counting pass, auto mode: a stream that needs several times the iterations its entries would fill
   // (a hub row: one entry per iteration) makes the caller give the layout up -- stop counting there
   // (an iteration holds at most one entry per row of the wave: a short tail block is not a hub)
-  const int w_ = i % MDE_RING_NCW;
-  const int nrows_w = max(1, bounds[rb * (MDE_RING_NCW + 1) + w_ + 1] - bounds[rb * (MDE_RING_NCW + 1) + w_]);
+  const int nrows_w = max(1, wrows[i]);
   const int per_it = nrows_w < 64 ? nrows_w : 64;
   // (a sparse stream -- the short last row block -- needs its iterations for the chunk windows it has to
   // walk, a pair of iterations per SPAN + 1 chunks: that is not a hub either)
@@ -322,7 +413,7 @@ __global__ __launch_bounds__(64) void k_ring_schedule(int nseg, const int32_t* _
 // caps[i] = iterations reserved for stream i by the single-pass build: `factor` times what its entries
 // (or its chunk windows) need at least, a multiple of 4
 __global__ __launch_bounds__(MDE_BLOCK) void k_ring_caps(int nseg, const int32_t* __restrict__ seg,
-                                                         const int32_t* __restrict__ bounds, int R, int Q, int NC, int SPAN,
+                                                         const int32_t* __restrict__ wrows, int R, int Q, int NC, int SPAN,
                                                          int factor, int32_t* __restrict__ caps) {
   const int i = blockIdx.x * MDE_BLOCK + threadIdx.x;
   if (i > nseg) return;
@@ -330,8 +421,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_caps(int nseg, const int32_t
     caps[i] = 0;
     return;
   }
-  const int rb = (i / MDE_RING_NCW) / Q, w = i % MDE_RING_NCW;
-  const int nrows_w = max(1, bounds[rb * (MDE_RING_NCW + 1) + w + 1] - bounds[rb * (MDE_RING_NCW + 1) + w]);
+  const int nrows_w = max(1, wrows[i]);
   const int per_it = nrows_w < 64 ? nrows_w : 64;
   const int walk = 2 * ((NC / Q + SPAN + 1) / (SPAN + 1));
   const int need = max((seg[i + 1] - seg[i] + per_it - 1) / per_it, walk);
@@ -617,14 +707,14 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   const int64_t H = plan->H;
   const int nseg = z.NRB * z.Q * MDE_RING_NCW;
   const uint32_t JM = (1u << z.JB) - 1u;
-  uint32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr, *packed = nullptr, *hdr = nullptr;
-  int32_t *hrow = nullptr, *bounds = nullptr, *seg = nullptr, *iters = nullptr, *iter_base = nullptr;
+  uint32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr, *packed = nullptr, *hdr = nullptr, *wmap = nullptr;
+  int32_t *hrow = nullptr, *wrows = nullptr, *seg = nullptr, *iters = nullptr, *iter_base = nullptr;
   int32_t *it_ent = nullptr, *it_cnt = nullptr, *it_m = nullptr, *peid = nullptr;
   float* partial = nullptr;
   void* tmp = nullptr;
   hipError_t e = hipSuccess;
   auto release = [&](bool all) {
-    void* scratch[] = {keys, vals, keys2, vals2, hrow, bounds, seg, iters, it_ent, it_cnt, it_m, tmp};
+    void* scratch[] = {keys, vals, keys2, vals2, hrow, wrows, wmap, seg, iters, it_ent, it_cnt, it_m, tmp};
     for (void* p : scratch)
       if (p) (void)hipFree(p);
     if (all) {
@@ -658,18 +748,23 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   RB(hipMalloc(&keys2, hb));
   RB(hipMalloc(&vals2, hb));
   RB(hipMalloc(&hrow, hb));
-  RB(hipMalloc(&bounds, (size_t)z.NRB * (MDE_RING_NCW + 1) * sizeof(int32_t)));
+  RB(hipMalloc(&wrows, ((size_t)nseg + 1) * sizeof(int32_t)));
+  RB(hipMalloc(&wmap, (size_t)z.NRB * z.Q * z.R * sizeof(uint32_t)));
   RB(hipMalloc(&seg, ((size_t)nseg + 1) * sizeof(int32_t)));
   RB(hipMalloc(&iters, ((size_t)nseg + 1) * sizeof(int32_t)));
   RB(hipMalloc(&iter_base, ((size_t)nseg + 1) * sizeof(int32_t)));
   tick("scratch allocations");
-  hipLaunchKernelGGL(k_ring_bounds, dim3((z.NRB * (MDE_RING_NCW + 1) + MDE_BLOCK - 1) / MDE_BLOCK), dim3(MDE_BLOCK), 0,
-                     st, (int)nloc, z.R, z.NRB, plan->rowptr, bounds);
+  // MDE_RING_ASSIGN=1: the greedy, sweep-balanced row -> wave map (14.6 ms at config 4, no faster: see k_ring_assign);
+  // default: contiguous row ranges of equal half-edge count
+  const int contiguous = getenv("MDE_RING_ASSIGN") ? atoi(getenv("MDE_RING_ASSIGN")) == 0 : 1;
+  hipLaunchKernelGGL(k_ring_assign, dim3(z.NRB * z.Q), dim3(64), 0, st, (int)nloc, z.R, z.Q, z.NC, z.C, contiguous, plan->rowptr,
+                     plan->nbr, wmap, wrows);
   RB(hipGetLastError());
+  tick("row -> wave assignment");
   hipLaunchKernelGGL(k_ring_keys, dim3(mde_grid(nloc * 16, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, (int)nloc,
-                     plan->rowptr, plan->nbr, bounds, z.R, z.Q, z.NC, z.C, z.JB, keys, vals, hrow);
+                     plan->rowptr, plan->nbr, wmap, z.R, z.Q, z.NC, z.C, z.JB, keys, vals, hrow);
   RB(hipGetLastError());
-  tick("bounds + keys kernels");
+  tick("keys kernel");
   size_t tmp_bytes = 0, scan_bytes = 0;
   const int end_bit = std::min(32, bits_for_u64((uint64_t)nseg) + z.JB);
   RB(mde_sort_pairs_u32(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)H, 0, end_bit, st));
@@ -715,17 +810,15 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   // (keys is free from here on: it holds the scheduler's meta words)
   uint32_t* meta = keys;
   hipLaunchKernelGGL(k_ring_meta, dim3(mde_grid(H, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st, H, keys2, vals2, hrow, plan->nbr,
-                     z.JB, z.R, z.Q, d, meta);
+                     wmap, z.JB, z.R, z.Q, d, meta);
   RB(hipGetLastError());
   // rows of the largest wave range (the scheduler keeps one LDS word per row of its wave)
   int flag_rows = 64;
   {
-    std::vector<int32_t> hbd((size_t)z.NRB * (MDE_RING_NCW + 1));
-    RB(hipMemcpyAsync(hbd.data(), bounds, hbd.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    std::vector<int32_t> hwr((size_t)nseg);
+    RB(hipMemcpyAsync(hwr.data(), wrows, hwr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     RB(hipStreamSynchronize(st));
-    for (int b = 0; b < z.NRB; ++b)
-      for (int w = 0; w < MDE_RING_NCW; ++w)
-        flag_rows = std::max(flag_rows, hbd[(size_t)b * (MDE_RING_NCW + 1) + w + 1] - hbd[(size_t)b * (MDE_RING_NCW + 1) + w]);
+    for (int i = 0; i < nseg; ++i) flag_rows = std::max(flag_rows, hwr[(size_t)i]);
     flag_rows = (flag_rows + 63) / 64 * 64;
   }
   const size_t flag_bytes = (size_t)flag_rows * sizeof(int);
@@ -744,7 +837,7 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   int32_t total_iters = 0, total_cap = 0;
   // (regions of 2 x the minimum: the scratch they take is what the build's time goes into -- fresh device
   // memory costs ~10 ms per GB to map on first use, more than the kernels that fill it)
-  hipLaunchKernelGGL(k_ring_caps, dim3((nseg + 1 + MDE_BLOCK - 1) / MDE_BLOCK), dim3(MDE_BLOCK), 0, st, nseg, seg, bounds, z.R, z.Q,
+  hipLaunchKernelGGL(k_ring_caps, dim3((nseg + 1 + MDE_BLOCK - 1) / MDE_BLOCK), dim3(MDE_BLOCK), 0, st, nseg, seg, wrows, z.R, z.Q,
                      z.NC, span, 2, caps);
   e = hipGetLastError();
   if (e == hipSuccess) e = mde_exclusive_sum_i32(tmp, tmp_bytes, caps, cap_base, nseg + 1, st);
@@ -769,7 +862,7 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     }
   }
   if (single) {
-    hipLaunchKernelGGL(k_ring_schedule<true>, dim3(nseg), dim3(64), flag_bytes, st, nseg, seg, bounds, keys2, meta, JM, span, z.R,
+    hipLaunchKernelGGL(k_ring_schedule<true>, dim3(nseg), dim3(64), flag_bytes, st, nseg, seg, wrows, keys2, meta, JM, span, z.R,
                        z.Q, z.NC, d, cap, 4, iters, cap_base, it_ent, it_cnt, it_m, flag_rows, caps);
     e = hipGetLastError();
     if (e == hipSuccess) e = mde_exclusive_sum_i32(tmp, tmp_bytes, iters, iter_base, nseg + 1, st);
@@ -791,7 +884,7 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     }
   }
   if (!single) {
-    hipLaunchKernelGGL(k_ring_schedule<false>, dim3(nseg), dim3(64), flag_bytes, st, nseg, seg, bounds, keys2, meta, JM, span,
+    hipLaunchKernelGGL(k_ring_schedule<false>, dim3(nseg), dim3(64), flag_bytes, st, nseg, seg, wrows, keys2, meta, JM, span,
                        z.R, z.Q, z.NC, d, cap, panel_mode() == 1 ? 0 : 4, iters, nullptr, nullptr, nullptr, nullptr, flag_rows,
                        nullptr);
     e = hipGetLastError();
@@ -825,14 +918,17 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   if (e == hipSuccess) e = hipMalloc(&packed, (size_t)Hp * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc(&peid, (size_t)Hp * sizeof(int32_t));
   if (e == hipSuccess) e = hipMalloc(&hdr, (size_t)total_iters * MDE_RING_HW * sizeof(uint32_t));
-  if (e == hipSuccess && z.Q > 1) e = hipMalloc(&partial, sizeof(float) * (size_t)z.Q * (size_t)nloc * (size_t)d);
+  // (+ two words per row block behind the rows: ticket and flag of the in-launch sum of Q = 2 groups, zero between launches)
+  const size_t partial_floats = (size_t)z.Q * (size_t)nloc * (size_t)d;
+  if (e == hipSuccess && z.Q > 1) e = hipMalloc(&partial, sizeof(float) * (partial_floats + 2 * (size_t)z.NRB));
+  if (e == hipSuccess && z.Q > 1) e = hipMemsetAsync(partial + partial_floats, 0, sizeof(float) * 2 * (size_t)z.NRB, st);
   if (e != hipSuccess) {
     drop_caps();
     return fail(e, "ring layout: output allocations");
   }
   tick("output allocations");
   if (!single) {
-    hipLaunchKernelGGL(k_ring_schedule<true>, dim3(nseg), dim3(64), flag_bytes, st, nseg, seg, bounds, keys2, meta, JM, span, z.R,
+    hipLaunchKernelGGL(k_ring_schedule<true>, dim3(nseg), dim3(64), flag_bytes, st, nseg, seg, wrows, keys2, meta, JM, span, z.R,
                        z.Q, z.NC, d, cap, 0, nullptr, iter_base, it_ent, it_cnt, it_m, flag_rows, nullptr);
     e = hipGetLastError();
   }
@@ -886,6 +982,36 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
         worst = std::max(worst, gap);
       }
       fprintf(stderr, "[mde ring] hand-shake contract: %lld of %d pairs exceed the window (worst gap %d chunks)\n", bad, total_iters / 2, worst);
+      // how far apart are the consumer waves of a workgroup along the column sweep?  At the same fraction of
+      // their streams: newest minus oldest chunk over the waves (a ring slot is free when ALL of them are past it)
+      {
+        std::vector<int32_t> hb2((size_t)nseg + 1);
+        RB(hipMemcpy(hb2.data(), iter_base, hb2.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        std::vector<int> sp;
+        for (int g0 = 0; g0 + MDE_RING_NCW <= nseg; g0 += MDE_RING_NCW) {
+          int len = 1 << 30;
+          for (int w = 0; w < MDE_RING_NCW; ++w) len = std::min(len, hb2[g0 + w + 1] - hb2[g0 + w]);
+          if (len < 16) continue;
+          for (int k = 0; k < len; k += 2) {
+            int lo = 1 << 30, hi2 = 0;
+            for (int w = 0; w < MDE_RING_NCW; ++w) {
+              const int nit_w = hb2[g0 + w + 1] - hb2[g0 + w];
+              const int64_t it = hb2[g0 + w] + (((int64_t)k * nit_w / len) & ~(int64_t)1);
+              const int m = (int)hh[it * MDE_RING_HW];
+              lo = std::min(lo, m);
+              hi2 = std::max(hi2, m);
+            }
+            sp.push_back(hi2 - lo);
+          }
+        }
+        if (!sp.empty()) {
+          std::sort(sp.begin(), sp.end());
+          double mean = 0;
+          for (int v : sp) mean += v;
+          fprintf(stderr, "[mde ring] spread of a workgroup's consumer waves along the column sweep (chunks): mean %.2f median %d p90 %d max %d\n",
+                  mean / sp.size(), sp[sp.size() / 2], sp[sp.size() * 9 / 10], sp.back());
+        }
+      }
     }
     fprintf(stderr, "[mde ring] d=%d R=%d NRB=%d Q=%d chunks=%d x %d cols, window %d, cap %d, placement %d: %d iterations for %lld half-edges "
             "(%.1f%% padding), %.1f%% with padding lanes; loss terms: %.1f%% of the iterations add all, %.2f%% test per lane\n",

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ packed, const float* __restrict__ a0,
     const float* __restrict__ a1, int a0_scalar, int a1_scalar, const float* __restrict__ X,
     float* __restrict__ grad, float* __restrict__ partial, double* __restrict__ loss_partials, Fn fn,
-    float fix_value, float grad_scale, float* __restrict__ loss_out, double loss_scale, int dbg_arg) {
+    float fix_value, float grad_scale, float* __restrict__ loss_out, double loss_scale, int fold, int dbg_arg) {
 #if MDE_RING_ABLATE
 #ifndef MDE_RING_ABLATE_MASK
 #define MDE_RING_ABLATE_MASK (~0)  // (a narrower mask lets hipcc fold the other probes away)
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     int* prog = reinterpret_cast<int*>(L + CTRL_PROG);
     int* F = reinterpret_cast<int*>(L + CTRL_F);
     if (tid < 16) prog[tid] = (tid < NCW) ? j_lo : MDE_RING_DONE;
-    if (tid >= 16 && tid < 16 + NPROD) F[tid - 16] = j_lo + (tid - 16);
+    if (tid == 16) F[0] = j_lo;  // LANDED: every chunk below this is in its ring slot
     if (CB && tid >= 32 && tid < 32 + MDE_RING_CB_VALUES)
       reinterpret_cast<float*>(L + CTRL_CB)[tid - 32] = a0[tid - 32] * Fn::kParamScale;
   }
@@ -234,9 +234,10 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         }
       }
     };
-    int minprog = j_lo;
+    int minprog = j_lo, landed = j_lo;
+    const uint32_t poll_addr = lane < 16 ? CTRL_PROG + 4u * (uint32_t)lane : (uint32_t)CTRL_F;
 #if MDE_RING_ABLATE
-    unsigned long long pr_t0 = RING_CLK(), pr_blocked = 0, pr_polls = 0;
+    unsigned long long pr_t0 = RING_CLK(), pr_blocked = 0, pr_polls = 0, pr_chain = 0, pr_data = 0, pr_write = 0;
 #endif
 #pragma unroll
     for (int k = 0; k < DEPTH; ++k) fetch(k, j_lo + p + k * NPROD);
@@ -252,12 +253,19 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
             const unsigned long long tb0 = RING_CLK();
             ++pr_polls;
 #endif
-            // one LDS read (lane w = consumer w), then a scalar minimum over the consumers' lanes
-            const int v = ring_ctrl_load(CTRL_PROG + 4u * (uint32_t)(lane & 15));
-            int mn = __builtin_amdgcn_readlane(v, 0);
-#pragma unroll
-            for (int w = 1; w < NCW; ++w) mn = min(mn, __builtin_amdgcn_readlane(v, w));
-            minprog = mn;
+            // one LDS read (lane & 15 = consumer, the words past NCW hold DONE), the minimum over each row of
+            // 16 lanes with DPP shifts (3-4 VALU instead of one v_readlane + s_min per consumer), one v_readlane
+            // (lanes 16.. read LANDED with the same instruction: the publish below finds it without a poll of its own)
+            int v = ring_ctrl_load(poll_addr);
+            // (v_min_i32_dpp: lanes without a source in their row keep their value; two wait states between a VALU
+            // write and a DPP read of the same register)
+            asm volatile("s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1"
+                         : "+v"(v));
+            if (NCW > 8) asm volatile("v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(v));
+            minprog = __builtin_amdgcn_readlane(v, NCW <= 8 ? 7 : 15);
+            landed = __builtin_amdgcn_readlane(v, 16);
             if (j - S >= minprog) __builtin_amdgcn_s_sleep(MDE_RING_PSLEEP);
 #if MDE_RING_ABLATE
             pr_blocked += RING_CLK() - tb0;
@@ -274,6 +282,17 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
             }
 #endif
           }
+#if MDE_RING_ABLATE
+          // (probe: how long the chunk's own loads still take once its slot is free -- the newer loads of the
+          // wave's other buffers may stay in flight)
+          unsigned long long td0 = 0;
+          if (dbg & 512) {
+            td0 = RING_CLK();
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (((DEPTH - 1) * PIECES) & 15) | ((((DEPTH - 1) * PIECES) >> 4) << 14));
+            pr_data += RING_CLK() - td0;
+            td0 = RING_CLK();
+          }
+#endif
           char* dst = L + (uint32_t)__builtin_amdgcn_readfirstlane(ring_off + slot * CBYTES) + lane * 16;
           if (j != NC - 1 || (nbytes & 15) == 0) {
 #pragma unroll
@@ -301,19 +320,35 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           // the chunk's stores are ISSUED in front of the publish: float stores against an int store, which
           // type-based alias analysis would let the compiler swap)
           asm volatile("" ::: "memory");
-          ring_ctrl_store_counted(L, CTRL_F + 4u * (uint32_t)p, j + NPROD);
+          // publish IN CHUNK ORDER (round 5): LANDED == j says every chunk below j is in its slot, so the consumers
+          // read ONE word (a v_readfirstlane) where they took a minimum over the producers' four.  The chunk below
+          // belongs to the producer next door, which got its slot earlier: the wait is short.  (ring_ctrl_load
+          // drains this wave's LDS queue: the chunk's stores have completed when the word is written.)
+          // (LANDED == j, once seen, holds until this wave publishes: the value read with the slot poll will do)
+          while (landed != j && !(dbg & 8)) {
+            landed = __builtin_amdgcn_readfirstlane(ring_ctrl_load((uint32_t)CTRL_F + 0u * (uint32_t)lane));
+#if MDE_RING_ABLATE
+            ++pr_chain;
+#endif
+            if (landed != j) __builtin_amdgcn_s_sleep(0);
+          }
+          ring_ctrl_store_counted(L, CTRL_F, j + 1);
+#if MDE_RING_ABLATE
+          if (dbg & 512) pr_write += RING_CLK() - td0;
+#endif
           fetch(k, j + DEPTH * NPROD);
           slot += NPROD;
-          if (slot >= S) slot -= S;  // (S >= 6 > NPROD: choose_sizes)
+          while (slot >= S) slot -= S;
         }
       }
     }
-    ring_ctrl_store_counted(L, CTRL_F + 4u * (uint32_t)p, MDE_RING_DONE);
 #if MDE_RING_ABLATE
     if ((dbg & 512) && lane == 0 && blockIdx.x < 1024) {
       atomicAdd(&g_ring_probe[3][blockIdx.x], RING_CLK() - pr_t0);
       atomicAdd(&g_ring_probe[4][blockIdx.x], pr_blocked);
       atomicAdd(&g_ring_probe[6][blockIdx.x], pr_polls);
+      atomicAdd(&g_ring_probe[5][blockIdx.x], pr_data);
+      atomicAdd(&g_ring_probe[7][blockIdx.x], pr_write);
     }
 #endif
   } else {
@@ -450,45 +485,61 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       // the chunk window of a pair at its first iteration (k_ring_schedule), so one test covers both.
       const uint32_t prog_addr = CTRL_PROG + 4u * (uint32_t)wave;
       int ready = j_lo;  // chunks below this have landed
+      // The producers' F words are read one hand-shake AHEAD (round 5): a poll issued when the wave needs its
+      // answer costs a whole LDS round trip behind everything the wave has in flight (ring_ctrl_load drains
+      // the LDS queue), and with a 9-slot ring the cached `ready` covers hardly more than one pair -- nearly
+      // every pair polled at least once, ~280 clocks each, a third of the loop.  The prefetched words are a pair
+      // old, i.e. merely conservative (F only grows); when they are not enough the wave polls as before.
+      typedef __attribute__((address_space(3))) const volatile int* lds_cvint;
+      const uint32_t f_addr = (uint32_t)CTRL_F + 0u * (uint32_t)lane;  // (a VGPR for the inline-asm poll)
+      int fl_pre = *(lds_cvint)(L + CTRL_F);
       auto wait_pair = [&](int u, int q) __attribute__((always_inline)) {
         const int need = __builtin_amdgcn_readlane((int)hv[u], 4 * q + 1);
         if (__builtin_expect(need >= ready && !(dbg & 1), 0)) {
+          ready = __builtin_amdgcn_readfirstlane(fl_pre);
+          if (__builtin_expect(need >= ready, 0)) {
 #if MDE_RING_ABLATE
-          const unsigned long long tp0 = RING_CLK();
+            const unsigned long long tp0 = RING_CLK();
 #endif
-          for (;;) {
-            const int fl = ring_ctrl_load(CTRL_F + 4u * (uint32_t)min(lane, NPROD - 1));
-            ready = __builtin_amdgcn_readlane(fl, 0);
-#pragma unroll
-            for (int pp = 1; pp < NPROD; ++pp) ready = min(ready, __builtin_amdgcn_readlane(fl, pp));
+            for (;;) {
+              ready = __builtin_amdgcn_readfirstlane(ring_ctrl_load(f_addr));
 #if MDE_RING_ABLATE
-            ++cs_trips;
-            if (cs_trips > MDE_RING_SPINMAX) {
-              if (lane == 0) {
-                const int k = atomicAdd(&g_ring_ndiag, 1);
-                if (k < 64) {
-                  int* r = g_ring_diag[k];
-                  r[0] = 1; r[1] = blockIdx.x; r[2] = wave; r[3] = need; r[4] = ready; r[5] = 0; r[6] = u * 4 + q; r[7] = NB;
+              ++cs_trips;
+              if (cs_trips > MDE_RING_SPINMAX) {
+                if (lane == 0) {
+                  const int k = atomicAdd(&g_ring_ndiag, 1);
+                  if (k < 64) {
+                    int* r = g_ring_diag[k];
+                    r[0] = 1; r[1] = blockIdx.x; r[2] = wave; r[3] = need; r[4] = ready; r[5] = 0; r[6] = u * 4 + q; r[7] = NB;
+                  }
                 }
+                cs_trips = 0;
+                ready = need + 1;
+                break;
               }
-              cs_trips = 0;
-              ready = need + 1;
-              break;
+#endif
+              if (need < ready) break;
+              __builtin_amdgcn_s_sleep(MDE_RING_CSLEEP);
             }
-#endif
-            if (need < ready) break;
-            __builtin_amdgcn_s_sleep(MDE_RING_CSLEEP);
-          }
 #if MDE_RING_ABLATE
-          cs_poll += RING_CLK() - tp0;
+            cs_poll += RING_CLK() - tp0;
 #endif
+          }
           asm volatile("" ::: "memory");
         }
       };
+      // (issued right behind a pair's operand reads and its release)
+      auto prefetch_landed = [&]() __attribute__((always_inline)) { fl_pre = *(lds_cvint)(L + CTRL_F); };
       // (m never decreases along a stream; past its end the headers are copies of the last block and
       // the value published is merely too old)
+      // (the lane that holds the header word stores it: no v_readlane / v_mov round trip through the scalar unit)
+      // EVERY lane stores its header word: the lane that holds word 4 q (the pair's m) to prog[wave], the others
+      // into the spare half of the control block (lanes l and l + 32 share a word: different 32-lane passes) --
+      // no branch around a one-lane store, no address or data to move per pair
+      const uint32_t rel_addr[2] = {lane == 0 ? 4u * (uint32_t)wave : 128u + 4u * (uint32_t)(lane & 31),
+                                    lane == 8 ? 4u * (uint32_t)wave : 128u + 4u * (uint32_t)(lane & 31)};
       auto release_to = [&](int u, int q) __attribute__((always_inline)) {
-        ring_ctrl_store_counted(L, prog_addr, __builtin_amdgcn_readlane((int)hv[u], 4 * q));
+        ring_ctrl_store_counted(L, CTRL_PROG + rel_addr[q >> 1], (int)hv[u]);
       };
 
       // Software pipeline over PAIRS of iterations.  In the region of pair p the wave (after the
@@ -518,6 +569,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           const Pre xna = issue_x(pq[un][qn], (a0_scalar || CB) ? a0s : wq[un][qn]);
           const Pre xnb = issue_x(pq[un][qn + 1], (a0_scalar || CB) ? a0s : wq[un][qn + 1]);
           release_to((u + 1) % PFB, q);  // (the pair after that one: next block, same slot)
+          prefetch_landed();
           const float p1a = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q] : a1s;
           const float p1b = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q + 1] : a1s;
           const bool lc2 = decltype(lc_tag)::value == 2;
@@ -538,6 +590,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       xa = issue_x(pq[0][0], (a0_scalar || CB) ? a0s : wq[0][0]);
       xb = issue_x(pq[0][1], (a0_scalar || CB) ? a0s : wq[0][1]);
       release_to(0, 2);
+      prefetch_landed();
       if (HAS_GRAD) ring_ld<D>(L + GR_OFF + row_of(pq[0][0]), acc);
       for (int base = 0; base < NB; base += PFB) {
 #pragma unroll
@@ -571,7 +624,62 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     __builtin_amdgcn_s_waitcnt(0x0F70);
   }
   __syncthreads();
-  if (HAS_GRAD) {
+  if (HAS_GRAD && fold) {
+    // Q == 2, one launch (round 5): the two column groups of a row block meet at a ticket.  The group that
+    // arrives FIRST leaves its unscaled rows in `partial` (relaxed device-scope stores: write-through, the
+    // XCDs' L2s are not coherent) and raises a flag once they have completed; the SECOND adds them to the
+    // rows it still holds in LDS and writes the final gradient rows.  a + b = b + a to the last bit, so
+    // the result does not depend on who arrives first and equals k_ring_combine's (partial[0] + partial[1])
+    // * scale.  With 16 groups (8-way shards) an in-launch reducer was slower than the second launch both
+    // times it was built; with two there is one 63 KB partial to read, and the second launch
+    // cost 6.5 us + a launch gap per evaluation.
+    unsigned int* sync = reinterpret_cast<unsigned int*>(partial + (size_t)Q * nloc * D) + 2 * rb;
+    int* tk = reinterpret_cast<int*>(L + 512);  // (the x_v region is free now)
+    if (tid == 0) *tk = (int)__hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool second = *tk != 0;
+    float* mine = partial + ((size_t)qg * nloc + r0) * D;
+    const float* other = partial + ((size_t)(1 - qg) * nloc + r0) * D;
+    float* grow = grad + (size_t)(row_lo + r0) * D;
+    if (!second) {
+      if constexpr (D == 2) {
+        for (int i = tid; i < nr; i += BS)
+          __hip_atomic_store(reinterpret_cast<double*>(mine) + i, reinterpret_cast<const double*>(GR)[i], __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        for (int i = tid; i < nr * D; i += BS) __hip_atomic_store(mine + i, GR[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the rows have completed
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (tid == 0) {
+        while (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+        // (both words back to zero for the next launch)
+        __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if constexpr (D == 2) {
+        for (int i = tid; i < nr; i += BS) {
+          const double o = __hip_atomic_load(reinterpret_cast<const double*>(other) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float2 ov = *reinterpret_cast<const float2*>(&o);
+          const float2 mv = reinterpret_cast<const float2*>(GR)[i];
+          // (group order, as k_ring_combine adds them)
+          float2 r;
+          r.x = (qg == 0 ? mv.x + ov.x : ov.x + mv.x) * grad_scale;
+          r.y = (qg == 0 ? mv.y + ov.y : ov.y + mv.y) * grad_scale;
+          reinterpret_cast<float2*>(grow)[i] = r;
+        }
+      } else {
+        for (int i = tid; i < nr * D; i += BS) {
+          const float o = __hip_atomic_load(other + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          grow[i] = (qg == 0 ? GR[i] + o : o + GR[i]) * grad_scale;
+        }
+      }
+    }
+    __syncthreads();
+  } else if (HAS_GRAD) {
     // Q == 1: the rows are final.  Q > 1: unscaled per-group partials, summed by k_ring_combine
     float* grow = (Q == 1) ? grad + (size_t)(row_lo + r0) * D : partial + ((size_t)qg * nloc + r0) * D;
     const float sc = (Q == 1) ? grad_scale : 1.0f;
@@ -683,12 +791,15 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
 #else
   const int dbg = 0;
 #endif
+  // two column groups per row block: their rows are added inside the launch (MDE_RING_FOLD=0: by k_ring_combine)
+  static const int fold_env = getenv("MDE_RING_FOLD") ? atoi(getenv("MDE_RING_FOLD")) : 1;
+  const int fold = (Q == 2 && A.grad && fold_env) ? 1 : 0;
   // (every edge adds its loss term once here, not once per endpoint: twice the caller's scale)
   hipLaunchKernelGGL(kern, dim3(L.n_row_blocks * Q), dim3(MDE_RING_BS), 0, A.st,
                      (int)(A.plan->row_hi - A.plan->row_lo), (int)A.plan->row_lo, (int)A.plan->n,
                      L.rows_per_block, Q, L.n_chunks, L.ring_off, L.slots, L.wave_iter, L.hdr, stream, a0, A.a1, A.a0_scalar,
                      A.a1_scalar, A.X, A.grad, L.partial, A.plan->partials, fn, fix_value, out_scale,
-                     A.loss_out, 2.0 * A.loss_scale, dbg);
+                     A.loss_out, 2.0 * A.loss_scale, fold, dbg);
   MDE_LAUNCH_CHECK();
 #if MDE_RING_ABLATE
   {
@@ -718,10 +829,35 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
         for (int i = 0; i < nb; ++i) s[k] += (double)h[k * 1024 + i];
       const double L8 = 8.0 * nb;  // launches x workgroups
       fprintf(stderr, "[mde ring probe] per consumer wave and launch: loop %.0f clk, in chunk polls %.0f clk (%.1f%%), %.0f poll trips | "
-              "per producer wave: loop %.0f clk, blocked on a slot %.0f (%.1f%%), waiting for pieces %.0f (%.1f%%), %.0f slot polls\n",
+              "per producer wave: loop %.0f clk, blocked on a slot %.0f (%.1f%%), waiting for the chunk's loads %.0f (%.1f%%), %.0f slot polls, LDS stores + ordered publish %.0f clk\n",
               s[0] / L8 / MDE_RING_NCW, s[1] / L8 / MDE_RING_NCW, 100.0 * s[1] / s[0], s[2] / L8 / MDE_RING_NCW,
               s[3] / L8 / MDE_RING_NPROD, s[4] / L8 / MDE_RING_NPROD, 100.0 * s[4] / s[3], s[5] / L8 / MDE_RING_NPROD,
-              100.0 * s[5] / s[3], s[6] / L8 / MDE_RING_NPROD);
+              100.0 * s[5] / s[3], s[6] / L8 / MDE_RING_NPROD, s[7] / L8 / MDE_RING_NPROD);
+      // per workgroup: the consumers' loop and the part of it that is NOT polling (is there a tail? do the
+      // workgroups that add all the loss terms -- low row blocks, upper column group -- run longer?)
+      std::vector<double> loop(nb), work(nb);
+      for (int i = 0; i < nb; ++i) {
+        loop[i] = (double)h[i] / 8.0 / MDE_RING_NCW;
+        work[i] = ((double)h[i] - (double)h[1024 + i]) / 8.0 / MDE_RING_NCW;
+      }
+      auto quant = [&](std::vector<double> v, const char* what) {
+        std::sort(v.begin(), v.end());
+        double m = 0;
+        for (double x : v) m += x;
+        fprintf(stderr, "[mde ring probe] per workgroup, %s: min %.0f p10 %.0f median %.0f mean %.0f p90 %.0f max %.0f clk\n", what, v[0],
+                v[v.size() / 10], v[v.size() / 2], m / v.size(), v[v.size() * 9 / 10], v.back());
+      };
+      quant(loop, "consumer loop");
+      quant(work, "consumer loop minus polls");
+      for (int q8 = 0; q8 < 8; ++q8) {
+        double a = 0, b2 = 0;
+        int c = 0;
+        for (int i = q8 * nb / 8; i < (q8 + 1) * nb / 8; ++i, ++c) {
+          a += loop[i];
+          b2 += work[i];
+        }
+        fprintf(stderr, "[mde ring probe] workgroups %d..%d: loop %.0f, minus polls %.0f\n", q8 * nb / 8, (q8 + 1) * nb / 8 - 1, a / c, b2 / c);
+      }
     }
   }
 #endif
@@ -730,7 +866,7 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
   // partials) was built twice -- round 2 with a fence, round 3 with write-through stores and relaxed
   // loads -- and measured slower both times (8-way shard: 77 vs 57 us per evaluation): 8 x 32 KB of
   // partials per row block are an order of magnitude more than an in-launch reducer reads for free.
-  if (Q > 1 && A.grad) {
+  if (Q > 1 && A.grad && !fold) {
     const int64_t nlocD = (A.plan->row_hi - A.plan->row_lo) * (int64_t)D;
     float* out = A.grad + (size_t)A.plan->row_lo * D;
     if (nlocD % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {

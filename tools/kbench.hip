@@ -9,6 +9,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <chrono>
 #include <vector>
 #include <algorithm>
@@ -45,6 +46,28 @@ __global__ void k_gen(int64_t n, int64_t p, int deg, int64_t* edges, float* w) {
     const uint64_t h = splitmix(k);
     int64_t dst = (int64_t)(h % (uint64_t)(n - 1));
     dst += dst >= src;
+    edges[2 * k] = src < dst ? src : dst;
+    edges[2 * k + 1] = src < dst ? dst : src;
+    w[k] = ((h >> 40) % 10) < 3 ? 2.0f : 1.0f;
+  }
+}
+// KB_GRAPH=strat: every vertex has exactly one out-edge and (nearly) one in-edge per column stratum of n / deg
+// vertices -- the rows' half-edges are spread EVENLY over the column sweep, so the consumer waves of the ring
+// kernel advance in step whatever the row -> wave map is (the bound of what a balanced map can buy)
+__global__ void k_gen_strat(int64_t n, int64_t p, int deg, int64_t* edges, float* w) {
+  const int64_t m = n / deg;  // stratum width
+  for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k < p;
+       k += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t src = k / deg;
+    const int i = (int)(k % deg);
+    const uint64_t hi = splitmix(1000003ull * (uint64_t)i + 17ull);
+    // multiplier coprime with m (m = 20000 = 2^5 5^4 at config 4: odd, not a multiple of 5)
+    uint64_t A = (hi % (uint64_t)m) | 1ull;
+    while (A % 5ull == 0ull) A += 2ull;
+    const uint64_t B = (hi >> 32) % (uint64_t)m;
+    int64_t dst = (int64_t)i * m + (int64_t)(((uint64_t)src * A + B) % (uint64_t)m);
+    if (dst == src) dst = (int64_t)i * m + (dst - (int64_t)i * m + 1) % m;
+    const uint64_t h = splitmix(k);
     edges[2 * k] = src < dst ? src : dst;
     edges[2 * k + 1] = src < dst ? dst : src;
     w[k] = ((h >> 40) % 10) < 3 ? 2.0f : 1.0f;
@@ -151,7 +174,11 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&X, n * 2 * 4));
   CK(hipMalloc(&grad, n * 2 * 4));
   CK(hipMalloc(&loss, 64));
-  hipLaunchKernelGGL(k_gen, dim3(2048), dim3(256), 0, st, n, p, deg, edges, w);
+  if (getenv("KB_GRAPH") && !strcmp(getenv("KB_GRAPH"), "strat")) {
+    printf("graph: stratified (one out-edge per column stratum of %lld vertices)\n", (long long)(n / deg));
+    hipLaunchKernelGGL(k_gen_strat, dim3(2048), dim3(256), 0, st, n, p, deg, edges, w);
+  } else
+    hipLaunchKernelGGL(k_gen, dim3(2048), dim3(256), 0, st, n, p, deg, edges, w);
   hipLaunchKernelGGL(k_genx, dim3(2048), dim3(256), 0, st, n * 2, X);
   CK(hipStreamSynchronize(st));
 
