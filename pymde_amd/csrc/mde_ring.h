@@ -46,6 +46,9 @@ __host__ __device__ constexpr int ring_gr_off(int d) { return ring_ctrl_off(d) +
 #ifndef MDE_RING_DEPTH
 #define MDE_RING_DEPTH 2           // chunks in flight (in VGPRs) per producer wave
 #endif
+#ifndef MDE_RING_UNIT
+#define MDE_RING_UNIT 1            // consecutive chunks a producer step moves (one slot poll, one publish)
+#endif
 #ifndef MDE_RING_PFB
 #define MDE_RING_PFB 3             // stream blocks (4 iterations each) in flight per consumer wave
 #endif

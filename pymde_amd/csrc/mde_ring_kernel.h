@@ -215,22 +215,27 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     const char* Xb = reinterpret_cast<const char*>(X);
     const size_t nbytes = (size_t)n * D * 4;
     const size_t last16 = nbytes - 16;  // (X is 16-byte aligned, n * D * 4 >= 16: checked by the launcher)
-    constexpr int DEPTH = MDE_RING_DEPTH;
-    ring_f4 buf[DEPTH][PIECES];
-    auto fetch = [&](int k, int j) __attribute__((always_inline)) {
-      if (j < NC - 1) {
-        // a chunk that lies wholly inside the table: one base address, the pieces at immediate offsets
-        // (the producers share their SIMDs' issue slots with the consumers: every instruction here counts)
-        const ring_f4* src = reinterpret_cast<const ring_f4*>(Xb + (size_t)j * CBYTES + (size_t)lane * 16);
+    constexpr int DEPTH = MDE_RING_DEPTH, UNIT = MDE_RING_UNIT;
+    // a producer step moves UNIT consecutive chunks: one slot poll and one publish for all of them
+    ring_f4 buf[DEPTH][UNIT * PIECES];
+    auto fetch = [&](int k, int j0u) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) buf[k][i] = src[i * 64];
-      } else {
-        // the table's last chunk, or a prefetch past the end of the table (clamped, never written)
-        const size_t off0 = (size_t)min(j, NC - 1) * CBYTES + (size_t)lane * 16;
+      for (int c = 0; c < UNIT; ++c) {
+        const int j = j0u + c;
+        if (j < NC - 1) {
+          // a chunk that lies wholly inside the table: one base address, the pieces at immediate offsets
+          // (the producers share their SIMDs' issue slots with the consumers: every instruction here counts)
+          const ring_f4* src = reinterpret_cast<const ring_f4*>(Xb + (size_t)j * CBYTES + (size_t)lane * 16);
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-          const size_t off = off0 + (size_t)i * 1024;
-          buf[k][i] = *reinterpret_cast<const ring_f4*>(Xb + (off < last16 ? off : last16));
+          for (int i = 0; i < PIECES; ++i) buf[k][c * PIECES + i] = src[i * 64];
+        } else {
+          // the table's last chunk, or a prefetch past the end of the table (clamped, never written)
+          const size_t off0 = (size_t)min(j, NC - 1) * CBYTES + (size_t)lane * 16;
+#pragma unroll
+          for (int i = 0; i < PIECES; ++i) {
+            const size_t off = off0 + (size_t)i * 1024;
+            buf[k][c * PIECES + i] = *reinterpret_cast<const ring_f4*>(Xb + (off < last16 ? off : last16));
+          }
         }
       }
     };
@@ -240,15 +245,17 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     unsigned long long pr_t0 = RING_CLK(), pr_blocked = 0, pr_polls = 0, pr_chain = 0, pr_data = 0, pr_write = 0;
 #endif
 #pragma unroll
-    for (int k = 0; k < DEPTH; ++k) fetch(k, j_lo + p + k * NPROD);
-    int slot = (j_lo + p) % S;
-    for (int j0 = j_lo + p; j0 < j_hi && !(dbg & 128); j0 += DEPTH * NPROD) {
+    for (int k = 0; k < DEPTH; ++k) fetch(k, j_lo + UNIT * (p + k * NPROD));
+    int slot = (j_lo + UNIT * p) % S;
+    for (int j0 = j_lo + UNIT * p; j0 < j_hi && !(dbg & 128); j0 += UNIT * DEPTH * NPROD) {
 #pragma unroll
       for (int k = 0; k < DEPTH; ++k) {
-        const int j = j0 + k * NPROD;
+        const int j = j0 + k * UNIT * NPROD;
         if (j < j_hi) {
-          // slot j % S still holds chunk j - S until every consumer is past it
-          while (j - S >= minprog && !(dbg & 8)) {
+          const int jl = min(j + UNIT, j_hi) - 1;  // the step's last chunk
+          // slot jl % S still holds chunk jl - S until every consumer is past it (the slots of the step's
+          // earlier chunks were released before)
+          while (jl - S >= minprog && !(dbg & 8)) {
 #if MDE_RING_ABLATE
             const unsigned long long tb0 = RING_CLK();
             ++pr_polls;
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
             if (NCW > 8) asm volatile("v_min_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1" : "+v"(v));
             minprog = __builtin_amdgcn_readlane(v, NCW <= 8 ? 7 : 15);
             landed = __builtin_amdgcn_readlane(v, 16);
-            if (j - S >= minprog) __builtin_amdgcn_s_sleep(MDE_RING_PSLEEP);
+            if (jl - S >= minprog) __builtin_amdgcn_s_sleep(MDE_RING_PSLEEP);
 #if MDE_RING_ABLATE
             pr_blocked += RING_CLK() - tb0;
             if (pr_polls > MDE_RING_SPINMAX) {
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
                 }
               }
               pr_polls = 0;
-              minprog = j;  // (give up: overwrite the slot)
+              minprog = jl;  // (give up: overwrite the slot)
             }
 #endif
           }
@@ -288,42 +295,48 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           unsigned long long td0 = 0;
           if (dbg & 512) {
             td0 = RING_CLK();
-            __builtin_amdgcn_s_waitcnt(0x0F70 | (((DEPTH - 1) * PIECES) & 15) | ((((DEPTH - 1) * PIECES) >> 4) << 14));
+            __builtin_amdgcn_s_waitcnt(0x0F70 | (((DEPTH - 1) * UNIT * PIECES) & 15) | ((((DEPTH - 1) * UNIT * PIECES) >> 4) << 14));
             pr_data += RING_CLK() - td0;
             td0 = RING_CLK();
           }
 #endif
-          char* dst = L + (uint32_t)__builtin_amdgcn_readfirstlane(ring_off + slot * CBYTES) + lane * 16;
-          if (j != NC - 1 || (nbytes & 15) == 0) {
 #pragma unroll
-            for (int i = 0; i < PIECES; ++i) *reinterpret_cast<ring_f4*>(dst + i * 1024) = buf[k][i];
-          } else {
-            // the table's last chunk when the table is not a multiple of 16 bytes: the lane whose 16
-            // bytes straddle the end loaded the LAST 16 bytes instead -- shift them into place
-            const size_t off0 = (size_t)j * CBYTES + (size_t)lane * 16;
+          for (int c = 0; c < UNIT; ++c) {
+            const int jc = j + c;
+            if (UNIT > 1 && jc >= j_hi) break;
+            int sc = slot + c;
+            if (UNIT > 1 && sc >= S) sc -= S;
+            char* dst = L + (uint32_t)__builtin_amdgcn_readfirstlane(ring_off + sc * CBYTES) + lane * 16;
+            if (jc != NC - 1 || (nbytes & 15) == 0) {
 #pragma unroll
-            for (int i = 0; i < PIECES; ++i) {
-              const size_t off = off0 + (size_t)i * 1024;
-              ring_f4 v = buf[k][i];
-              if (off > last16 && off < nbytes) {
-                const int sh4 = (int)((off - last16) >> 2);  // 1..3 floats
-                const float t1 = v[1], t2 = v[2], t3 = v[3];
-                v[0] = sh4 == 1 ? t1 : (sh4 == 2 ? t2 : t3);
-                v[1] = sh4 == 1 ? t2 : (sh4 == 2 ? t3 : 0.0f);
-                v[2] = sh4 == 1 ? t3 : 0.0f;
-                v[3] = 0.0f;
+              for (int i = 0; i < PIECES; ++i) *reinterpret_cast<ring_f4*>(dst + i * 1024) = buf[k][c * PIECES + i];
+            } else {
+              // the table's last chunk when the table is not a multiple of 16 bytes: the lane whose 16
+              // bytes straddle the end loaded the LAST 16 bytes instead -- shift them into place
+              const size_t off0 = (size_t)jc * CBYTES + (size_t)lane * 16;
+#pragma unroll
+              for (int i = 0; i < PIECES; ++i) {
+                const size_t off = off0 + (size_t)i * 1024;
+                ring_f4 v = buf[k][c * PIECES + i];
+                if (off > last16 && off < nbytes) {
+                  const int sh4 = (int)((off - last16) >> 2);  // 1..3 floats
+                  const float t1 = v[1], t2 = v[2], t3 = v[3];
+                  v[0] = sh4 == 1 ? t1 : (sh4 == 2 ? t2 : t3);
+                  v[1] = sh4 == 1 ? t2 : (sh4 == 2 ? t3 : 0.0f);
+                  v[2] = sh4 == 1 ? t3 : 0.0f;
+                  v[3] = 0.0f;
+                }
+                *reinterpret_cast<ring_f4*>(dst + i * 1024) = v;
               }
-              *reinterpret_cast<ring_f4*>(dst + i * 1024) = v;
             }
           }
-          // (the LDS executes a wave's accesses in order: whoever sees the new F sees the chunk -- provided
-          // the chunk's stores are ISSUED in front of the publish: float stores against an int store, which
+          // (the LDS executes a wave's accesses in order: whoever sees the new LANDED sees the chunks -- provided
+          // their stores are ISSUED in front of the publish: float stores against an int store, which
           // type-based alias analysis would let the compiler swap)
           asm volatile("" ::: "memory");
           // publish IN CHUNK ORDER (round 5): LANDED == j says every chunk below j is in its slot, so the consumers
           // read ONE word (a v_readfirstlane) where they took a minimum over the producers' four.  The chunk below
-          // belongs to the producer next door, which got its slot earlier: the wait is short.  (ring_ctrl_load
-          // drains this wave's LDS queue: the chunk's stores have completed when the word is written.)
+          // belongs to the producer next door, which got its slot earlier: the wait is short.
           // (LANDED == j, once seen, holds until this wave publishes: the value read with the slot poll will do)
           while (landed != j && !(dbg & 8)) {
             landed = __builtin_amdgcn_readfirstlane(ring_ctrl_load((uint32_t)CTRL_F + 0u * (uint32_t)lane));
@@ -332,12 +345,12 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
 #endif
             if (landed != j) __builtin_amdgcn_s_sleep(0);
           }
-          ring_ctrl_store_counted(L, CTRL_F, j + 1);
+          ring_ctrl_store_counted(L, CTRL_F, jl + 1);
 #if MDE_RING_ABLATE
           if (dbg & 512) pr_write += RING_CLK() - td0;
 #endif
-          fetch(k, j + DEPTH * NPROD);
-          slot += NPROD;
+          fetch(k, j + UNIT * DEPTH * NPROD);
+          slot += UNIT * NPROD;
           while (slot >= S) slot -= S;
         }
       }

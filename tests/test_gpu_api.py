@@ -134,3 +134,71 @@ def test_recipes_laplacian_embedding_and_neighbors_on_graph():
     assert int(g["png_n_neg"]) <= int((w < 0).sum()) <= len(g["png_edges_pos"])
     pn.embed(max_iter=50)
     assert np.isfinite(float(pn.value))
+
+
+def test_reference_signature_seam_average_distortion():
+    """The operator-level seam of the reference, ``_average_distortion(X, f, lhs, rhs)``
+    [ref: pymde/average_distortion.py:58-59 `_gather_indices`, :109 `_AverageDistortion.apply`;
+    problem.py:130-132 builds lhs / rhs as stride-0 expanded views of edges[:, 0 / 1]]: called the way the
+    reference's optimiser calls it, twice (the second call must hit the plan cache), then after an IN-PLACE
+    edit of `edges` (the cache must miss: the views' version counter moved) -- bitwise equal to
+    ``MDE.average_distortion`` and equal to the oracle each time."""
+    import pymde_amd
+    from conftest import assert_grad_close
+    from pymde_amd import average_distortion as ad
+    rng = np.random.default_rng(3)
+    n, d, p = 3000, 2, 40000
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    key = np.unique(np.minimum(i, j).astype(np.int64) * n + np.maximum(i, j))
+    edges_np = np.stack([key // n, key % n], 1)
+    p = len(edges_np)
+    w_np = (1.0 + (rng.random(p) < 0.3)).astype(np.float32)
+    edges = torch.tensor(edges_np, device=DEV)
+    f = pymde_amd.penalties.Log1p(torch.tensor(w_np, device=DEV))
+    X_np = rng.standard_normal((n, d)).astype(np.float32)
+
+    def via_seam():
+        lhs = ad._gather_indices(edges[:, 0], d)   # (p, d), strides (2, 0): only column 0 is real
+        rhs = ad._gather_indices(edges[:, 1], d)
+        assert lhs.stride(1) == 0 and rhs.stride(1) == 0
+        X = torch.tensor(X_np, device=DEV, requires_grad=True)
+        E = ad._average_distortion(X, f, lhs, rhs)
+        E.backward()
+        return E.detach().clone(), X.grad.clone()
+
+    def via_mde(e_np):
+        mde = pymde_amd.MDE(n, d, torch.tensor(e_np, device=DEV), f)
+        X = torch.tensor(X_np, device=DEV, requires_grad=True)
+        E = mde.average_distortion(X)
+        E.backward()
+        return E.detach().clone(), X.grad.clone()
+
+    ad._PLAN_CACHE.clear()
+    E1, g1 = via_seam()
+    assert len(ad._PLAN_CACHE) == 1
+    binding1 = next(iter(ad._PLAN_CACHE.values()))[0]
+    E2, g2 = via_seam()                                # fresh views of the same storage: cache hit
+    assert len(ad._PLAN_CACHE) == 1 and next(iter(ad._PLAN_CACHE.values()))[0] is binding1
+    assert torch.equal(E1, E2) and torch.equal(g1, g2)
+    Em, gm = via_mde(edges_np)
+    assert torch.equal(E1, Em) and torch.equal(g1, gm)
+    wE, wgrad = oracle.average_distortion(edges_np, X_np, oracle.func("LOG1P", w_np, None, (1.5,)))
+    assert float(E1) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(g1.cpu().numpy(), wgrad)
+    # in-place edit: re-point the first edge to another (unused) partner
+    have = set(map(tuple, edges_np.tolist()))
+    a = int(edges_np[0, 0])
+    b = next(v for v in range(a + 1, n) if (a, v) not in have)
+    edges[0, 1] = b
+    edited = edges_np.copy()
+    edited[0, 1] = b
+    E3, g3 = via_seam()
+    assert len(ad._PLAN_CACHE) == 2                   # a miss: a new plan for the edited list
+    assert not torch.equal(g3, g1)
+    Em3, gm3 = via_mde(edited)
+    assert torch.equal(E3, Em3) and torch.equal(g3, gm3)
+    wE3, wgrad3 = oracle.average_distortion(edited, X_np, oracle.func("LOG1P", w_np, None, (1.5,)))
+    assert float(E3) == pytest.approx(wE3, rel=1e-5)
+    assert_grad_close(g3.cpu().numpy(), wgrad3)
+    ad._PLAN_CACHE.clear()

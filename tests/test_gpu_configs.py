@@ -306,3 +306,88 @@ def test_config5_full_size_against_oracle():
         wE, wgrad = oracle.average_distortion(e_np, X_np, oracle.func(name, w_np, None, scal))
         assert float(buf[n * d]) == pytest.approx(wE, rel=1e-5), name
         assert_grad_close(buf[:n * d].view(n, d).cpu().numpy(), wgrad)
+
+
+def _ring_full_size_case(n, deg, d, make_f, oracle_func, runs=3):
+    """>= 5e7 half-edge entries through the LDS-ring kernel: against the OpenMP oracle at the kernel
+    tolerances, `runs` evaluations bitwise equal (a race in the ring protocol shows up as a few rows that
+    differ from run to run -- the round-4 d = 3 race was invisible below ~1e7 entries)."""
+    import bench
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    dev = torch.device(DEV, 0)
+    edges, w, X = bench.make_workload(dev, n=n, deg=deg, d=d)
+    p = edges.shape[0]
+    assert 2 * p >= 5 * 10 ** 7
+    f, fd = make_f(w, p, dev), None
+    b = Binding(EdgePlan(n, edges), f)
+    bufs = []
+    for _ in range(runs):
+        buf = torch.zeros(n * d + 1, device=dev)
+        fused_evaluate(b, X, buf[:n * d].view(n, d), buf[n * d:])
+        bufs.append(buf)
+    assert b.struct(d).layout == 1, "the LDS-ring layout should have been chosen"
+    for other in bufs[1:]:
+        assert torch.equal(other, bufs[0]), "two evaluations differ bitwise"
+    fd = oracle_func(f, w.cpu().numpy())
+    wE, wgrad = oracle.average_distortion(edges.cpu().numpy(), X.cpu().numpy(), fd)
+    assert float(bufs[0][n * d]) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(bufs[0][:n * d].view(n, d).cpu().numpy(), wgrad)
+    return b
+
+
+@pytest.mark.parametrize("case", ["pen_huber_d3", "pen_quadratic_d3", "loss_huber_d3", "log1p_fp32_d3",
+                                  "runtime_logistic_d1", "runtime_power_d4", "pen_cubic_scalar_d2"])
+def test_ring_units_full_size_against_oracle_and_bitwise(case):
+    """Every translation unit that instantiates the ring kernel (mde_ring_k_*.hip) at full size, in the
+    dimensions and parameter forms the headline tests do not take: the penalty unit and the loss unit at
+    d = 3 (codebook streams), the Log1p unit's fp32 stream at d = 3, the run-time functor at d = 1 and
+    d = 4 (fp32 streams), and a scalar-parameter form at d = 2.  25M edges = 5e7 entries each."""
+    import pymde_amd
+    pen, los = pymde_amd.penalties, pymde_amd.losses
+    n, deg = 250_000, 100
+
+    def cont(w, p, dev, lo=0.25, hi=1.75, seed=11):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        return torch.rand(p, device=dev, generator=g) * (hi - lo) + lo
+
+    if case == "pen_huber_d3":
+        b = _ring_full_size_case(n, deg, 3, lambda w, p, dev: pen.Huber(w, 0.5),
+                                 lambda f, w: oracle.func("HUBER", w, None, (0.5,)))
+        assert b.codebook
+    elif case == "pen_quadratic_d3":
+        b = _ring_full_size_case(n, deg, 3, lambda w, p, dev: pen.Quadratic(w),
+                                 lambda f, w: oracle.func("QUADRATIC", w))
+        assert b.codebook
+    elif case == "loss_huber_d3":
+        # deviations {1, 2}: the loss unit's codebook stream at d = 3
+        b = _ring_full_size_case(n, deg, 3, lambda w, p, dev: los.Huber(w, 1.0),
+                                 lambda f, w: oracle.func("L_HUBER", w, None, (1.0,)))
+        assert b.codebook
+    elif case == "log1p_fp32_d3":
+        holder = {}
+
+        def mk(w, p, dev):
+            holder["w"] = cont(w, p, dev)
+            return pen.Log1p(holder["w"])
+        b = _ring_full_size_case(n, deg, 3, mk, lambda f, w: oracle.func("LOG1P", holder["w"].cpu().numpy(), None, (1.5,)))
+        assert not b.codebook
+    elif case == "runtime_logistic_d1":
+        holder = {}
+
+        def mk(w, p, dev):
+            holder["w"] = cont(w, p, dev)
+            return pen.Logistic(holder["w"], 0.5, 3.0)
+        b = _ring_full_size_case(n, deg, 1, mk, lambda f, w: oracle.func("LOGISTIC", holder["w"].cpu().numpy(), None, (0.5, 3.0)))
+        assert not b.codebook
+    elif case == "runtime_power_d4":
+        holder = {}
+
+        def mk(w, p, dev):
+            holder["w"] = cont(w, p, dev)
+            return pen.Power(holder["w"], 2.5)
+        b = _ring_full_size_case(n, deg, 4, mk, lambda f, w: oracle.func("POWER", holder["w"].cpu().numpy(), None, (2.5,)))
+        assert not b.codebook
+    else:
+        # one scalar weight for every edge (the LIN = false form: padding lanes are masked)
+        _ring_full_size_case(n, deg, 2, lambda w, p, dev: pen.Cubic(torch.tensor([1.5], device=dev)),
+                             lambda f, w: oracle.func("CUBIC", np.array([1.5], np.float32)))
