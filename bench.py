@@ -103,6 +103,24 @@ def make_workload(device, n=N_ITEMS, deg=OUT_DEGREE, d=DIM):
     return edges, w, X.contiguous()
 
 
+def make_workload_survey(device, n=N_ITEMS, deg=OUT_DEGREE, d=DIM):
+    """SURVEY 8d config 4a EXACTLY as the survey writes it: numpy default_rng(0) on the host for the edges and
+    the weights, torch.manual_seed(0) + CPU randn for X, then uploaded -- the tensors a reference-side run of the
+    recipe builds, bit for bit (bench.py --survey-seed; the default line keeps the device generator)."""
+    rng = np.random.default_rng(0)
+    p = n * deg
+    src = np.repeat(np.arange(n), deg)
+    dst = rng.integers(0, n - 1, p)
+    dst += dst >= src
+    edges = np.stack([np.minimum(src, dst), np.maximum(src, dst)], axis=1)
+    w = (1 + (rng.random(p) < 0.3)).astype(np.float32)
+    torch.manual_seed(0)
+    X = torch.randn(n, d)
+    X -= X.mean(0)
+    return (torch.from_numpy(edges).to(device).contiguous(), torch.from_numpy(w).to(device),
+            X.to(device).contiguous())
+
+
 def torch_reference_sequence(X, lhs, rhs, w, exponent=1.5):
     """The reference's op sequence for one evaluation [ref: pymde/average_distortion.py:68-105,
     penalties.py:310-321], restated with plain torch ops: index gathers, pow / sum / sqrt, the
@@ -254,7 +272,7 @@ def run_config4(args, world, rank, device):
     from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
 
     n, d = args.n, DIM
-    edges, w, X = make_workload(device, n=n)
+    edges, w, X = make_workload_survey(device, n=n) if args.survey_seed else make_workload(device, n=n)
     p = edges.shape[0]
     if args.variant == "4b":
         # the last third of the edges repulsive (w = -1), PushAndPull(Log1p, Log)
@@ -360,9 +378,11 @@ def run_config4(args, world, rank, device):
         "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3] / SURVEY 8d config %s: n=%d, |E|=%d uniform-random edges "
-                               "(out-degree 50), d=2, %s; seeded on the "
-                               "device with torch.Generator(0) (the survey's recipe uses numpy default_rng(0): "
-                               "same distribution, another stream)" % (args.variant, n, p, fname),
+                               "(out-degree 50), d=2, %s; %s" % (args.variant, n, p, fname,
+                               "the survey's exact tensors: numpy default_rng(0) edges and weights, torch.manual_seed(0) "
+                               "CPU randn X, built on the host and uploaded (--survey-seed)" if args.survey_seed else
+                               "seeded on the device with torch.Generator(0) (the survey's recipe uses numpy "
+                               "default_rng(0): same distribution, another stream; --survey-seed builds that one)"),
                    "parallelism": ("vertex-range shards x%d + %s of [grad|loss]" % (world, exchange.mode))
                    if world > 1 else ("single GPU" if args.emulate_world <= 1 else
                                       "rank 0 of a %d-way shard, kernel only (emulation, no collective)" % args.emulate_world),
@@ -388,6 +408,14 @@ def run_config4(args, world, rank, device):
         out["config"]["fp32_parameter_stream"] = {
             "kernel_ms": k2, "value": p / (k2 * 1e-3), "unit": "edges/s/iter (kernel time)",
             "roofline_frac": alg_bytes / (k2 * 1e-3) / HBM_PEAK_BPS}
+    if args.survey_seed and world == 1 and args.variant == "4a" and args.function == "log1p":
+        # the loss of the survey's exact workload next to the oracle's (the OpenMP restatement on the same tensors)
+        from oracle import oracle as _oracle
+        o_loss, _ = _oracle.average_distortion(edges.cpu().numpy(), X.cpu().numpy(),
+                                               _oracle.func("LOG1P", w.cpu().numpy(), None, (1.5,)), want_grad=False)
+        out["config"]["survey_seed"] = {"loss": gpu_loss, "oracle_loss": float(o_loss),
+                                        "rel_diff": abs(gpu_loss - float(o_loss)) / abs(float(o_loss))}
+        assert abs(float(o_loss) - gpu_loss) <= 1e-5 * abs(float(o_loss)), (o_loss, gpu_loss)
     if world == 1 and args.emulate_world <= 1 and not args.no_cpu_baseline and args.variant == "4a" and args.function == "log1p":
         cb, cpu_loss = cpu_baseline(edges, w, X, p)
         out["cpu_baseline"] = cb
@@ -480,6 +508,69 @@ def run_config5(args, device):
                              "%.1f GB per evaluation), so the attainable bound is the random-row gather rate "
                              "(tools/rowprobe: 7.4 TB/s from the 256 MB table) -> see row_gather_TBps"
                              % (gather_bytes / 1e9)},
+    }
+
+
+def run_config5_sharded(args, world, rank, device):
+    """BASELINE configs[4] on N GPUs (or rank 0 of an N-way shard on one GPU, --emulate-world): n = 500k, |E| = 20M,
+    d = 128, Log1p.  Uniform slice-major ownership (pymde_amd.distributed.ShardLayout): every rank evaluates its K
+    slices one after the other and the in-place all-gather of slice k travels under the kernel of slice k + 1."""
+    import pymde_amd
+    from pymde_amd import distributed
+    n, deg, d = 500_000, 40, 128
+    edges, w, _ = make_workload(device, n=n, deg=deg, d=2)
+    p = edges.shape[0]
+    torch.manual_seed(0)
+    X = pymde_amd.Standardized().initialization(n, d, device=device).contiguous()
+    W = world if world > 1 else args.emulate_world
+    layout = distributed.shard_layout(n, edges, W, d=d)
+    f = pymde_amd.penalties.Log1p(w)
+    ev = distributed.ShardedEvaluator(n, d, edges, f, layout, rank, W)
+    buf = torch.zeros(n * d + 1, dtype=torch.float32, device=device)
+
+    def step():
+        ev.evaluate(X, buf)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    block_s = timed_blocks(step, barrier, args.steps, max(args.blocks, 1), world, device)
+    elapsed = float(np.median(block_s))
+    # this rank's kernels alone (no exchange), HIP events around the K launches
+    shared = None
+
+    def local_only():
+        for k in range(len(ev.plans)):
+            ev._local(k, X, buf[:n * d].view(n, d), ev._lossvec[k:k + 1], shared)
+    k_ms, _ = time_launches(local_only, max(args.steps, 1), device)
+    per_rank = [k_ms]
+    if world > 1:
+        t = torch.zeros(world, dtype=torch.float64, device=device)
+        t[rank] = k_ms
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per_rank = [float(v) for v in t.cpu()]
+    if rank != 0:
+        return None
+    gather_bytes = 4.0 * n * d * (W - 1) / W
+    return {
+        "metric": "edges/sec/iter (avg_distortion fwd+bwd), n=500k |E|=20M d=128", "value": p * args.steps / elapsed,
+        "unit": "edges/s/iter", "n_gpus": max(world, 1), "steps": args.steps, "warmup": max(args.warmup, 2),
+        "ms_per_step": 1e3 * elapsed / args.steps, "blocks": len(block_s),
+        "ms_per_step_blocks": [round(1e3 * b / args.steps, 5) for b in block_s], "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[4] / SURVEY 8d config 5: n=%d, |E|=%d uniform-random edges (out-degree 40), "
+                               "d=128, penalties.Log1p(1.5), weights in {1,2}, X = Standardized().initialization" % (n, p),
+                   "parallelism": ("vertex-range shards x%d, %d slices per rank, exchange %s" % (world, max(layout.slices, 1), ev.mode))
+                   if world > 1 else "rank 0 of a %d-way shard, %d slices, kernels only (emulation, no collective)"
+                   % (W, max(layout.slices, 1)),
+                   "exchange": ev.mode if world > 1 else None, "slices": layout.slices,
+                   "kernel_ms_per_rank": per_rank,
+                   "all_gather_bytes_received_per_rank": gather_bytes,
+                   "loss": float(buf[n * d].item())},
     }
 
 
@@ -746,6 +837,9 @@ def main():
                     help="config 4 only: another distortion function on the same graph (secondary records)")
     ap.add_argument("--embed", action="store_true", help="configs 4 and 5: a full embed() at that shape (s/iter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--survey-seed", action="store_true",
+                    help="config 4: SURVEY 8d's exact numpy default_rng(0) / torch.manual_seed(0) workload, built on the "
+                         "host and uploaded; prints its loss next to the oracle's (the default line keeps the device generator)")
     ap.add_argument("--no-codebook", action="store_true",
                     help="stream the weights as fp32 (8 B/half-edge) even though they take 2 values")
     ap.add_argument("--n", type=int, default=N_ITEMS)
@@ -789,6 +883,8 @@ def main():
         out = run_config4_embed(args, device)
     elif args.config == 4:
         out = run_config4(args, world, rank, device)
+    elif args.config == 5 and (world > 1 or args.emulate_world > 1) and not args.embed:
+        out = run_config5_sharded(args, world, rank, device)
     elif world > 1:
         raise SystemExit("--config %d is a single-GPU record" % args.config)
     elif args.config == 5:

@@ -266,17 +266,22 @@ class _NativeProblem(object):
     def value_and_grad(self, X, project=True):
         from pymde_amd import average_distortion as ad
         e, lib = self.e, self.e.lib
-        if self.reducer is not None and getattr(self.reducer, "needs_zero", lambda: True)():
-            e.gbuf.zero_()  # (an all-gather exchange overwrites the other ranks' rows instead)
-        if self.binding.fused:
-            _lib.check(lib.mde_average_distortion(
-                self._plan_handle, e.p(X), e.d, self._fref, 1.0, e.p(e.g), e.p(e.loss_dev), e._stream))
+        if self.reducer is not None and hasattr(self.reducer, "evaluate"):
+            # sharded problem: the evaluator runs this rank's kernels and the exchange (slice by slice, the
+            # all-gather of one slice under the kernel of the next) and leaves [grad | loss] complete
+            self.reducer.evaluate(X, e.gbuf)
         else:
-            grad, value = ad._unfused(self.binding, X, True)
-            e.g.copy_(grad)
-            e.loss_dev.copy_(value.reshape(1))
-        if self.reducer is not None:
-            self.reducer(e.gbuf)
+            if self.reducer is not None and getattr(self.reducer, "needs_zero", lambda: True)():
+                e.gbuf.zero_()  # (an all-gather exchange overwrites the other ranks' rows instead)
+            if self.binding.fused:
+                _lib.check(lib.mde_average_distortion(
+                    self._plan_handle, e.p(X), e.d, self._fref, 1.0, e.p(e.g), e.p(e.loss_dev), e._stream))
+            else:
+                grad, value = ad._unfused(self.binding, X, True)
+                e.g.copy_(grad)
+                e.loss_dev.copy_(value.reshape(1))
+            if self.reducer is not None:
+                self.reducer(e.gbuf)
         if self.kind == "standardized":
             if project:
                 _lib.check(lib.mde_std_tangent(e.n, e.d, _lib.ptr(X), _lib.ptr(e.g), _lib.ptr(e.work),
@@ -351,11 +356,11 @@ def _make_problem(engine, objective_fn, constraint):
     if _is_native(objective_fn, constraint):
         reducer = getattr(owner, "_reducer", None)
         binding = owner._binding()
-        if reducer is not None and not binding.fused:
+        if reducer is not None and not binding.fused and not hasattr(reducer, "evaluate"):
             # the unfused path evaluates the full mean on every rank and fills only the owned
-            # gradient rows: the exchange would produce garbage (average_distortion raises too)
-            raise NotImplementedError("a sharded problem needs a built-in distortion function "
-                                      "(pymde_amd.penalties / pymde_amd.losses)")
+            # gradient rows: a bare exchange would produce garbage (ShardedEvaluator handles it)
+            raise NotImplementedError("a sharded problem with a plain exchange object needs a built-in distortion "
+                                      "function (pymde_amd.penalties / pymde_amd.losses)")
         return _NativeProblem(engine, binding, constraint, reducer)
     return _GenericProblem(engine, objective_fn, constraint)
 

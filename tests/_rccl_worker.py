@@ -48,14 +48,27 @@ def main():
     assert torch.equal(red(buf.clone()), buf)
 
     # a sharded solve whose every evaluation goes through the RCCL exchange == the plain solve
-    sharded = distributed.ShardedMDE(n, d, edges, pymde_amd.penalties.PushAndPull(torch.tensor(w, device=dev)),
-                                     constraint=pymde_amd.Centered(), device=dev)
-    sharded._reducer = distributed.GradExchange(n, d, sharded._bounds, 0, 1, force=True)
     Xs = single.embed(X=X0.clone(), max_iter=20).clone()
-    Xd = sharded.embed(X=X0.clone(), max_iter=20)
-    assert sharded._reducer.mode == "all_gather"
-    assert torch.equal(Xs, Xd), float((Xs - Xd).abs().max())
-    np.testing.assert_array_equal(sharded.solve_stats.average_distortions, single.solve_stats.average_distortions)
+    for slices in (1, 4):
+        sharded = distributed.ShardedMDE(n, d, edges, pymde_amd.penalties.PushAndPull(torch.tensor(w, device=dev)),
+                                         constraint=pymde_amd.Centered(), device=dev, slices=slices, force_exchange=True)
+        assert sharded._layout.slices == slices and len(sharded._reducer.plans) == slices
+        Xd = sharded.embed(X=X0.clone(), max_iter=20)
+        # (one slice: the in-place all-gather of GradExchange; four: the sliced gathers on the side stream, each
+        # behind its slice's kernel, with the loss share as a one-float all-reduce)
+        assert sharded._reducer.mode == "all_gather", (slices, sharded._reducer.mode)
+        if slices == 1:
+            assert torch.equal(Xs, Xd), float((Xs - Xd).abs().max())
+            np.testing.assert_array_equal(sharded.solve_stats.average_distortions, single.solve_stats.average_distortions)
+        else:
+            # (the loss is the fp32 sum of four slice shares: last bits; the gradient is bit-equal)
+            xs = X0.clone().requires_grad_(True)
+            single.average_distortion(xs).backward()
+            xd = X0.clone().requires_grad_(True)
+            sharded.average_distortion(xd).backward()
+            assert torch.equal(xs.grad, xd.grad)
+            np.testing.assert_allclose(sharded.solve_stats.average_distortions[:3],
+                                       single.solve_stats.average_distortions[:3], rtol=1e-5)
     torch.cuda.synchronize()
     print("rccl single-rank ok")
     dist.destroy_process_group()

@@ -145,3 +145,59 @@ def test_bench_refuses_more_ranks_than_gpus():
                          capture_output=True, text=True, timeout=300)
     assert out.returncode != 0
     assert "needs 64 visible GPUs" in (out.stderr + out.stdout)
+
+
+def _sliced_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pymde_amd import distributed
+    # the uniform slice-major layout: rank r owns range r of every slice; the slices' in-place all-gathers
+    # (issued one by one, as the evaluator does behind each slice's kernel) assemble the full [n, d] rows
+    n, d, K = 48, 128, 4
+    lay = distributed.ShardLayout.uniform(n, world, K)
+    assert lay.slices == K and lay.bounds is None
+    m = n // (world * K)
+    assert lay.ranges[rank] == [((k * world + rank) * m, (k * world + rank + 1) * m) for k in range(K)]
+    covered = sorted(r for rr in lay.ranges for r in rr)
+    assert covered[0][0] == 0 and covered[-1][1] == n and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    full = torch.arange(n * d, dtype=torch.float32) * 0.25 - 100.0
+    buf = torch.full((n * d + 1,), float("nan"))
+    for lo, hi in lay.ranges[rank]:
+        buf[lo * d:hi * d] = full[lo * d:hi * d]
+    buf[n * d] = float(rank + 1)
+    handles = [distributed.gather_slice(buf, n, d, world, K, k, rank) for k in range(K)]
+    h = dist.all_reduce(buf[n * d:n * d + 1], op=dist.ReduceOp.SUM, async_op=True)
+    for w in handles:
+        w.wait()
+    h.wait()
+    assert torch.equal(buf[:n * d], full)
+    assert float(buf[n * d]) == float(sum(range(1, world + 1)))
+    # K = 1 of the uniform layout carries bounds (the one-range exchange object takes it)
+    one = distributed.ShardLayout.uniform(n, world, 1)
+    assert one.bounds == [r * (n // world) for r in range(world + 1)] and one.slices == 1
+    skew = distributed.ShardLayout.from_bounds(n, world, [0, 10, n])
+    assert skew.slices == 0 and skew.ranges[1] == [(10, n)]
+    # slices by size: one below 8 MB per rank, four above; the environment overrides
+    assert distributed.default_slices(1_000_000, 2, 8) == 1 and distributed.default_slices(500_000, 128, 8) == 4
+    os.environ["MDE_SHARD_SLICES"] = "2"
+    assert distributed.default_slices(1_000_000, 2, 8) == 2
+    os.environ.pop("MDE_SHARD_SLICES")
+    ret[rank] = 1
+    dist.destroy_process_group()
+
+
+def test_sliced_in_place_all_gather_two_gloo_ranks():
+    """The chunked exchange of the uniform slice-major layout (round 5), world_size 2 on gloo."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sliced_worker, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert ret[0] == 1 and ret[1] == 1
