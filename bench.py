@@ -408,6 +408,18 @@ def run_config4(args, world, rank, device):
         out["config"]["fp32_parameter_stream"] = {
             "kernel_ms": k2, "value": p / (k2 * 1e-3), "unit": "edges/s/iter (kernel time)",
             "roofline_frac": alg_bytes / (k2 * 1e-3) / HBM_PEAK_BPS}
+        # ... and 40 distinct values (the hop counts of a distance problem on a graph are tens of distinct integers)
+        # an index byte per half-edge beside the packed word: 5 B/half-edge
+        del b2
+        g40 = torch.Generator(device=device).manual_seed(3)
+        w40 = 1.0 + torch.randint(0, 40, (p,), device=device, generator=g40).float() / 40.0
+        b3 = Binding(plan, pymde_amd.penalties.Log1p(w40))
+        fused_evaluate(b3, X, grad, loss)
+        k3, _ = time_launches(lambda: fused_evaluate(b3, X, grad, loss), max(args.steps, 1), device)
+        out["config"]["byte_index_parameter_stream"] = {
+            "distinct_values": 40, "stream": b3.stream_kind, "kernel_ms": k3, "value": p / (k3 * 1e-3),
+            "unit": "edges/s/iter (kernel time)", "roofline_frac": alg_bytes / (k3 * 1e-3) / HBM_PEAK_BPS}
+        del b3
     if args.survey_seed and world == 1 and args.variant == "4a" and args.function == "log1p":
         # the loss of the survey's exact workload next to the oracle's (the OpenMP restatement on the same tensors)
         from oracle import oracle as _oracle
@@ -779,7 +791,9 @@ def run_embed_config(args, device, which):
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": label, "n_items": int(mde.n_items), "edges": p, "problem_build_s": build_s,
                    "edges_per_s_per_iter": p * n_it / dt, "kernel_layout": "LDS ring" if layout == 1 else "CSR",
-                   "parameter_stream": "codebook" if mde._binding().codebook else "fp32",
+                   "parameter_stream": mde._binding().stream_kind,
+                   "distinct_parameter_values": int(torch.unique(next(iter(mde.distortion_function.buffers()))).numel())
+                   if hasattr(mde.distortion_function, "buffers") and list(mde.distortion_function.buffers()) else None,
                    "functor": functor, "final_average_distortion": float(mde.value)},
     }
 

@@ -124,7 +124,8 @@ typedef struct mde_func {
   const float* a0;   /* device; per-edge weights / deviations.  Order: see each call      */
   const float* a1;   /* device; second per-edge array (weighted losses) or NULL           */
   int32_t a0_scalar; /* 1: a0 points at ONE value broadcast to every edge (nelement()==1);
-                        2: a0 is a codebook stream written by mde_plan_expand_codebook (layout 1) */
+                        2: a0 is a codebook stream written by mde_plan_expand_codebook (layout 1);
+                        3: a0 is a byte-index stream written by mde_plan_expand_bytes (layout 1)  */
   int32_t a1_scalar;
   float s0, s1, s2;  /* scalars of `kind`                                                 */
   float n0, n1, n2;  /* scalars of `kind_neg`                                             */
@@ -192,6 +193,17 @@ int64_t mde_plan_layout_half_edges(const mde_plan* plan, int32_t layout);
  * fix-up of f'/d for codebook streams).  Results are identical either way.  SYNC. */
 int mde_plan_expand_codebook(const mde_plan* plan, const float* in_edge, float* out_half,
                              int32_t* n_values_host, void* stream);
+/* Byte-index parameter stream for layout 1 at d = 2 and d = 3: when `in_edge` [p] holds at most 255 distinct
+ * values (the hop-count deviations of preserve_distances on a graph [ref: pymde/recipes.py:194-215,
+ * preprocess/graph.py:402-474], quantised weights) write to out_half [mde_plan_layout_half_edges(plan, 1)
+ * floats of space] one index BYTE per entry of the layout (in the order of the packed half-edge words),
+ * followed at byte offset H by the 256-entry value table (entry 0 = 0.0, the weight of padding lanes; entries
+ * 1..n the values in ascending bit order), and set *n_values_host = n; the fused kernel then streams 5 instead
+ * of 8 bytes per half-edge and keeps the table in LDS (mde_func.a0 = out_half, a0_scalar = 3).
+ * *n_values_host = 0: not applicable (more values, a NaN / infinite / > 1e6 value, a layout without 1 KB of LDS
+ * behind its chunk ring) -- use mde_plan_expand_layout.  Results are identical either way.  SYNC. */
+int mde_plan_expand_bytes(const mde_plan* plan, const float* in_edge, float* out_half,
+                          int32_t* n_values_host, void* stream);
 int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in_edge,
                            float* out_half, void* stream);
 

@@ -59,6 +59,7 @@ SYMBOLS = {
     "mde_plan_layout": (c_i32, [c_vp, c_i32, c_vp]),
     "mde_plan_layout_half_edges": (c_i64, [c_vp, c_i32]),
     "mde_plan_expand_codebook": (c_i32, [c_vp, c_vp, c_vp, ctypes.POINTER(c_i32), c_vp]),
+    "mde_plan_expand_bytes": (c_i32, [c_vp, c_vp, c_vp, ctypes.POINTER(c_i32), c_vp]),
     "mde_plan_expand_layout": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp]),
     "mde_edges_deduplicate": (c_i32, [c_i64, c_i64, c_vp, c_vp, ctypes.POINTER(c_i64), c_vp]),
     "mde_edges_count_unique": (c_i32, [c_i64, c_i64, c_vp, c_vp, c_vp, ctypes.POINTER(c_i64), c_vp]),

@@ -103,6 +103,21 @@ class EdgePlan(object):
                                                     ctypes.byref(nv), _lib.stream_ptr(self.device)))
         return out if nv.value > 0 else None
 
+    def expand_bytes(self, per_edge):
+        """Layout 1 only: the byte-index form of a per-edge array with at most 255 distinct values
+        (``mde_plan_expand_bytes``), or None when it does not apply."""
+        lib = _lib.load()
+        t = per_edge.detach().to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
+        if t.numel() != self.p:
+            return None
+        size = int(lib.mde_plan_layout_half_edges(self._handle, 1))
+        out = torch.empty(max(size, 1), dtype=torch.float32, device=self.device)
+        nv = ctypes.c_int32(0)
+        with torch.cuda.device(self.device):
+            _lib.check(lib.mde_plan_expand_bytes(self._handle, _lib.ptr(t), _lib.ptr(out),
+                                                 ctypes.byref(nv), _lib.stream_ptr(self.device)))
+        return out if nv.value > 0 else None
+
     def csr(self):
         """(rowptr, nbr, eid) as int32 tensors (copies; for tests and debugging)."""
         lib = _lib.load()
@@ -136,6 +151,8 @@ class Binding(object):
         self._keep = None
         self._key = None
         self.codebook = False
+        self.byte_stream = False
+        self.stream_kind = None
 
     @property
     def fused(self):
@@ -169,6 +186,11 @@ class Binding(object):
             if layout == 1 and spec.a0 is not None and spec.a0.numel() > 1:
                 a0 = plan.expand_codebook(spec.a0)
             self.codebook = a0 is not None
+            # ... up to 255: one index byte per entry beside the packed words, 5 bytes (hop-count deviations)
+            self.byte_stream = False
+            if a0 is None and layout == 1 and spec.a0 is not None and spec.a0.numel() > 1:
+                a0 = plan.expand_bytes(spec.a0)
+                self.byte_stream = a0 is not None
             if a0 is None:
                 a0 = prep(spec.a0)
             a1 = prep(spec.a1)
@@ -176,6 +198,10 @@ class Binding(object):
             self._struct = spec.to_struct(a0, a1)
             if self.codebook:
                 self._struct.a0_scalar = 2
+            elif self.byte_stream:
+                self._struct.a0_scalar = 3
+            self.stream_kind = ("codebook" if self.codebook else "byte index" if self.byte_stream else
+                                "scalar" if (spec.a0 is not None and spec.a0.numel() == 1) else "fp32")
             self._struct.layout = layout
             self._key = key
             self.spec = spec

@@ -18,7 +18,10 @@
 // the whole table past its rows -- is what the kernel's duration followed), which leaves ~36 KB of
 // ring at d = 2; the chunks in flight therefore live in the producers' VGPRs, not in ring slots.
 #define MDE_RING_LDS_BYTES 163840
-__host__ __device__ constexpr int ring_row_cap(int d) { return d == 1 ? 12288 : (d == 2 ? 7872 : (d == 3 ? 5216 : 3936)); }
+// (round 5: 7816 / 5200 rows at d = 2 / 3 instead of 7872 / 5216 -- 1M rows are still 128 blocks at d = 2, evenly
+// filled now (127 x 7872 left a last block of 256 rows), and the 1 KB this frees behind the ring holds the
+// 256-entry value table of the byte-index parameter stream)
+__host__ __device__ constexpr int ring_row_cap(int d) { return d == 1 ? 12288 : (d == 2 ? 7816 : (d == 3 ? 5200 : 3936)); }
 __host__ __device__ constexpr int ring_ctrl_off(int d) { return (ring_row_cap(d) + 32) * 4 * d; }
 __host__ __device__ constexpr int ring_gr_off(int d) { return ring_ctrl_off(d) + 256; }
 #define MDE_RING_CTRL_PROG(d) (ring_ctrl_off(d))        // int prog[16]: oldest chunk consumer w still reads
@@ -53,6 +56,7 @@ __host__ __device__ constexpr int ring_gr_off(int d) { return ring_ctrl_off(d) +
 #define MDE_RING_PFB 3             // stream blocks (4 iterations each) in flight per consumer wave
 #endif
 #define MDE_RING_CB_VALUES 8
+#define MDE_RING_BX_VALUES 256      // entries of the byte-index stream's value table (entry 0 = the padding lanes' weight 0)
 #ifndef MDE_RING_ABLATE
 #define MDE_RING_ABLATE 0
 #endif

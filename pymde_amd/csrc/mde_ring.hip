@@ -1224,6 +1224,159 @@ extern "C" int mde_plan_expand_codebook(const mde_plan* plan, const float* in_ed
   return MDE_OK;
 }
 
+// ---------------------------------------------------------------- byte-index parameter streams
+// Up to 255 distinct per-edge parameters (the hop counts of a distance-preserving problem on a graph are tens of
+// distinct integers; quantised similarity weights): one index BYTE per entry beside the packed words -- 5 B per
+// half-edge instead of 8 -- and a 256-entry value table that the kernel keeps in the 1 KB behind its chunk ring.
+// The distinct bit patterns are collected in a hash table (per workgroup in LDS first, the winners carried to the
+// global one), the host sorts them (canonical order: ascending bit patterns, entry 0 = the padding lanes' +0.0),
+// and k_bytes_pack looks every entry's value up by bisection.
+#define MDE_BX_SLOTS 1024  // hash slots (a power of two, >= 4 x the values a table holds)
+__device__ __forceinline__ uint32_t bx_hash(uint32_t v) {
+  v ^= v >> 16;
+  v *= 0x7feb352du;
+  v ^= v >> 15;
+  v *= 0x846ca68bu;
+  v ^= v >> 16;
+  return v & (MDE_BX_SLOTS - 1);
+}
+// insert v into an open-addressing table; returns 1 when v was not there before, 0 when it was, -1 when the table is full
+__device__ __forceinline__ int bx_insert(unsigned int* tb, uint32_t v) {
+  uint32_t h = bx_hash(v);
+  for (int probe = 0; probe < MDE_BX_SLOTS; ++probe) {
+    const unsigned int old = atomicCAS(&tb[h], MDE_CB_EMPTY, v);
+    if (old == MDE_CB_EMPTY) return 1;
+    if (old == v) return 0;
+    h = (h + 1) & (MDE_BX_SLOTS - 1);
+  }
+  return -1;
+}
+// state[0] = number of distinct values in the global table, state[1] = overflow flag
+__global__ __launch_bounds__(MDE_BLOCK) void k_bytes_scan(int64_t p, const float* __restrict__ in,
+                                                          unsigned int* __restrict__ table, int* __restrict__ state) {
+  __shared__ unsigned int stb[MDE_BX_SLOTS];
+  __shared__ int s_count;
+  for (int i = threadIdx.x; i < MDE_BX_SLOTS; i += MDE_BLOCK) stb[i] = MDE_CB_EMPTY;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  unsigned int last0 = MDE_CB_EMPTY, last1 = MDE_CB_EMPTY;
+  const int64_t stride = (int64_t)gridDim.x * MDE_BLOCK;
+  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < p; i += stride) {
+    // (continuous weights: some workgroup sees its 256th value within its first few elements -- everybody leaves)
+    if (__hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const unsigned int v = __float_as_uint(in[i]);
+    if (v == last0 || v == last1) continue;
+    last1 = last0;
+    last0 = v;
+    if (v == MDE_CB_EMPTY) {  // (the pattern that marks a free slot: a NaN, no table)
+      state[1] = 1;
+      return;
+    }
+    const int fresh = bx_insert(stb, v);
+    if (fresh == 0) continue;  // some thread of this workgroup has carried it already
+    if (fresh < 0 || atomicAdd(&s_count, 1) >= MDE_RING_BX_VALUES - 1) {
+      state[1] = 1;
+      return;
+    }
+    const int g = bx_insert(table, v);
+    if (g < 0 || (g == 1 && atomicAdd(&state[0], 1) >= MDE_RING_BX_VALUES - 1)) {
+      state[1] = 1;
+      return;
+    }
+  }
+}
+
+// out[q] = index of in[eid[q]] in the sorted table (entries 1..nv; padding entries keep index 0)
+__global__ __launch_bounds__(MDE_BLOCK) void k_bytes_pack(int64_t H, const int32_t* __restrict__ eid,
+                                                          const float* __restrict__ in,
+                                                          const unsigned int* __restrict__ table, int nv,
+                                                          uint8_t* __restrict__ out) {
+  __shared__ unsigned int tb[MDE_RING_BX_VALUES];
+  for (int i = threadIdx.x; i < MDE_RING_BX_VALUES; i += MDE_BLOCK) tb[i] = table[i];
+  __syncthreads();
+  for (int64_t q = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; q < H; q += (int64_t)gridDim.x * MDE_BLOCK) {
+    uint32_t idx = 0;
+    if (eid[q] >= 0) {
+      const unsigned int v = __float_as_uint(in[eid[q]]);
+      int lo = 1, hi = nv;  // tb[1..nv] ascending, v is one of them
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (tb[mid] < v) lo = mid + 1; else hi = mid;
+      }
+      idx = (uint32_t)lo;
+    }
+    out[q] = (uint8_t)idx;
+  }
+}
+
+// Try to put a per-edge parameter array into byte-index form for layout 1 (d = 2, 3).  On success
+// (*n_values_host in 1..255) out_half holds the H index bytes (in the order of the packed words: one 32-bit word
+// per lane and block of four iterations) followed by the 256-entry value table; pass it as mde_func.a0 with
+// a0_scalar = 3.  *n_values_host = 0: not applicable (another d, more distinct values, NaNs, values beyond 1e6,
+// no room behind the ring) -- nothing usable is written and the caller streams fp32.  SYNC.
+extern "C" int mde_plan_expand_bytes(const mde_plan* plan, const float* in_edge, float* out_half,
+                                     int32_t* n_values_host, void* stream) {
+  if (!plan || !in_edge || !out_half || !n_values_host) return MDE_E_INVALID;
+  *n_values_host = 0;
+  const mde_ring_layout& L = plan->ring;
+  if (!L.packed || (L.d != 2 && L.d != 3) || L.H < 4 * MDE_RING_BX_VALUES || plan->p == 0) return MDE_OK;
+  if (MDE_RING_LDS_BYTES - (L.ring_off + L.slots * ring_chunk_bytes(L.d)) < 4 * MDE_RING_BX_VALUES) return MDE_OK;
+  const char* e = getenv("MDE_BYTE_STREAM");
+  if (e && atoi(e) == 0) return MDE_OK;
+  hipStream_t st = mde_stream(stream);
+  unsigned int* dtable = nullptr;
+  int* dstate = nullptr;
+  MDE_HIP(hipMalloc(&dtable, MDE_BX_SLOTS * sizeof(unsigned int) + 2 * sizeof(int)));
+  dstate = reinterpret_cast<int*>(dtable + MDE_BX_SLOTS);
+  hipError_t err = hipMemsetAsync(dtable, 0xFF, MDE_BX_SLOTS * sizeof(unsigned int), st);
+  if (err == hipSuccess) err = hipMemsetAsync(dstate, 0, 2 * sizeof(int), st);
+  std::vector<unsigned int> host_tb(MDE_BX_SLOTS);
+  int host_state[2] = {0, 0};
+  if (err == hipSuccess) {
+    hipLaunchKernelGGL(k_bytes_scan, dim3(mde_grid(plan->p, MDE_BLOCK, 2048)), dim3(MDE_BLOCK), 0, st, plan->p, in_edge, dtable,
+                       dstate);
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipMemcpyAsync(host_tb.data(), dtable, MDE_BX_SLOTS * sizeof(unsigned int), hipMemcpyDeviceToHost, st);
+  if (err == hipSuccess) err = hipMemcpyAsync(host_state, dstate, sizeof(host_state), hipMemcpyDeviceToHost, st);
+  if (err == hipSuccess) err = hipStreamSynchronize(st);
+  if (err != hipSuccess) {
+    (void)hipFree(dtable);
+    return mde_hip_fail(err, "byte-index stream: value scan", __FILE__, __LINE__);
+  }
+  std::vector<unsigned int> vals;
+  if (!host_state[1])
+    for (unsigned int v : host_tb)
+      if (v != MDE_CB_EMPTY) vals.push_back(v);
+  bool ok = !host_state[1] && !vals.empty() && (int)vals.size() <= MDE_RING_BX_VALUES - 1;
+  // (finite values of ordinary size only, as for the codebook: the kernel skips the NaN / Inf fix-up of f'/d)
+  for (size_t i = 0; ok && i < vals.size(); ++i) {
+    float fv;
+    memcpy(&fv, &vals[i], sizeof(float));
+    if (!std::isfinite(fv) || std::fabs(fv) > 1.0e6f) ok = false;
+  }
+  if (!ok) {
+    (void)hipFree(dtable);
+    return MDE_OK;
+  }
+  std::sort(vals.begin(), vals.end());
+  const int nv = (int)vals.size();
+  std::vector<unsigned int> tb(MDE_RING_BX_VALUES, 0u);  // entry 0 = +0.0f (padding lanes), unused entries 0 too
+  for (int i = 0; i < nv; ++i) tb[1 + i] = vals[i];
+  unsigned int* table = reinterpret_cast<unsigned int*>(out_half) + L.H / 4;  // behind the H index bytes
+  err = hipMemcpyAsync(table, tb.data(), MDE_RING_BX_VALUES * sizeof(unsigned int), hipMemcpyHostToDevice, st);
+  if (err == hipSuccess) {
+    hipLaunchKernelGGL(k_bytes_pack, dim3(mde_grid(L.H, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, L.H, L.eid, in_edge, table, nv,
+                       reinterpret_cast<uint8_t*>(out_half));
+    err = hipGetLastError();
+  }
+  if (err == hipSuccess) err = hipStreamSynchronize(st);  // (`tb` is a host buffer)
+  (void)hipFree(dtable);
+  if (err != hipSuccess) return mde_hip_fail(err, "byte-index stream: pack", __FILE__, __LINE__);
+  *n_values_host = nv;
+  return MDE_OK;
+}
+
 extern "C" int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in_edge,
                                       float* out_half, void* stream) {
   if (!plan || !in_edge || !out_half) return MDE_E_INVALID;

@@ -134,11 +134,15 @@ static __device__ int g_ring_ndiag;
 // The loss term of an edge is added on ONE of its two entries (the one whose row is the smaller
 // vertex; the header says, per block of four iterations, none / all / test per lane), so half of the
 // blocks skip the loss arithmetic altogether; the gradient is owner-computes as before.
-template <int D, class Fn, bool HAS_GRAD, bool CB, bool LIN>
+// PS, the form of the first parameter: 0 = an fp32 array next to the packed words (or one scalar), 1 = codebook
+// (value index in the packed word's spare bits, <= 7 / 3 values), 2 = byte index (one byte per entry beside the
+// packed words -- 5 B per half-edge --, a 256-entry value table in the 1 KB behind the ring; round 5: the hop
+// counts of a distance-preserving problem on a graph are tens of distinct integers, which streamed 8 B until now)
+template <int D, class Fn, bool HAS_GRAD, int PS, bool LIN>
 __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     int nloc, int row_lo, int n, int R, int Q, int NC, int ring_off, int S, const int32_t* __restrict__ wave_iter,
-    const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ packed, const float* __restrict__ a0,
-    const float* __restrict__ a1, int a0_scalar, int a1_scalar, const float* __restrict__ X,
+    const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ packed, const uint32_t* __restrict__ bidx,
+    const float* __restrict__ a0, const float* __restrict__ a1, int a0_scalar, int a1_scalar, const float* __restrict__ X,
     float* __restrict__ grad, float* __restrict__ partial, double* __restrict__ loss_partials, Fn fn,
     float fix_value, float grad_scale, float* __restrict__ loss_out, double loss_scale, int fold, int dbg_arg) {
 #if MDE_RING_ABLATE
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
   constexpr int dbg = 0;
 #endif
   constexpr int BS = MDE_RING_BS, NCW = MDE_RING_NCW, NPROD = MDE_RING_NPROD;
+  constexpr bool CB = PS == 1, BX = PS == 2;
   constexpr int GR_OFF = ring_gr_off(D), CTRL_PROG = MDE_RING_CTRL_PROG(D), CTRL_F = MDE_RING_CTRL_F(D), CTRL_CB = MDE_RING_CTRL_CB(D);
   constexpr int C = ring_chunk_cols(D), CBYTES = ring_chunk_bytes(D), PIECES = CBYTES / 1024;
   static_assert(GR_OFF + (ring_row_cap(D) + 32) * 4 * D <= 65536 + GR_OFF && GR_OFF < 65536 && CTRL_CB + 32 < 65536,
@@ -167,7 +172,8 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
   const int r0 = rb * R;
   const int nr = min(R, nloc - r0);
   const uint32_t dummy_row = (uint32_t)R * 4u * (uint32_t)D;  // the padding lanes' row slots start here
-  const float a0s = (a0_scalar && !CB) ? a0[0] : 1.0f;
+  const float a0s = (a0_scalar && PS == 0) ? a0[0] : 1.0f;
+  const uint32_t tab_off = (uint32_t)ring_off + (uint32_t)S * (uint32_t)CBYTES;  // (BX: the value table behind the ring)
   const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
   const bool a1_arr = a1 && !a1_scalar;
   // ---- prologue: accumulators, x_v, control words
@@ -200,6 +206,8 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     if (tid == 16) F[0] = j_lo;  // LANDED: every chunk below this is in its ring slot
     if (CB && tid >= 32 && tid < 32 + MDE_RING_CB_VALUES)
       reinterpret_cast<float*>(L + CTRL_CB)[tid - 32] = a0[tid - 32] * Fn::kParamScale;
+    if (BX && tid >= 64 && tid < 64 + MDE_RING_BX_VALUES)
+      reinterpret_cast<float*>(L + tab_off)[tid - 64] = a0[tid - 64] * Fn::kParamScale;
   }
   __syncthreads();
   float loss = 0.0f, loss2 = 0.0f;  // (the fused Log1p path keeps the log2 terms and the corrections apart)
@@ -370,7 +378,8 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     const int ib = __builtin_amdgcn_readfirstlane(wave_iter[blockIdx.x * NCW + wave]);
     const int NB = (__builtin_amdgcn_readfirstlane(wave_iter[blockIdx.x * NCW + wave + 1]) - ib) >> 2;
     if (NB > 0 && !(dbg & 64)) {
-      const bool a0_arr = !a0_scalar && !CB;
+      const bool a0_arr = !a0_scalar && PS == 0;
+      const uint32_t* bp = BX ? bidx + (size_t)(ib >> 2) * 64 + lane : nullptr;
       const ring_u4* sp = reinterpret_cast<const ring_u4*>(packed) + (size_t)(ib >> 2) * 64 + lane;
       const ring_f4* ap = reinterpret_cast<const ring_f4*>(a0_arr ? a0 : reinterpret_cast<const float*>(packed)) +
                           (size_t)(ib >> 2) * 64 + lane;
@@ -389,6 +398,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       ring_u4 pq[PFB] = {};
       uint32_t hv[PFB] = {};
       ring_f4 wq[PFB] = {};
+      uint32_t bq[PFB] = {};  // (BX: the value indices of a block's four iterations, one byte each)
       const uint32_t* hvp = hdr + (size_t)ib * MDE_RING_HW + (lane & 15);
       auto load_block = [&](int u, int b) __attribute__((always_inline)) {
         const int bc = min(b, lastb);
@@ -400,7 +410,8 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         pq[u] = sp[(size_t)bc * 64];
 #endif
         hv[u] = hvp[(size_t)bc * 16];
-        if (!CB) wq[u] = ap[(size_t)bc * 64];
+        if (PS == 0) wq[u] = ap[(size_t)bc * 64];
+        if (BX) bq[u] = bp[(size_t)bc * 64];
       };
 #if MDE_RING_ABLATE
       unsigned long long cs_t0 = RING_CLK(), cs_poll = 0, cs_trips = 0;
@@ -415,14 +426,19 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       auto col_of = [&](uint32_t w) __attribute__((always_inline)) {
         return D == 2 ? ((w >> 13) & 0x3fff8u) : ((w >> 14) & 0x3fffcu);
       };
-      auto issue_x = [&](uint32_t w, float p0) __attribute__((always_inline)) {
+      auto issue_x = [&](uint32_t w, float p0, uint32_t bi4) __attribute__((always_inline)) {
         Pre r;
-        // (codebook index: the bits the row address leaves free -- 3 at d = 2, 2 at d = 3)
-        r.p0 = CB ? *reinterpret_cast<const float*>(L + CTRL_CB + ((w & (D == 2 ? 7u : 3u)) << 2)) : p0 * Fn::kParamScale;
+        // (codebook index: the bits the row address leaves free -- 3 at d = 2, 2 at d = 3; byte index: bi4 = 4 x index)
+        if constexpr (BX)
+          r.p0 = *reinterpret_cast<const float*>(L + tab_off + bi4);
+        else
+          r.p0 = CB ? *reinterpret_cast<const float*>(L + CTRL_CB + ((w & (D == 2 ? 7u : 3u)) << 2)) : p0 * Fn::kParamScale;
         ring_ld_operand<D>(L, row_of(w), r.xr);
         ring_ld_operand<D>(L, col_of(w), r.xc);
         return r;
       };
+      // 4 x the value index of iteration q of a block (byte q of the block's index word)
+      auto bx4 = [&](uint32_t bw, int q) __attribute__((always_inline)) { return BX ? ((bw >> (8 * q)) & 0xffu) << 2 : 0u; };
       // this entry adds the loss term iff its row is the smaller vertex (blocks around the diagonal)
       auto counts_here = [&](uint32_t w, uint32_t hm) __attribute__((always_inline)) {
         const uint32_t off = col_of(w) - (uint32_t)ring_off;
@@ -484,7 +500,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         }
         if (!HAS_GRAD) return;
         // (codebook values are finite -- mde_plan_expand_codebook refuses others)
-        const float g = (Fn::kFiniteG && CB) ? gd : mde_fix_g_to(gd, fix_value);
+        const float g = (Fn::kFiniteG && PS != 0) ? gd : mde_fix_g_to(gd, fix_value);
 #pragma unroll
         for (int c = 0; c < D; ++c) acc[c] = fmaf(v[c], g, acc[c]);
         ring_st<D>(L + GR_OFF + rowaddr, acc);
@@ -579,8 +595,8 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           // the last block: resident chunks, harmless reads, nothing new published
           const int un = h == 0 ? u : (u + 1) % PFB, qn = (q + 2) & 3;
           wait_pair(un, qn);
-          const Pre xna = issue_x(pq[un][qn], (a0_scalar || CB) ? a0s : wq[un][qn]);
-          const Pre xnb = issue_x(pq[un][qn + 1], (a0_scalar || CB) ? a0s : wq[un][qn + 1]);
+          const Pre xna = issue_x(pq[un][qn], (a0_scalar || PS != 0) ? a0s : wq[un][qn], bx4(bq[un], qn));
+          const Pre xnb = issue_x(pq[un][qn + 1], (a0_scalar || PS != 0) ? a0s : wq[un][qn + 1], bx4(bq[un], qn + 1));
           release_to((u + 1) % PFB, q);  // (the pair after that one: next block, same slot)
           prefetch_landed();
           const float p1a = a1_arr ? a1[((size_t)((ib >> 2) + b) * 64 + lane) * 4 + q] : a1s;
@@ -600,8 +616,8 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       for (int u = 0; u < PFB; ++u) load_block(u, u);
       release_to(0, 0);  // (a sparse stream may begin chunks after j_lo: the producers must know before this wave waits)
       wait_pair(0, 0);
-      xa = issue_x(pq[0][0], (a0_scalar || CB) ? a0s : wq[0][0]);
-      xb = issue_x(pq[0][1], (a0_scalar || CB) ? a0s : wq[0][1]);
+      xa = issue_x(pq[0][0], (a0_scalar || PS != 0) ? a0s : wq[0][0], bx4(bq[0], 0));
+      xb = issue_x(pq[0][1], (a0_scalar || PS != 0) ? a0s : wq[0][1], bx4(bq[0], 1));
       release_to(0, 2);
       prefetch_landed();
       if (HAS_GRAD) ring_ld<D>(L + GR_OFF + row_of(pq[0][0]), acc);
@@ -773,9 +789,13 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_combine(int64_t m, int Q, co
 template <int D, class Fn, bool LIN>
 static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
   const mde_ring_layout& L = A.plan->ring;
-  const bool cb = A.a0_scalar == 2;
-  if (cb && D != 2 && D != 3) {
-    mde_set_error("codebook parameter streams exist for d = 2 and d = 3 only");
+  const bool cb = A.a0_scalar == 2, bx = A.a0_scalar == 3;
+  if ((cb || bx) && D != 2 && D != 3) {
+    mde_set_error("codebook / byte-index parameter streams exist for d = 2 and d = 3 only");
+    return MDE_E_INVALID;
+  }
+  if (bx && MDE_RING_LDS_BYTES - (L.ring_off + L.slots * ring_chunk_bytes(D)) < 4 * MDE_RING_BX_VALUES) {
+    mde_set_error("byte-index parameter stream: no room for the value table behind the ring");
     return MDE_E_INVALID;
   }
   if (reinterpret_cast<uintptr_t>(A.X) & 15) {
@@ -786,13 +806,15 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
     // one scalar parameter for every edge: padding lanes would carry it too -- mask them instead
     if (A.a0_scalar == 1) return launch_ring<D, Fn, false>(A, fn, nblocks);
   }
-  auto kern = A.grad ? k_fused_ring<D, Fn, true, false, LIN> : k_fused_ring<D, Fn, false, false, LIN>;
+  auto kern = A.grad ? k_fused_ring<D, Fn, true, 0, LIN> : k_fused_ring<D, Fn, false, 0, LIN>;
   if constexpr (D == 2 || D == 3) {
-    if (cb) kern = A.grad ? k_fused_ring<D, Fn, true, true, LIN> : k_fused_ring<D, Fn, false, true, LIN>;
+    if (cb) kern = A.grad ? k_fused_ring<D, Fn, true, 1, LIN> : k_fused_ring<D, Fn, false, 1, LIN>;
+    if (bx) kern = A.grad ? k_fused_ring<D, Fn, true, 2, LIN> : k_fused_ring<D, Fn, false, 2, LIN>;
   }
-  // codebook form: a0 = [H packed words | 8 values]
+  // codebook form: a0 = [H packed words | 8 values]; byte-index form: a0 = [H index bytes | 256 values]
   const uint32_t* stream = cb ? reinterpret_cast<const uint32_t*>(A.a0) : L.packed;
-  const float* a0 = cb ? A.a0 + L.H : A.a0;
+  const uint32_t* bidx = bx ? reinterpret_cast<const uint32_t*>(A.a0) : nullptr;
+  const float* a0 = cb ? A.a0 + L.H : (bx ? A.a0 + L.H / 4 : A.a0);
   const int Q = L.col_groups;
   *nblocks = L.n_row_blocks * Q;
   // the accumulators hold sum f'/d (x_v - x_u); 1/p is applied with the output scale (the
@@ -810,7 +832,7 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
   // (every edge adds its loss term once here, not once per endpoint: twice the caller's scale)
   hipLaunchKernelGGL(kern, dim3(L.n_row_blocks * Q), dim3(MDE_RING_BS), 0, A.st,
                      (int)(A.plan->row_hi - A.plan->row_lo), (int)A.plan->row_lo, (int)A.plan->n,
-                     L.rows_per_block, Q, L.n_chunks, L.ring_off, L.slots, L.wave_iter, L.hdr, stream, a0, A.a1, A.a0_scalar,
+                     L.rows_per_block, Q, L.n_chunks, L.ring_off, L.slots, L.wave_iter, L.hdr, stream, bidx, a0, A.a1, A.a0_scalar,
                      A.a1_scalar, A.X, A.grad, L.partial, A.plan->partials, fn, fix_value, out_scale,
                      A.loss_out, 2.0 * A.loss_scale, fold, dbg);
   MDE_LAUNCH_CHECK();

@@ -335,6 +335,35 @@ def _ring_full_size_case(n, deg, d, make_f, oracle_func, runs=3):
     return b
 
 
+@pytest.mark.parametrize("ndist,d", [(40, 2), (200, 2), (255, 3)])
+def test_byte_index_parameter_stream_full_size(ndist, d):
+    """The byte-index parameter stream (round 5; <= 255 distinct per-edge parameters: 5 bytes per half-edge, the
+    value table in the 1 KB behind the kernel's ring) on the ring kernel at full size: losses.Huber with `ndist`
+    distinct integer deviations -- what preserve_distances on a graph produces [ref: pymde/recipes.py:194-215,
+    losses.py:101-125] -- on the config-4 graph (d = 2: 50M edges) and at d = 3 (25M edges), against the oracle,
+    three evaluations bitwise equal; 256 distinct values fall back to the fp32 stream with the same result."""
+    import pymde_amd
+    los = pymde_amd.losses
+    n, deg = (1_000_000, 50) if d == 2 else (250_000, 100)
+    holder = {}
+
+    def mk(w, p, dev):
+        g = torch.Generator(device=dev).manual_seed(7)
+        holder["dev"] = 1.0 + torch.randint(0, ndist, (p,), device=dev, generator=g).float()
+        return los.Huber(holder["dev"], 1.0)
+    b = _ring_full_size_case(n, deg, d, mk, lambda f, w: oracle.func("L_HUBER", holder["dev"].cpu().numpy(), None, (1.0,)))
+    assert b.byte_stream and not b.codebook and b.stream_kind == "byte index"
+    if d == 3:
+        # one value more than the table holds: the fp32 stream, same numbers
+        def mk2(w, p, dev):
+            g = torch.Generator(device=dev).manual_seed(7)
+            holder["dev"] = 1.0 + torch.randint(0, 256, (p,), device=dev, generator=g).float()
+            return los.Huber(holder["dev"], 1.0)
+        b2 = _ring_full_size_case(n, deg, d, mk2, lambda f, w: oracle.func("L_HUBER", holder["dev"].cpu().numpy(), None, (1.0,)),
+                                  runs=1)
+        assert not b2.byte_stream and not b2.codebook and b2.stream_kind == "fp32"
+
+
 @pytest.mark.parametrize("case", ["pen_huber_d3", "pen_quadratic_d3", "loss_huber_d3", "log1p_fp32_d3",
                                   "runtime_logistic_d1", "runtime_power_d4", "pen_cubic_scalar_d2"])
 def test_ring_units_full_size_against_oracle_and_bitwise(case):

@@ -123,7 +123,7 @@ def test_ring_kernel_issues_its_lds_accesses_in_protocol_order(tmp_path):
              os.path.join(ROOT, "pymde_amd", "csrc", u + ".hip"), "-o", str(out)],
             stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     # ring_ctrl_off(d) = (row cap + 32) * 4 d: prog[] at +0, LANDED at +64, accumulators from +256
-    ctrl_of = {1: (12288 + 32) * 4, 2: (7872 + 32) * 8, 3: (5216 + 32) * 12, 4: (3936 + 32) * 16}
+    ctrl_of = {1: (12288 + 32) * 4, 2: (7816 + 32) * 8, 3: (5200 + 32) * 12, 4: (3936 + 32) * 16}
     words_of = {"ds_read_b32": 1, "ds_read2_b32": 2, "ds_read_b64": 2, "ds_read2_b64": 4, "ds_read_b96": 3, "ds_read_b128": 4,
                 "ds_read_u8": 1, "ds_read_u16": 1}
     seen = {}
