@@ -14,7 +14,7 @@ Prints ONE JSON line: metric/value = edges/s/iter, plus
   roofline     -- algorithmic bytes (12.32 B/edge) / fused-kernel duration (median of
                   per-launch HIP-event times on the launching stream), against the 8 TB/s HBM peak;
                   `traffic` = HBM bytes per launch from the rocprofv3 PMC passes of THIS kernel
-                  source (profiles/r04_pmc_traffic.json, ignored when the source has changed since)
+                  source (profiles/r05_pmc_traffic.json, ignored when the source has changed since)
   cpu_baseline -- the reference's op sequence (average_distortion.py:68-105: index gathers,
                   pow/sum/sqrt, the penalty under autograd, two scatter_add_) restated in torch and
                   timed on ALL of this host's cores (kind "torch-aten-sequence"); the OpenMP CPU
@@ -72,18 +72,18 @@ def source_sha():
 def pmc_traffic(key):
     """HBM bytes per launch recorded by the PMC passes (tools/pmc_traffic.sh), or None when the
     record is missing or belongs to another version of the kernel source."""
-    path = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
     try:
         rec = json.load(open(path))
     except Exception:
         return None, None
     if rec.get("source_sha") != source_sha():
-        return None, "profiles/r04_pmc_traffic.json is from another kernel source (stale): ignored"
+        return None, "profiles/r05_pmc_traffic.json is from another kernel source (stale): ignored"
     b = rec.get("bytes_per_launch", {})
     v = b.get(key)
     if v is not None and key.startswith("ring") and "ring_combine" in b:
         v += b["ring_combine"]  # (the 2 column groups per row block: their partial rows are added by a second launch)
-    return v, "profiles/r04_pmc_traffic.json (rocprofv3 --pmc, bytes/launch; ring kernel + combine launch)"
+    return v, "profiles/r05_pmc_traffic.json (rocprofv3 --pmc, bytes/launch; the ring kernel, which adds its two column groups itself)"
 
 
 def make_workload(device, n=N_ITEMS, deg=OUT_DEGREE, d=DIM):
@@ -294,8 +294,20 @@ def run_config4(args, world, rank, device):
             "log1p2": lambda: (pen.Log1p(w, exponent=2.0), "penalties.Log1p(2)"),
             "l_huber": lambda: (los.Huber(dev, 0.5), "losses.Huber(0.5), deviations in {1.5,2.5}"),
             "l_quadratic": lambda: (los.Quadratic(dev), "losses.Quadratic, deviations in {1.5,2.5}"),
-            "logistic": lambda: (pen.Logistic(w), "penalties.Logistic (run-time functor on the ring kernel)"),
-            "power": lambda: (pen.Power(w, 2.5), "penalties.Power(2.5) (run-time functor on the ring kernel)"),
+            "logistic": lambda: (pen.Logistic(w), "penalties.Logistic"),
+            "power": lambda: (pen.Power(w, 2.5), "penalties.Power(2.5) (compile-time kind, run-time exponent)"),
+            "power15": lambda: (pen.Power(w, 1.5), "penalties.Power(1.5)"),
+            "sigmoid": lambda: (pen.Sigmoid(w, 1.0), "penalties.Sigmoid(threshold 1)"),
+            "hinge": lambda: (pen.Hinge(w, 1.0), "penalties.Hinge(threshold 1)"),
+            "invpower": lambda: (pen.InvPower(-w, 1), "penalties.InvPower(1), weights in {-1,-2}"),
+            "logratio": lambda: (pen.LogRatio(-w, 2), "penalties.LogRatio(2), weights in {-1,-2}"),
+            "l_cubic": lambda: (los.Cubic(dev), "losses.Cubic, deviations in {1.5,2.5}"),
+            "l_power": lambda: (los.Power(dev, 1.5), "losses.Power(1.5), deviations in {1.5,2.5}"),
+            "l_logistic": lambda: (los.Logistic(dev), "losses.Logistic, deviations in {1.5,2.5}"),
+            "l_fractional": lambda: (los.Fractional(dev), "losses.Fractional, deviations in {1.5,2.5}"),
+            "l_softfractional": lambda: (los.SoftFractional(dev), "losses.SoftFractional, deviations in {1.5,2.5}"),
+            "runtime": lambda: (pen._ClippedQuadratic(w, 1.0) if hasattr(pen, "_ClippedQuadratic") else pen.Logistic(w),
+                                "a private kind through the run-time functor on the ring kernel"),
         }[args.function]()
     else:
         f = pymde_amd.penalties.Log1p(w)
@@ -847,7 +859,8 @@ def main():
                     help="config 4 only: 4a Log1p (the headline), 4b PushAndPull(Log1p, Log) with 1/3 repulsive edges")
     ap.add_argument("--function", default="log1p",
                     choices=("log1p", "quadratic", "linear", "cubic", "huber", "log", "log1p2", "l_huber", "l_quadratic",
-                             "logistic", "power"),
+                             "logistic", "power", "power15", "sigmoid", "hinge", "invpower", "logratio", "l_cubic", "l_power",
+                             "l_logistic", "l_fractional", "l_softfractional", "runtime"),
                     help="config 4 only: another distortion function on the same graph (secondary records)")
     ap.add_argument("--embed", action="store_true", help="configs 4 and 5: a full embed() at that shape (s/iter)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

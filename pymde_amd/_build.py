@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB = os.path.join(HERE, "libmde_hip.so")
 SOURCES = ["mde_plan.hip", "mde_distortion.hip", "mde_ring.hip", "mde_ring_k_log1p.hip", "mde_ring_k_pushpull.hip",
-           "mde_ring_k_penalty.hip", "mde_ring_k_loss.hip", "mde_ring_k_runtime.hip", "mde_vec.hip", "mde_mfma.hip", "mde_edges.hip", "mde_knn.hip", "mde_graph.hip"]
+           "mde_ring_k_penalty.hip", "mde_ring_k_penalty2.hip", "mde_ring_k_loss.hip", "mde_ring_k_loss2.hip", "mde_ring_k_runtime.hip", "mde_vec.hip", "mde_mfma.hip", "mde_edges.hip", "mde_knn.hip", "mde_graph.hip"]
 ARCH = "gfx950"
 
 

@@ -142,4 +142,6 @@ int mde_ring_launch_log1p(const RingArgs& A, const mde_func* f, int* nblocks);  
 int mde_ring_launch_pushpull(const RingArgs& A, const mde_func* f, int* nblocks);  // mde_ring_k_pushpull.hip
 int mde_ring_launch_penalty(const RingArgs& A, const mde_func* f, int* nblocks);   // mde_ring_k_penalty.hip
 int mde_ring_launch_loss(const RingArgs& A, const mde_func* f, int* nblocks);      // mde_ring_k_loss.hip
+int mde_ring_launch_penalty2(const RingArgs& A, const mde_func* f, int* nblocks);  // mde_ring_k_penalty2.hip
+int mde_ring_launch_loss2(const RingArgs& A, const mde_func* f, int* nblocks);     // mde_ring_k_loss2.hip
 int mde_ring_launch_runtime(const RingArgs& A, const mde_func* f, int* nblocks);   // mde_ring_k_runtime.hip

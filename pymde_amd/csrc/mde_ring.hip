@@ -1411,6 +1411,12 @@ int mde_ring_try(mde_plan* plan, const float* X, int d, const mde_func* f, float
   else if (f->kind == MDE_F_L_QUADRATIC || f->kind == MDE_F_L_WEIGHTED_QUADRATIC || f->kind == MDE_F_L_ABSOLUTE ||
            f->kind == MDE_F_L_HUBER)
     rc = mde_ring_launch_loss(A, f, nblocks);
+  else if (f->kind == MDE_F_L_CUBIC || f->kind == MDE_F_L_POWER || f->kind == MDE_F_L_LOGISTIC ||
+           f->kind == MDE_F_L_FRACTIONAL || f->kind == MDE_F_L_SOFT_FRACTIONAL)
+    rc = mde_ring_launch_loss2(A, f, nblocks);
+  else if (f->kind == MDE_F_LOGISTIC || f->kind == MDE_F_SIGMOID || f->kind == MDE_F_HINGE || f->kind == MDE_F_POWER ||
+           f->kind == MDE_F_INVPOWER || f->kind == MDE_F_LOGRATIO)
+    rc = mde_ring_launch_penalty2(A, f, nblocks);
   else
     rc = mde_ring_launch_penalty(A, f, nblocks);
   if (rc != 0) return rc;

@@ -720,3 +720,58 @@ def test_ring_layout_gives_way_on_hub_graphs():
     wE, wgrad = oracle.average_distortion(edges, X, oracle.func("LOG1P", w, None, (1.5,)))
     assert float(E) == pytest.approx(wE, rel=1e-5)
     assert_grad_close(Xt.grad.cpu().numpy(), wgrad)
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_ring_kernel_every_public_function(monkeypatch, d):
+    """Every public penalty and loss has a compile-time functor on the ring kernel since round 5 (the units
+    mde_ring_k_penalty2 / mde_ring_k_loss2 added Power, Logistic, Sigmoid, Hinge, InvPower, LogRatio and the
+    losses Cubic, Power, Logistic, Fractional, SoftFractional): each against the oracle on the ring kernel
+    (forced on), with continuous parameters (fp32 stream), 3 distinct values (codebook) and 60 (byte index)."""
+    import pymde_amd
+    pen, los = pymde_amd.penalties, pymde_amd.losses
+    monkeypatch.setenv("MDE_PANEL", "1")
+    rng = np.random.default_rng(31 + d)
+    n, p = 30000, 400000
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    key = np.unique(np.minimum(i, j).astype(np.int64) * n + np.maximum(i, j))
+    edges = np.stack([key // n, key % n], 1)
+    p = len(edges)
+    et = torch.tensor(edges, device=DEV)
+    X = (rng.standard_normal((n, d)) * 1.5).astype(np.float32)
+    params = {"fp32": rng.uniform(0.5, 2.0, p).astype(np.float32),
+              "codebook": rng.choice(np.array([0.5, 1.0, 2.0], dtype=np.float32), size=p),
+              "byte index": (0.5 + rng.integers(0, 60, p) / 40.0).astype(np.float32)}
+    cases = [
+        ("LOGISTIC", lambda a: pen.Logistic(a, 0.5, 3.0), (0.5, 3.0), +1),
+        ("SIGMOID", lambda a: pen.Sigmoid(a, 1.0, 2.0), (1.0, 2.0), +1),
+        ("HINGE", lambda a: pen.Hinge(a, 1.0), (1.0, 0.5), +1),
+        ("POWER", lambda a: pen.Power(a, 2.5), (2.5,), +1),
+        ("POWER", lambda a: pen.Power(a, 1.5), (1.5,), +1),
+        ("POWER", lambda a: pen.Power(a, 0.5), (0.5,), +1),
+        ("INVPOWER", lambda a: pen.InvPower(a, 1), (1.0,), -1),
+        ("INVPOWER", lambda a: pen.InvPower(a, 2.5), (2.5,), -1),
+        ("LOGRATIO", lambda a: pen.LogRatio(a, 2), (2.0,), -1),
+        ("LOGRATIO", lambda a: pen.LogRatio(a, 1.5), (1.5,), -1),
+        ("L_CUBIC", lambda a: los.Cubic(a), (), +1),
+        ("L_POWER", lambda a: los.Power(a, 1.5), (1.5,), +1),
+        ("L_LOGISTIC", lambda a: los.Logistic(a), (), +1),
+        ("L_FRACTIONAL", lambda a: los.Fractional(a), (), +1),
+        ("L_SOFT_FRACTIONAL", lambda a: los.SoftFractional(a, 10.0), (10.0,), +1),
+    ]
+    for kind, make, scal, sign in cases:
+        for stream, a in params.items():
+            if kind not in ("LOGISTIC", "POWER", "L_CUBIC", "LOGRATIO") and stream != "fp32" and d == 3:
+                continue  # (keep the d = 3 sweep short: every kind on one stream, four kinds on all three)
+            a = (sign * a).astype(np.float32)
+            f = make(torch.tensor(a, device=DEV))
+            mde = pymde_amd.MDE(n, d, et, f)
+            Xt = torch.tensor(X, device=DEV, requires_grad=True)
+            E = mde.average_distortion(Xt)
+            E.backward()
+            b = mde._binding()
+            assert b.struct(d).layout == 1 and b.stream_kind == stream, (kind, stream, b.stream_kind)
+            wE, wgrad = oracle.average_distortion(edges, X, oracle.func(kind, a, None, scal))
+            assert float(E.detach()) == pytest.approx(wE, rel=2e-5), (kind, scal, stream)
+            assert_grad_close(Xt.grad.cpu().numpy(), wgrad)

@@ -113,7 +113,8 @@ def test_ring_kernel_issues_its_lds_accesses_in_protocol_order(tmp_path):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("no hipcc")
-    units = ["mde_ring_k_log1p", "mde_ring_k_pushpull", "mde_ring_k_penalty", "mde_ring_k_loss", "mde_ring_k_runtime"]
+    units = ["mde_ring_k_log1p", "mde_ring_k_pushpull", "mde_ring_k_penalty", "mde_ring_k_penalty2", "mde_ring_k_loss",
+             "mde_ring_k_loss2", "mde_ring_k_runtime"]
     procs = []
     for u in units:
         out = tmp_path / (u + ".s")
@@ -165,7 +166,7 @@ def test_ring_kernel_issues_its_lds_accesses_in_protocol_order(tmp_path):
             # every kernel has the prologue's and the loop's releases; forward-only kernels too
             assert releases >= 3 and publishes >= 1, (u, dim, releases, publishes, lines[s0][:80])
             seen[(u, dim)] = seen.get((u, dim), 0) + 1
-    for u in units[:4]:
+    for u in units[:6]:
         assert seen.get((u, 2), 0) >= 4 and seen.get((u, 3), 0) >= 4, (u, seen)
     for dim in (1, 2, 3, 4):
         assert seen.get(("mde_ring_k_runtime", dim), 0) >= 2, seen

@@ -20,11 +20,11 @@ sys.path.insert(0, ROOT)
 
 def classify(name):
     if "k_fused_ring<" in name:
-        # k_fused_ring<D, Fn, HAS_GRAD, CB, LIN>(...)
+        # k_fused_ring<D, Fn, HAS_GRAD, PS, LIN>(...): PS = 0 fp32 stream, 1 codebook, 2 byte index
         targs = name.split("k_fused_ring<", 1)[1].split(">(", 1)[0]
         flags = [t.strip() for t in targs.split(",")][-3:]
         if len(flags) == 3 and flags[0] == "true":
-            return "ring_codebook" if flags[1] == "true" else "ring_fp32"
+            return {"0": "ring_fp32", "1": "ring_codebook", "2": "ring_bytes"}.get(flags[1])
     if "k_ring_combine" in name:
         return "ring_combine"
     if "k_fused_wide4" in name:
