@@ -140,7 +140,8 @@ def load():
             raise ImportError(
                 "pymde_amd: %s is missing and could not be built; the HIP extension is the "
                 "only compute path (no CPU fallback)" % LIB_PATH)
-        lib = ctypes.CDLL(LIB_PATH)
+        # (design experiments on the GPU box: another build of the same library, tools/build_variant.sh)
+        lib = ctypes.CDLL(os.environ.get("PYMDE_AMD_LIB_VARIANT") or LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
