@@ -368,7 +368,8 @@ struct FnPushPull {
       false;
 #endif
   // (the merged pair keeps f'/d finite at d = 0 the way Log1p does: a term far below one ulp of the
-  // reciprocal's argument for every d >= 1e-11; at d = 0 the reference's NaN / Inf -> 1 rule multiplies
+  // reciprocal's argument on the attractive side, a clamp at 2e-38 (the smallest normal numbers) on the repulsive one (exact for every
+  // d >= 2e-13); at d = 0 the reference's NaN / Inf -> 1 rule multiplies
   // x_v - x_u = 0 and so does this 0)
   static constexpr bool kFiniteG = kMerged;
   static constexpr bool kRingFused = false;
@@ -404,7 +405,10 @@ struct FnPushPull {
       const float ser = d * fmaf(d, fmaf(d, fmaf(d, -1.0f / 24.0f, 1.0f / 6.0f), -0.5f), 1.0f);
       // (a third bit select here -- mask from the sign of d - 1/16 -- measured no faster than v_cmp + v_cndmask: 0.2418 vs 0.2402 ms)
       const float om = d < 0.0625f ? ser : 1.0f - em;
-      const float r = mde_rcp(sel(fmaf(sd, t, 1.0e-30f), fmaf(om, ss, 1.0e-36f)));
+      // (the repulsive argument (1 - exp(-d)) d^2 ~ d^3 is CLAMPED from below, not biased: a bias of 1e-36 put
+      // f'/d off by a factor of two at d = 1e-12; the clamp is exact down to d ~ 2e-13 -- below that d^3 leaves
+      // the normal range -- and keeps r finite at d = 0, where the term multiplies x_v - x_u = 0)
+      const float r = mde_rcp(sel(fmaf(sd, t, 1.0e-30f), fmaxf(om * ss, 2.0e-38f)));
       gd = a0 * (sel(1.5f, d * em) * r);
       const float t2 = 1.0f - em;
       const float corr = sel((pe - (t - 1.0f)) * sd * r, d > 1.0f ? (-em - (t2 - 1.0f)) * (1.0f + em) : 0.0f);

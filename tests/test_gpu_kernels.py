@@ -775,3 +775,67 @@ def test_ring_kernel_every_public_function(monkeypatch, d):
             wE, wgrad = oracle.average_distortion(edges, X, oracle.func(kind, a, None, scal))
             assert float(E.detach()) == pytest.approx(wE, rel=2e-5), (kind, scal, stream)
             assert_grad_close(Xt.grad.cpu().numpy(), wgrad)
+
+
+def test_pushpull_on_the_ring_kernel_at_near_coincident_points(monkeypatch):
+    """The merged PushAndPull(Log1p, Log) of the ring kernel keeps f'/d finite by construction and skips the
+    NaN / Inf fix-up for codebook streams (mde_functions.h).  Repulsive AND attractive edges whose endpoints
+    are 0, 1e-12, 1e-9, 1e-6 and 1e-3 apart, next to ordinary ones, against the oracle (the reference's rule:
+    NaN / Inf -> 1, which at d = 0 multiplies x_i - x_j = 0): the gradient at the kernel tolerance; the loss
+    with the coincident repulsive pairs left out (log(1 - exp(-0)) = -inf there, in the reference too)."""
+    import pymde_amd
+    pen = pymde_amd.penalties
+    monkeypatch.setenv("MDE_PANEL", "1")
+    rng = np.random.default_rng(77)
+    n, p, d = 30000, 400000, 2
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    key = np.unique(np.minimum(i, j).astype(np.int64) * n + np.maximum(i, j))
+    edges = np.stack([key // n, key % n], 1)
+    p = len(edges)
+    X = rng.standard_normal((n, d)).astype(np.float32) * 0.5
+    w = rng.choice(np.array([-1.0, 1.0, 2.0], dtype=np.float32), size=p, p=[0.3, 0.4, 0.3])
+    # near the origin float32 resolves tiny separations: pairs of vertices placed `gap` apart, joined by an edge
+    gaps = [0.0, 1e-12, 1e-9, 1e-6, 1e-3]
+    special = []
+    for k, gap in enumerate(gaps):
+        for sgn in (-1.0, 1.0):
+            a, b = 2 * (2 * k + (sgn > 0)), 2 * (2 * k + (sgn > 0)) + 1   # vertices 0..19, distinct pairs
+            X[a] = (1e-3 * (k + 1), 0.0)
+            X[b] = (np.float32(1e-3 * (k + 1)) + np.float32(gap), 0.0) if gap >= 1e-9 else X[a]
+            if 0.0 < gap < 1e-9:
+                X[a] = (0.0, 0.0)
+                X[b] = (np.float32(gap), 0.0)
+            special.append((a, b, sgn, gap))
+    have = set(map(tuple, edges.tolist()))
+    add = np.array([[a, b] for a, b, _, _ in special if (a, b) not in have], dtype=np.int64)
+    addw = np.array([sgn for a, b, sgn, _ in special if (a, b) not in have], dtype=np.float32)
+    edges = np.concatenate([edges, add])
+    w = np.concatenate([w, addw])
+    f = pen.PushAndPull(torch.tensor(w, device=DEV), pen.Log1p, pen.Log)
+    mde = pymde_amd.MDE(n, d, torch.tensor(edges, device=DEV), f)
+    Xt = torch.tensor(X, device=DEV, requires_grad=True)
+    E = mde.average_distortion(Xt)
+    E.backward()
+    b = mde._binding()
+    assert b.struct(d).layout == 1 and b.codebook
+    fd = oracle.func("LOG1P", w, None, (1.5,), "LOG", (1.0,))
+    _, wgrad = oracle.average_distortion(edges, X, fd)
+    got = Xt.grad.cpu().numpy()
+    assert np.isfinite(got).all()
+    # the rows of the near-coincident pairs, one by one (their entries span 20 orders of magnitude), then the rest
+    for a, bb, sgn, gap in special:
+        for v in (a, bb):
+            np.testing.assert_allclose(got[v], wgrad[v], rtol=2e-4, atol=2e-5 * np.abs(wgrad[v]).max() + 1e-12,
+                                       err_msg="gap %g, weight %g" % (gap, sgn))
+    rest = np.ones(n, bool)
+    rest[:20] = False
+    assert_grad_close(got[rest], wgrad[rest])
+    # the loss: without the coincident repulsive pair (-inf x w there, here and in the reference)
+    keep = ~((np.linalg.norm(X[edges[:, 0]] - X[edges[:, 1]], axis=1) == 0) & (w < 0))
+    assert np.isinf(float(E.detach())) or not (~keep).any()
+    mde2 = pymde_amd.MDE(n, d, torch.tensor(edges[keep], device=DEV),
+                         pen.PushAndPull(torch.tensor(w[keep], device=DEV), pen.Log1p, pen.Log))
+    E2 = float(mde2.average_distortion(torch.tensor(X, device=DEV)))
+    wE2, _ = oracle.average_distortion(edges[keep], X, oracle.func("LOG1P", w[keep], None, (1.5,), "LOG", (1.0,)), want_grad=False)
+    assert E2 == pytest.approx(wE2, rel=1e-5)
