@@ -431,7 +431,7 @@ typedef struct mde_turn_desc {
   const double* host_board;  /* >= 25 doubles: the last kernel of an iteration writes its sequence number behind
                                 the 24 mirrored board entries, and mde_turn_wait polls that word */
   double seq;                /* (library state: sequence number of the iteration enqueued last) */
-  double pre_id;             /* (library state: the L-BFGS step of the iteration after it is queued behind it) */
+  double pre_id;             /* (library state: > 0 the L-BFGS step of the iteration after it is queued behind it, -1 that step has run and is pending) */
 } mde_turn_desc;
 /* f0: the loss at X[cur]; the acceptance test of the trial (c1, c2) is made by the iteration's last kernel,
  * on the device.  allow_pre: also queue the L-BFGS step of the iteration AFTER this one behind it -- its
@@ -440,7 +440,12 @@ typedef struct mde_turn_desc {
 int mde_turn_enqueue(mde_turn_desc* T, int32_t cur, float t_prev, double f0, double c1, double c2,
                      int32_t allow_pre, void* stream);
 /* out (>= 24 doubles): [0] f_new, [1] accepted, [2] next iteration enqueued, [3] status word,
- * [4,12) trial statistics, [12,20) direction statistics.  eps_pre >= 0: the iteration enqueued here gets
+ * [4,12) trial statistics, [12,20) direction statistics, [20] 1 when the gated L-BFGS step of the NEXT iteration
+ * has run (the trial was accepted and the iteration was enqueued with allow_pre) but allow_next = 0 kept that
+ * iteration from being launched: the step is then PENDING -- g_prev, the history, dir and out[12,20) are already
+ * those of the next iteration, the next mde_turn_enqueue on this descriptor skips its own step (t_prev = 1 is
+ * what the pending step used), and mde_lbfgs_dev_step must not be called on the same history in between.
+ * eps_pre >= 0: the iteration enqueued here gets
  * allow_pre when the accepted point's gradient norm is above eps_pre; < 0: never.  SYNC (waits for the
  * stream). */
 int mde_turn_wait(mde_turn_desc* T, int32_t cur, double f0, int32_t allow_next, double c1, double c2,

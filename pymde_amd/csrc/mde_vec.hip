@@ -2467,7 +2467,12 @@ static int turn_enqueue_impl(mde_turn_desc* T, int32_t cur, float t_prev, double
 
 extern "C" int mde_turn_enqueue(mde_turn_desc* T, int32_t cur, float t_prev, double f0, double c1, double c2,
                                 int32_t allow_pre, void* stream) {
-  return turn_enqueue_impl(T, cur, t_prev, f0, c1, c2, allow_pre != 0, false, stream);
+  // a gated L-BFGS step that has run but was not followed by its iteration (mde_turn_wait with allow_next = 0
+  // on an accepted trial; out[20] said so) IS this iteration's step: running it again would stage s = t d with
+  // the direction the first run has already overwritten and y = g - g_prev = 0
+  const bool pending = T && T->pre_id == -1.0;
+  if (pending) T->pre_id = 0.0;
+  return turn_enqueue_impl(T, cur, t_prev, f0, c1, c2, allow_pre != 0, pending, stream);
 }
 
 extern "C" int mde_turn_wait(mde_turn_desc* T, int32_t cur, double f0, int32_t allow_next, double c1, double c2,
@@ -2504,8 +2509,16 @@ extern "C" int mde_turn_wait(mde_turn_desc* T, int32_t cur, double f0, int32_t a
   const bool accept = hb[8] != 0.0;
   out[1] = accept ? 1.0 : 0.0;
   out[2] = 0.0;
-  const bool step_done = accept && *T->host_status == 0 && T->pre_id != 0.0;  // (its gate opened)
+  const bool step_done = accept && *T->host_status == 0 && T->pre_id > 0.0;  // (its gate opened)
   T->pre_id = 0.0;
+  out[20] = 0.0;
+  if (step_done && !allow_next) {
+    // the speculative step of the next iteration has run (g_prev <- g, a new history pair, dir and the
+    // direction statistics overwritten) and the caller does not want that iteration launched now: the step
+    // stays PENDING -- the next mde_turn_enqueue on this descriptor takes it as done -- and the caller is told
+    T->pre_id = -1.0;
+    out[20] = 1.0;
+  }
   if (accept && allow_next && *T->host_status == 0) {
     // (hb[1]: |g|^2 at the accepted point -- the next iteration goes on to another one iff it is above eps)
     const bool allow_pre = eps_pre >= 0.0 && std::sqrt(hb[1]) > eps_pre;

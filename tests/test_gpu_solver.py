@@ -564,3 +564,71 @@ def test_turn_calls_follow_the_python_loop_bit_for_bit(monkeypatch, cname, n, p)
         assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2], kwargs
         if "eps" in kwargs:
             assert len(outs[0][1]) < 40
+
+
+def test_turn_wait_reports_a_pending_speculative_step():
+    """mde_turn_enqueue(allow_pre = 1) queues the NEXT iteration's L-BFGS step behind a gate that opens when the
+    trial is accepted.  If the caller then waits with allow_next = 0 the step has run all the same: out[20] must
+    say so, and the next mde_turn_enqueue must take it as done -- not run a second step on g_prev == g (round-4
+    advisor finding; the Python driver never gets there, the C API has to hold on its own)."""
+    import ctypes
+    import pymde_amd
+    from pymde_amd import _lib, optim
+    lib = _lib.load()
+    rng = np.random.default_rng(2)
+    n, d, p = 4000, 2, 40000
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    e_np = np.unique(np.sort(np.stack([i, j], 1), 1), axis=0)
+    w = torch.tensor((1.0 + (rng.random(len(e_np)) < 0.3)).astype(np.float32), device=DEV)
+    c = pymde_amd.Centered()
+    mde = pymde_amd.MDE(n, d, torch.tensor(e_np, device=DEV), pymde_amd.penalties.Quadratic(w), constraint=c)
+    torch.manual_seed(0)
+    X0 = c.initialization(n, d, device=DEV)
+    e = optim._Engine(X0, 10)
+    prob = optim._NativeProblem(e, mde._binding(), c)
+    T = prob.turn_desc()
+    assert T is not None
+    # the first iteration by hand (optim.lbfgs: evaluate, d = -g, t = min(1, 1 / |g|_1), accepted point = X + t d)
+    prob.value_and_grad(e.X)
+    e.stats(e.g, None, e.X)
+    vals, loss0 = e.read_board(8)
+    e.reset_memory()
+    e.axpy(-2.0, e.g, e.g, e.dir)
+    e.axpy(0.0, e.g, e.g, e.g_prev)
+    t0 = float(min(1.0, 1.0 / vals[optim._G1]))
+    prob.retract_step(t0, e.X_trial)
+    e.X, e.X_trial = e.X_trial, e.X
+    prob.value_and_grad(e.X)
+    _, loss1 = e.read_board(8)
+    bufs = (T.X[0], T.X[1])
+    cur = 0 if e.X.data_ptr() == bufs[0] else 1
+    out = np.zeros(24)
+    outp = ctypes.c_void_p(out.ctypes.data)
+    cnt, acc = ctypes.c_int32(0), ctypes.c_int32(0)
+    pending_seen = False
+    f = loss1
+    t_prev = t0
+    _lib.check(lib.mde_lbfgs_dev_info(e.lbfgs, ctypes.byref(cnt), ctypes.byref(acc), e._stream))
+    expect = cnt.value                            # pairs in the history
+    own_step = True                               # the first enqueue runs its own L-BFGS step
+    for _ in range(6):
+        _lib.check(lib.mde_turn_enqueue(ctypes.byref(T), cur, float(t_prev), float(f), 1e-4, 0.9, 1, e._stream))
+        _lib.check(lib.mde_turn_wait(ctypes.byref(T), cur, float(f), 0, 1e-4, 0.9, 0.0, outp, e._stream))
+        assert out[2] == 0.0                      # allow_next = 0: nothing launched
+        expect = min(expect + (1 if own_step else 0), 10)
+        _lib.check(lib.mde_lbfgs_dev_info(e.lbfgs, ctypes.byref(cnt), ctypes.byref(acc), e._stream))
+        if out[1] == 0.0:
+            assert out[20] == 0.0 and cnt.value == expect   # a rejected trial: the gate stayed shut
+            break
+        assert out[20] == 1.0, "accepted trial + allow_pre: the speculative step has run and must be reported"
+        pending_seen = True
+        # the gated step pushed ITS pair -- and an enqueue that found a pending step did not push another
+        expect = min(expect + 1, 10)
+        assert cnt.value == expect, (cnt.value, expect, own_step)
+        assert torch.equal(e.g_prev, e.g)         # g_prev <- g happened in the speculative step
+        cur = 1 - cur                             # the accepted trial becomes the iterate
+        f, t_prev, own_step = float(out[0]), 1.0, False
+    assert pending_seen
+    torch.cuda.synchronize()
+    e.close()
