@@ -389,7 +389,10 @@ int mde_lbfgs_dev_info(const mde_lbfgs* o, int32_t* count_host, int32_t* accepte
  * behind redoes the step from the staged sums -- the direction is the four-launch path's either way.
  * unfused != 0 forces the four launches; blocks / spins / lds_bytes > 0 (tests) launch that many
  * workgroups, with that spin limit and that much dynamic LDS each, so that the give-up path can be
- * provoked.  A negative argument leaves that setting as it is. */
+ * provoked.  A negative argument leaves that setting as it is.
+ * TEST HOOK, not part of the solver's interface: the settings are one unsynchronised process-wide record (do not
+ * call it while another thread is inside mde_lbfgs_dev_step), and the dynamic-LDS attribute it sets on the kernel
+ * goes back to 0 only when lds_bytes = 0 is passed again. */
 int mde_lbfgs_debug_knobs(int32_t unfused, int32_t blocks, int32_t spins, int32_t lds_bytes);
 
 /* ---- the solver's read-back -------------------------------------------------------------------------

@@ -33,12 +33,27 @@ extern "C" int64_t mde_work_doubles(int32_t d) {
   const int64_t dd = (int64_t)(d > 0 ? d : 1);
   return MDE_SMALL_DOUBLES + 8 * dd * dd + MDE_PARTIAL_DOUBLES;
 }
+// the small area, in doubles (one place: the users are spread over this file):
+//   [0, 2048)      column means, Gram staging and other per-launch scalars
+//   [2304, 3072)   k_lb_fused: three rows of MDE_LB_FUSED_MAXBLOCKS arrival flags (32-bit words)
+//   [3072, 3076)   k_lb_fused / k_lb_rescue: gave-up, done and rescue-count words; [3076, 3088) probe stamps (-DMDE_LB_PROBE)
+//   [3200]         the gate word of a pre-enqueued L-BFGS step (mde_turn_*)
+//   [4064, 4096)   arrival tickets of the reductions that finish in their last workgroup
+#define MDE_WS_MEAN_END 2048
+#define MDE_WS_LB_FLAGS 2304
+#define MDE_WS_LB_VERDICT 3072
+#define MDE_WS_LB_VERDICT_END 3088
+#define MDE_WS_TURN_GATE 3200
+#define MDE_WS_TICKETS (MDE_SMALL_DOUBLES - 32)
+static_assert(MDE_WS_MEAN_END <= MDE_WS_LB_FLAGS && MDE_WS_LB_VERDICT_END <= MDE_WS_TURN_GATE &&
+                  MDE_WS_TURN_GATE + 1 <= MDE_WS_TICKETS && MDE_WS_TICKETS + 32 == MDE_SMALL_DOUBLES,
+              "small area of the work buffer: regions overlap");
 static inline double* work_mats(double* work) { return work + MDE_SMALL_DOUBLES; }
 // arrival counters of the kernels that finish their reduction in the last workgroup: the last 32
 // doubles of the small area (zero between launches; the caller zeroes the buffer once)
 enum { TK_STATS = 0, TK_GRAM = 1, TK_CENTER = 2, TK_LB_STAGE = 3, TK_LB_COMBINE = 4, TK_RETRACT = 5 };
 static inline unsigned int* work_ticket(double* work, int which) {
-  return reinterpret_cast<unsigned int*>(work + MDE_SMALL_DOUBLES - 32) + which;
+  return reinterpret_cast<unsigned int*>(work + MDE_WS_TICKETS) + which;
 }
 static inline double* work_partials(double* work, int d) {
   return work + MDE_SMALL_DOUBLES + 8 * (int64_t)d * d;
@@ -1921,9 +1936,11 @@ __global__ __launch_bounds__(64) void k_lbfgs_direction(LbDev* __restrict__ dv, 
 #define MDE_LB_FUSED_LD 16       // history <= 15
 #define MDE_LB_FUSED_MAXN (1 << 18)
 #define MDE_LB_FUSED_MAXBLOCKS 512
-// the flag words of the fused kernel: doubles [2304, 3072) of the work buffer's small area (nothing
-// else is kept there; zero or an older epoch between launches)
-static inline unsigned int* work_lb_flags(double* work) { return reinterpret_cast<unsigned int*>(work + 2304); }
+// the flag words of the fused kernel: doubles [MDE_WS_LB_FLAGS, MDE_WS_LB_VERDICT) of the work buffer's small area
+// (three rows of MDE_LB_FUSED_MAXBLOCKS 32-bit words; zero or an older epoch between launches), the verdict
+// words right behind them
+static_assert(MDE_WS_LB_FLAGS + 3 * MDE_LB_FUSED_MAXBLOCKS / 2 == MDE_WS_LB_VERDICT, "k_lb_fused: flag rows and verdict words");
+static inline unsigned int* work_lb_flags(double* work) { return reinterpret_cast<unsigned int*>(work + MDE_WS_LB_FLAGS); }
 // (design probe, -DMDE_LB_PROBE: workgroup 0 leaves wall-clock stamps -- 100 MHz -- of its phases behind the
 // verdict words; tools/lbfused_probe.py prints them)
 #ifdef MDE_LB_PROBE
@@ -2270,12 +2287,21 @@ static LbKnobs& lb_knobs() {
   static LbKnobs k;
   return k;
 }
+// (test hook: one process-wide record, no synchronisation -- see include/mde_hip.h)
 extern "C" int mde_lbfgs_debug_knobs(int32_t unfused, int32_t blocks, int32_t spins, int32_t lds_bytes) {
   LbKnobs& k = lb_knobs();
   if (unfused >= 0) k.unfused = unfused != 0;
   if (blocks >= 0) k.blocks = blocks;
   if (spins >= 0) k.spins = spins;
-  if (lds_bytes >= 0) k.lds = lds_bytes;
+  if (lds_bytes >= 0) {
+    if (lds_bytes == 0 && k.lds > 0) {
+      // back to no dynamic LDS: the attribute a test raised on the kernels goes back too
+      MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lb_fused<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 0));
+      MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lb_fused<MDE_LB_GROUP>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 0));
+    }
+    k.lds = lds_bytes;
+  }
   return MDE_OK;
 }
 
@@ -2413,7 +2439,7 @@ extern "C" int mde_lbfgs_combine(mde_lbfgs* o, const float* g, float c_g, const 
 // ---------------------------------------------------------------- one solver iteration as two calls
 // the gate word of the pre-enqueued L-BFGS step (MdeGate): a double of the work buffer's small area nobody
 // else uses
-static inline unsigned int* work_turn_gate(double* work) { return reinterpret_cast<unsigned int*>(work + 3200); }
+static inline unsigned int* work_turn_gate(double* work) { return reinterpret_cast<unsigned int*>(work + MDE_WS_TURN_GATE); }
 static bool turn_pre_enabled() {
   static const bool on = getenv("MDE_TURN_NOPRE") == nullptr;  // (design probe: no look-ahead of the L-BFGS step)
   return on;

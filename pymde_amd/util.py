@@ -122,11 +122,21 @@ def work_buffer(device, d):
     buf = _WORK.pop(key, None)
     if buf is None or buf.numel() < need:
         # zeroed once: the small area holds the arrival counters of the kernels that finish their
-        # reduction in the last workgroup (they return to zero after every launch)
+        # reduction in the last workgroup (they return to zero after every launch).  The allocation happens
+        # with the KEY stream current (torch.cuda.current_stream above is the stream the caller launches on),
+        # which is what makes an eviction safe: the caching allocator hands a freed block to another stream
+        # only after the work queued on the allocating stream has passed the free.
         buf = torch.zeros(need, dtype=torch.float64, device=device)
     _WORK[key] = buf  # (re-inserted: most recently used last)
     while len(_WORK) > _WORK_KEEP:
-        _WORK.pop(next(iter(_WORK)))
+        old_key = next(iter(_WORK))
+        old = _WORK.pop(old_key)
+        # an evicted buffer may still be read by kernels in flight on ITS stream (callers pass the pointer of a
+        # temporary to asynchronous launches): tell the allocator, whatever stream is current at the free
+        try:
+            old.record_stream(torch.cuda.ExternalStream(old_key[1], device=device))
+        except Exception:  # (a stream that no longer exists: nothing is in flight on it)
+            pass
     return buf
 
 
