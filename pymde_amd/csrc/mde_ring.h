@@ -47,10 +47,13 @@ __host__ __device__ constexpr int ring_gr_off(int d) { return ring_ctrl_off(d) +
 #endif
 #define MDE_RING_BS (64 * (MDE_RING_NCW + MDE_RING_NPROD))
 #ifndef MDE_RING_DEPTH
-#define MDE_RING_DEPTH 2           // chunks in flight (in VGPRs) per producer wave
+#define MDE_RING_DEPTH 4           // chunks in flight (in VGPRs) per producer wave (round 5, with hand-placed waits: 2 / 3 / 4 measure 0.213 / 0.207 / 0.201 ms on the fp32 stream, 0.180 all three on the codebook stream)
 #endif
 #ifndef MDE_RING_UNIT
 #define MDE_RING_UNIT 1            // consecutive chunks a producer step moves (one slot poll, one publish)
+#endif
+#ifndef MDE_RING_ASMLOAD
+#define MDE_RING_ASMLOAD 1         // the producers' chunk loads as inline asm with hand-placed vmcnt waits (0: plain loads)
 #endif
 #ifndef MDE_RING_PFB
 #define MDE_RING_PFB 3             // stream blocks (4 iterations each) in flight per consumer wave

@@ -226,6 +226,20 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     constexpr int DEPTH = MDE_RING_DEPTH, UNIT = MDE_RING_UNIT;
     // a producer step moves UNIT consecutive chunks: one slot poll and one publish for all of them
     ring_f4 buf[DEPTH][UNIT * PIECES];
+    // The chunk loads are INLINE ASM and their waits are placed by hand (round 5).  Written as plain loads, the
+    // loop-carried buffers made hipcc wait with vmcnt(3..0) in front of a chunk's stores -- for ALL loads in
+    // flight, the other buffers' too: the wave overlapped half a chunk period with its loads instead of
+    // DEPTH - 1 periods (and DEPTH 3 / 4 measured nothing).  A producer wave issues no other vector-memory
+    // instruction inside its loop, so the count is simply: the (DEPTH - 1) x UNIT x PIECES loads issued after
+    // this buffer's may stay in flight.  The wait takes the buffer's registers as read-write operands, so
+    // every later use of them depends on it.
+    auto ld16 = [&](ring_f4& dst, const ring_f4* src) __attribute__((always_inline)) {
+#if MDE_RING_ASMLOAD
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(src) : "memory");
+#else
+      dst = *src;
+#endif
+    };
     auto fetch = [&](int k, int j0u) __attribute__((always_inline)) {
 #pragma unroll
       for (int c = 0; c < UNIT; ++c) {
@@ -235,18 +249,48 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           // (the producers share their SIMDs' issue slots with the consumers: every instruction here counts)
           const ring_f4* src = reinterpret_cast<const ring_f4*>(Xb + (size_t)j * CBYTES + (size_t)lane * 16);
 #pragma unroll
-          for (int i = 0; i < PIECES; ++i) buf[k][c * PIECES + i] = src[i * 64];
+          for (int i = 0; i < PIECES; ++i) ld16(buf[k][c * PIECES + i], src + i * 64);
         } else {
           // the table's last chunk, or a prefetch past the end of the table (clamped, never written)
           const size_t off0 = (size_t)min(j, NC - 1) * CBYTES + (size_t)lane * 16;
 #pragma unroll
           for (int i = 0; i < PIECES; ++i) {
             const size_t off = off0 + (size_t)i * 1024;
-            buf[k][c * PIECES + i] = *reinterpret_cast<const ring_f4*>(Xb + (off < last16 ? off : last16));
+            ld16(buf[k][c * PIECES + i], reinterpret_cast<const ring_f4*>(Xb + (off < last16 ? off : last16)));
           }
         }
       }
     };
+    auto wait_buf = [&](int k) __attribute__((always_inline)) {
+#if MDE_RING_ASMLOAD
+      static_assert(UNIT * PIECES == 4 || UNIT * PIECES == 2 || UNIT * PIECES == 3 || UNIT * PIECES == 8, "operand list of the wait");
+      constexpr int NEWER = (DEPTH - 1) * UNIT * PIECES;
+      if constexpr (UNIT * PIECES == 4)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(buf[k][0]), "+v"(buf[k][1]), "+v"(buf[k][2]), "+v"(buf[k][3]) : "n"(NEWER) : "memory");
+      else if constexpr (UNIT * PIECES == 3)
+        asm volatile("s_waitcnt vmcnt(%3)" : "+v"(buf[k][0]), "+v"(buf[k][1]), "+v"(buf[k][2]) : "n"(NEWER) : "memory");
+      else if constexpr (UNIT * PIECES == 2)
+        asm volatile("s_waitcnt vmcnt(%2)" : "+v"(buf[k][0]), "+v"(buf[k][1]) : "n"(NEWER) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%8)" : "+v"(buf[k][0]), "+v"(buf[k][1]), "+v"(buf[k][2]), "+v"(buf[k][3]), "+v"(buf[k][4]),
+                     "+v"(buf[k][5]), "+v"(buf[k][6]), "+v"(buf[k][7]) : "n"(NEWER) : "memory");
+#endif
+    };
+    // (see the stores below) the straddling 16-byte piece of the table's last chunk, for the lane that owns it
+    ring_f4 tail_v = {0.0f, 0.0f, 0.0f, 0.0f};
+    int tail_rel = -1;  // its byte offset inside the chunk
+    if ((nbytes & 15) != 0 && j_hi == NC) {
+      const size_t off_str = nbytes & ~(size_t)15;
+      const size_t rel = off_str - (size_t)(NC - 1) * CBYTES;
+      if (off_str >= (size_t)(NC - 1) * CBYTES && lane == (int)((rel & 1023) >> 4)) {
+        tail_rel = (int)rel;
+        const float* tp = reinterpret_cast<const float*>(Xb + off_str);
+        const int nt = (int)((nbytes - off_str) >> 2);  // 1..3 floats
+        tail_v[0] = tp[0];
+        if (nt > 1) tail_v[1] = tp[1];
+        if (nt > 2) tail_v[2] = tp[2];
+      }
+    }
     int minprog = j_lo, landed = j_lo;
     const uint32_t poll_addr = lane < 16 ? CTRL_PROG + 4u * (uint32_t)lane : (uint32_t)CTRL_F;
 #if MDE_RING_ABLATE
@@ -308,6 +352,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
             td0 = RING_CLK();
           }
 #endif
+          wait_buf(k);
 #pragma unroll
           for (int c = 0; c < UNIT; ++c) {
             const int jc = j + c;
@@ -315,28 +360,13 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
             int sc = slot + c;
             if (UNIT > 1 && sc >= S) sc -= S;
             char* dst = L + (uint32_t)__builtin_amdgcn_readfirstlane(ring_off + sc * CBYTES) + lane * 16;
-            if (jc != NC - 1 || (nbytes & 15) == 0) {
 #pragma unroll
-              for (int i = 0; i < PIECES; ++i) *reinterpret_cast<ring_f4*>(dst + i * 1024) = buf[k][c * PIECES + i];
-            } else {
-              // the table's last chunk when the table is not a multiple of 16 bytes: the lane whose 16
-              // bytes straddle the end loaded the LAST 16 bytes instead -- shift them into place
-              const size_t off0 = (size_t)jc * CBYTES + (size_t)lane * 16;
-#pragma unroll
-              for (int i = 0; i < PIECES; ++i) {
-                const size_t off = off0 + (size_t)i * 1024;
-                ring_f4 v = buf[k][c * PIECES + i];
-                if (off > last16 && off < nbytes) {
-                  const int sh4 = (int)((off - last16) >> 2);  // 1..3 floats
-                  const float t1 = v[1], t2 = v[2], t3 = v[3];
-                  v[0] = sh4 == 1 ? t1 : (sh4 == 2 ? t2 : t3);
-                  v[1] = sh4 == 1 ? t2 : (sh4 == 2 ? t3 : 0.0f);
-                  v[2] = sh4 == 1 ? t3 : 0.0f;
-                  v[3] = 0.0f;
-                }
-                *reinterpret_cast<ring_f4*>(dst + i * 1024) = v;
-              }
-            }
+            for (int i = 0; i < PIECES; ++i) *reinterpret_cast<ring_f4*>(dst + i * 1024) = buf[k][c * PIECES + i];
+            // the table's last chunk when the table is not a multiple of 16 bytes: the one lane whose 16 bytes
+            // straddle the end loaded the LAST 16 bytes instead -- it stores the piece it prepared before the loop
+            // over them (round 5: the shift used to sit in the loop as a second copy of the four stores, and the
+            // join of the two copies made hipcc wait for ALL loads in flight -- vmcnt(0) -- before every chunk)
+            if (jc == NC - 1 && tail_rel >= 0) *reinterpret_cast<ring_f4*>(dst - lane * 16 + tail_rel) = tail_v;
           }
           // (the LDS executes a wave's accesses in order: whoever sees the new LANDED sees the chunks -- provided
           // their stores are ISSUED in front of the publish: float stores against an int store, which

@@ -169,8 +169,14 @@ def test_push_and_pull_with_arbitrary_penalties_and_solver_limits():
     # the device-resident L-BFGS holds at most 63 pairs: a clear error instead of MDE_E_INVALID
     with pytest.raises(ValueError, match="memory_size"):
         mde.embed(max_iter=2, memory_size=64)
-    # a sharded problem cannot evaluate an arbitrary callable (each rank would add the full mean)
+    # a sharded problem evaluates an arbitrary callable too (round 5): distances and f replicated, the scatter
+    # over the owned rows, rank 0 carrying the mean -- here rank 0 of 2 without a process group: its own rows
+    # of the gradient, and the full value
     from pymde_amd import distributed
     sh = distributed.ShardedMDE(n, 2, torch.tensor(e, device=DEV), f, device=DEV, rank=0, world_size=2)
-    with pytest.raises(NotImplementedError):
-        sh.embed(max_iter=2)
+    Xs = X.detach().clone().requires_grad_(True)
+    Es = sh.average_distortion(Xs)
+    Es.backward()
+    lo, hi = sh._layout.ranges[0][0]
+    assert float(Es) == pytest.approx(float(E), rel=1e-6)
+    assert torch.equal(Xs.grad[lo:hi], X.grad[lo:hi])
