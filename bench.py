@@ -370,13 +370,14 @@ def run_config4(args, world, rank, device):
     achieved = alg_bytes / (k_ms * 1e-3)
     layout = int(binding.struct(d).layout)
     fn_name = ("Log1p" if args.function == "log1p" else args.function) if args.variant == "4a" else "PushPull<Log1p,Log>"
-    kernel = ("k_fused_ring<2,%s,%s> (LDS-resident rows, chunk ring filled through the producers' VGPRs, loss reduced in "
-              "the same launch) + k_ring_combine (adds the column groups' partial rows)"
-              % (fn_name, "codebook" if binding.codebook else "fp32 stream")) if layout == 1 \
+    kernel = ("k_fused_ring<2,%s,%s> (LDS-resident rows, chunk ring filled through the producers' VGPRs; loss and, with two "
+              "column groups per row block, the groups' rows added in the same launch; k_ring_combine behind it otherwise)"
+              % (fn_name, binding.stream_kind + " stream")) if layout == 1 \
         else "k_fused_small<2,G,%s> (CSR) + 1-block loss finalize" % fn_name
     traffic, traffic_src = (None, None)
     if world == 1 and args.emulate_world <= 1 and n == N_ITEMS and args.variant == "4a" and args.function == "log1p":
-        traffic, traffic_src = pmc_traffic("ring_codebook" if binding.codebook else "ring_fp32" if layout == 1 else "csr")
+        traffic, traffic_src = pmc_traffic({"codebook": "ring_codebook", "byte index": "ring_bytes"}.get(binding.stream_kind, "ring_fp32")
+                                           if layout == 1 else "csr")
 
     if rank != 0:
         return None
@@ -402,7 +403,8 @@ def run_config4(args, world, rank, device):
                    "kernel_ms_per_rank": per_rank_ms,
                    "parameter_stream": ("codebook: %d distinct weights ride in the packed half-edge word "
                                         "(4 B/half-edge)" % (2 if args.variant == "4a" else 3) if binding.codebook
-                                        else "fp32 weight per half-edge (8 B/half-edge)"),
+                                        else "byte index: one index byte per half-edge beside the packed word (5 B/half-edge)"
+                                        if binding.byte_stream else "fp32 weight per half-edge (8 B/half-edge)"),
                    "loss": gpu_loss},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BPS / 1e9,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_BPS, "traffic": traffic,
@@ -413,10 +415,13 @@ def run_config4(args, world, rank, device):
         # secondary: the general case (continuous per-edge parameters, configs 2 / 3) streams an
         # fp32 parameter per half-edge
         os.environ["MDE_CODEBOOK"] = "0"
+        os.environ["MDE_BYTE_STREAM"] = "0"
         b2 = Binding(plan, pymde_amd.penalties.Log1p(w.clone()))
         fused_evaluate(b2, X, grad, loss)
+        assert b2.stream_kind == "fp32", b2.stream_kind
         k2, _ = time_launches(lambda: fused_evaluate(b2, X, grad, loss), max(args.steps, 1), device)
         os.environ.pop("MDE_CODEBOOK")
+        os.environ.pop("MDE_BYTE_STREAM")
         out["config"]["fp32_parameter_stream"] = {
             "kernel_ms": k2, "value": p / (k2 * 1e-3), "unit": "edges/s/iter (kernel time)",
             "roofline_frac": alg_bytes / (k2 * 1e-3) / HBM_PEAK_BPS}
@@ -881,6 +886,7 @@ def main():
         sys.exit(self_launch(args))
     if args.no_codebook:
         os.environ["MDE_CODEBOOK"] = "0"
+        os.environ["MDE_BYTE_STREAM"] = "0"
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
