@@ -452,10 +452,22 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         float xr[D], xc[D], p0;
       };
       // packed word -> LDS byte addresses (ring_pack_word)
+      // (MDE_RING_PROBE_ROWLIN / _COLLIN: timing probes with wrong results -- the row / column side of every entry at
+      // a conflict-free address, same instruction count: what the LDS bank conflicts of that side cost)
+#ifdef MDE_RING_PROBE_ROWLIN
+      auto row_of = [&](uint32_t w) __attribute__((always_inline)) { return ((w & 0x7f00u) | ((uint32_t)lane << 3)) & 0xfff8u; };
+#else
       auto row_of = [&](uint32_t w) __attribute__((always_inline)) { return D == 2 ? (w & 0xfff8u) : (w & 0xfffcu); };
+#endif
+#ifdef MDE_RING_PROBE_COLLIN
+      auto col_of = [&](uint32_t w) __attribute__((always_inline)) {
+        return (((w >> 13) & 0x3f000u) | ((uint32_t)lane << 3)) & 0x3fff8u;
+      };
+#else
       auto col_of = [&](uint32_t w) __attribute__((always_inline)) {
         return D == 2 ? ((w >> 13) & 0x3fff8u) : ((w >> 14) & 0x3fffcu);
       };
+#endif
       auto issue_x = [&](uint32_t w, float p0, uint32_t bi4) __attribute__((always_inline)) {
         Pre r;
         // (codebook index: the bits the row address leaves free -- 3 at d = 2, 2 at d = 3; byte index: bi4 = 4 x index)
