@@ -268,12 +268,31 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_vec_stats(int64_t N, const float*
       }
     }
   }
-  for (; i < N4; i += stride) {
-    const float4 ga = g4[i], da = d ? d4[i] : z4, xa = x ? x4[i] : z4;
-    one(ga.x, da.x, xa.x);
-    one(ga.y, da.y, xa.y);
-    one(ga.z, da.z, xa.z);
-    one(ga.w, da.w, xa.w);
+  // the remaining trips (fewer than four when d and x are given), their loads issued TOGETHER from clamped
+  // indices and only the arithmetic predicated (round 5: 2M-element vectors on 256 workgroups are ~8 float4 per
+  // thread -- one unrolled trip and then three or four dependent ones, a memory latency each: 18 -> ~11 us; the
+  // elements a thread adds, and their order, are what they were)
+  while (i < N4) {
+    float4 ga[4], da[4], xa[4];
+    bool in[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t iu = i + u * stride;
+      in[u] = iu < N4;
+      const int64_t ic = in[u] ? iu : N4 - 1;
+      ga[u] = g4[ic];
+      da[u] = d ? d4[ic] : z4;
+      xa[u] = x ? x4[ic] : z4;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (in[u]) {
+        one(ga[u].x, da[u].x, xa[u].x);
+        one(ga[u].y, da[u].y, xa[u].y);
+        one(ga[u].z, da[u].z, xa[u].z);
+        one(ga[u].w, da[u].w, xa[u].w);
+      }
+    i += 4 * stride;
   }
   for (int64_t i = (N4 << 2) + (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N; i += stride)
     one(g[i], d ? d[i] : 0.0f, x ? x[i] : 0.0f);
@@ -317,17 +336,41 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_colsum(int64_t n, int d, int dp, 
   for (int c0 = 0; c0 < d; c0 += dp) {
     const int c = c0 + tc;
     double s = 0.0;
-    if (c < d)
-      for (int64_t r = (int64_t)blockIdx.x * rpp + tr; r < n; r += (int64_t)gridDim.x * rpp) {
-        float z;
-        if (STEP) {
-          z = fmaf(t, DIR[r * d + c], X0[r * d + c]);
-          Z[r * d + c] = z;
-        } else {
-          z = Z[r * d + c];
+    if (c < d) {
+      // eight rows of the thread's sequence in flight (clamped indices, the arithmetic predicated; round 5: one
+      // row per trip was a memory latency per row -- 17 us for 24 MB at n = 1M, d = 2); the rows a thread adds,
+      // and their order, are what they were
+      const int64_t rstep = (int64_t)gridDim.x * rpp;
+      for (int64_t r0 = (int64_t)blockIdx.x * rpp + tr; r0 < n; r0 += 8 * rstep) {
+        float a[8], b[8];
+        bool in[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int64_t r = r0 + u * rstep;
+          in[u] = r < n;
+          const int64_t rc = in[u] ? r : n - 1;
+          if (STEP) {
+            a[u] = DIR[rc * d + c];
+            b[u] = X0[rc * d + c];
+          } else {
+            a[u] = Z[rc * d + c];
+            b[u] = 0.0f;
+          }
         }
-        s += (double)z;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (in[u]) {
+            float z;
+            if (STEP) {
+              z = fmaf(t, a[u], b[u]);
+              Z[(r0 + u * rstep) * d + c] = z;
+            } else {
+              z = a[u];
+            }
+            s += (double)z;
+          }
       }
+    }
     __syncthreads();
     sm[threadIdx.x] = s;
     __syncthreads();
@@ -360,9 +403,19 @@ __global__ __launch_bounds__(64) void k_colsum_final(int nb, int d, int64_t n, c
 }
 __global__ __launch_bounds__(MDE_BLOCK) void k_sub_mean(int64_t N, int d, float* __restrict__ Z,
                                                         const double* __restrict__ mean) {
-  for (int64_t i = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i < N;
-       i += (int64_t)gridDim.x * MDE_BLOCK)
-    Z[i] = (float)((double)Z[i] - mean[i % d]);
+  const int64_t stride = (int64_t)gridDim.x * MDE_BLOCK;
+  for (int64_t i0 = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i0 < N; i0 += 4 * stride) {
+    float z[4];
+    bool in[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      in[u] = i0 + u * stride < N;
+      z[u] = Z[in[u] ? i0 + u * stride : N - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (in[u]) Z[i0 + u * stride] = (float)((double)z[u] - mean[(i0 + u * stride) % d]);
+  }
 }
 
 static int pow2_ge(int x) {
