@@ -839,3 +839,53 @@ def test_pushpull_on_the_ring_kernel_at_near_coincident_points(monkeypatch):
     E2 = float(mde2.average_distortion(torch.tensor(X, device=DEV)))
     wE2, _ = oracle.average_distortion(edges[keep], X, oracle.func("LOG1P", w[keep], None, (1.5,), "LOG", (1.0,)), want_grad=False)
     assert E2 == pytest.approx(wE2, rel=1e-5)
+
+
+def test_ring_layout_and_fold_options_agree_bitwise():
+    """Round-5 options of the ring path against the default on one problem with two column groups per row block
+    (where the groups' rows are added inside the launch): `MDE_RING_FOLD=0` (the k_ring_combine launch instead) and
+    `MDE_RING_ASSIGN=1` (the sweep-balanced row -> wave map: a row's entries still reach its accumulator in chunk
+    order, whichever wave owns it) must give the same bits, and the oracle's numbers."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import pymde_amd
+rng = np.random.default_rng(3)
+n, p, d = 600000, 6000000, 2
+i = rng.integers(0, n, p); j = (i + 1 + rng.integers(0, n - 1, p)) %% n
+e = np.stack([np.minimum(i, j), np.maximum(i, j)], 1)
+w = (1.0 + (rng.random(p) < 0.3)).astype(np.float32)
+X = rng.standard_normal((n, d)).astype(np.float32)
+mde = pymde_amd.MDE(n, d, torch.tensor(e, device='cuda'), pymde_amd.penalties.Log1p(torch.tensor(w, device='cuda')))
+Xt = torch.tensor(X, device='cuda', requires_grad=True)
+E = mde.average_distortion(Xt); E.backward()
+assert mde._binding().struct(d).layout == 1
+np.save(sys.argv[1], np.concatenate([Xt.grad.cpu().numpy().ravel(), [float(E)]]))
+"""
+    root = str(__import__("conftest").ROOT)
+    outs = {}
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        for name, env in (("default", {}), ("nofold", {"MDE_RING_FOLD": "0"}), ("assign", {"MDE_RING_ASSIGN": "1"})):
+            path = os.path.join(td, name + ".npy")
+            out = subprocess.run([sys.executable, "-c", code % root, path], env=dict(os.environ, MDE_PANEL="1", **env),
+                                 capture_output=True, text=True, timeout=600)
+            assert out.returncode == 0, (name, out.stderr[-2000:])
+            outs[name] = np.load(path)
+    assert np.array_equal(outs["default"], outs["nofold"]), "in-launch sum of the two column groups != k_ring_combine"
+    assert np.array_equal(outs["default"][:-1], outs["assign"][:-1]), "balanced row -> wave map changed a gradient bit"
+    np.testing.assert_allclose(outs["assign"][-1], outs["default"][-1], rtol=1e-6)
+    # ... and they are the oracle's numbers
+    rng = np.random.default_rng(3)
+    n, p, d = 600000, 6000000, 2
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    e = np.stack([np.minimum(i, j), np.maximum(i, j)], 1)
+    w = (1.0 + (rng.random(p) < 0.3)).astype(np.float32)
+    X = rng.standard_normal((n, d)).astype(np.float32)
+    wE, wgrad = oracle.average_distortion(e, X, oracle.func("LOG1P", w, None, (1.5,)))
+    assert outs["default"][-1] == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(outs["default"][:-1].reshape(n, d), wgrad)
