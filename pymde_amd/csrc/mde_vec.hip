@@ -1987,7 +1987,9 @@ __global__ __launch_bounds__(64) void k_lbfgs_direction(LbDev* __restrict__ dv, 
 //      itself in phase 1), publish the statistics partials; the last workgroup to arrive reduces
 //      them and writes the bookkeeping back to LbDev (everyone has finished reading it by then).
 #define MDE_LB_FUSED_LD 16       // history <= 15
+#ifndef MDE_LB_FUSED_MAXN
 #define MDE_LB_FUSED_MAXN (1 << 18)
+#endif
 #define MDE_LB_FUSED_MAXBLOCKS 512
 // the flag words of the fused kernel: doubles [MDE_WS_LB_FLAGS, MDE_WS_LB_VERDICT) of the work buffer's small area
 // (three rows of MDE_LB_FUSED_MAXBLOCKS 32-bit words; zero or an older epoch between launches), the verdict
