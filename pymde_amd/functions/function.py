@@ -55,6 +55,32 @@ class HipSpec(object):
         return f
 
 
+def read_scalars(module, names):
+    """The values of the scalar attributes ``names`` of a function object as Python floats.
+
+    A scalar that is a tensor on the GPU (the reference registers ``exponent`` / ``threshold`` as buffers,
+    function.py:22-26, so ``mde.to(device)`` moves them) costs a device-to-host copy AND a stream
+    synchronisation per ``.item()``; the fused path asks for the scalars on every evaluation (has a parameter
+    changed?), so the value is remembered per attribute and read again only when the attribute holds another
+    tensor, another storage, or the tensor's version counter says it was written in place."""
+    cache = module.__dict__.setdefault("_scalar_values", {})
+    out = []
+    for name in names:
+        x = getattr(module, name)
+        if not isinstance(x, torch.Tensor):
+            out.append(float(x))
+            continue
+        if not x.is_cuda:
+            out.append(float(x.item()))
+            continue
+        hit = cache.get(name)
+        if hit is None or hit[0] is not x or hit[1] != x._version or hit[2] != x.data_ptr():
+            hit = (x, x._version, x.data_ptr(), float(x.item()))
+            cache[name] = hit
+        out.append(hit[3])
+    return out
+
+
 def _as_param(t, device):
     return t.detach().to(device=device, dtype=torch.float32).contiguous().reshape(-1)
 

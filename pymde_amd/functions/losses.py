@@ -11,11 +11,7 @@ Same names, constructor arguments and semantics as ``pymde.functions.losses``
 import torch
 
 from pymde_amd import util
-from pymde_amd.functions.function import Function, HipSpec, KIND
-
-
-def _scalar(x):
-    return float(x.item()) if isinstance(x, torch.Tensor) else float(x)
+from pymde_amd.functions.function import Function, HipSpec, KIND, read_scalars
 
 
 class _Loss(Function):
@@ -28,7 +24,7 @@ class _Loss(Function):
         self.deviations = util.to_tensor(deviations)
 
     def _scalars(self):
-        vals = [_scalar(getattr(self, a)) for a in self._scalar_attrs]
+        vals = read_scalars(self, self._scalar_attrs)
         return tuple(vals + [0.0] * (3 - len(vals)))
 
     def _hip_spec(self):

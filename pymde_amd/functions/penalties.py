@@ -13,11 +13,7 @@ only carries the parameters.
 import torch
 
 from pymde_amd import util
-from pymde_amd.functions.function import Function, HipSpec, KIND
-
-
-def _scalar(x):
-    return float(x.item()) if isinstance(x, torch.Tensor) else float(x)
+from pymde_amd.functions.function import Function, HipSpec, KIND, read_scalars
 
 
 class _Penalty(Function):
@@ -31,7 +27,7 @@ class _Penalty(Function):
         self.weights = util.to_tensor(weights)
 
     def _scalars(self):
-        vals = [_scalar(getattr(self, a)) for a in self._scalar_attrs]
+        vals = read_scalars(self, self._scalar_attrs)
         return tuple(vals + [0.0] * (3 - len(vals)))
 
     def _hip_spec(self):

@@ -202,3 +202,51 @@ def test_reference_signature_seam_average_distortion():
     assert float(E3) == pytest.approx(wE3, rel=1e-5)
     assert_grad_close(g3.cpu().numpy(), wgrad3)
     ad._PLAN_CACHE.clear()
+
+
+def test_scalar_parameters_on_the_gpu_are_read_once_and_followed_when_they_change():
+    """The reference registers ``exponent`` / ``threshold`` as buffers [ref: pymde/functions/function.py:22-26,
+    penalties.py:318], so they live on the GPU with the rest of the problem.  The fused path needs them as kernel
+    arguments and asks on every evaluation whether a parameter has changed: that question must not cost a
+    device-to-host copy and a stream synchronisation per evaluation (round 5: it did -- 15 us of every timed
+    step of bench.py), and an in-place write or a new tensor must still be seen."""
+    import pymde_amd
+    from unittest import mock
+    rng = np.random.default_rng(5)
+    n, d, p = 2000, 2, 30000
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    key = np.unique(np.minimum(i, j).astype(np.int64) * n + np.maximum(i, j))
+    edges_np = np.stack([key // n, key % n], 1)
+    p = len(edges_np)
+    w_np = (1.0 + (rng.random(p) < 0.3)).astype(np.float32)
+    X_np = rng.standard_normal((n, d)).astype(np.float32)
+    f = pymde_amd.penalties.Log1p(_t(w_np), exponent=_t(1.5))
+    assert f.exponent.is_cuda
+    mde = pymde_amd.MDE(n, d, torch.tensor(edges_np, device=DEV), f)
+    X = _t(X_np)
+
+    def value(exponent):
+        got = float(mde.average_distortion(X))
+        want, _ = oracle.average_distortion(edges_np, X_np, oracle.func("LOG1P", w_np, None, (exponent,)))
+        assert got == pytest.approx(want, rel=1e-5)
+        return got
+
+    v15 = value(1.5)
+    reads = []
+    real_item = torch.Tensor.item
+    with mock.patch.object(torch.Tensor, "item", lambda self: (reads.append(self.shape), real_item(self))[1]):
+        for _ in range(3):
+            mde.average_distortion(X)
+            f._hip_spec()
+    assert reads == [], "a scalar parameter was copied to the host again although nothing changed: %r" % reads
+    f.exponent.fill_(2.0)                 # in place: the version counter moves
+    v2 = value(2.0)
+    assert v2 != v15
+    f.exponent = _t(1.0)                  # another tensor
+    v1 = value(1.0)
+    assert v1 != v2
+    h = pymde_amd.losses.Huber(_t(np.abs(w_np)), threshold=_t(0.25))
+    assert h._scalars()[0] == 0.25
+    h.threshold.mul_(2.0)
+    assert h._scalars()[0] == 0.5
