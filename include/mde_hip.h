@@ -293,6 +293,10 @@ int mde_center(int64_t n, int32_t d, float* Z, double* work, void* stream);
 /* Anchored (constraints.py:143-164): rows[anchors] = values (or 0 when values == NULL). */
 int mde_anchor_rows(int64_t n_anchors, int32_t d, const int64_t* anchors, const float* values,
                     float* Z, void* stream);
+/* Rows on a sphere (constraints.py:203-231, `_Sphere`: private in the reference, used by no recipe).
+ * X == NULL: the retraction Z[r] <- (Z[r] / |Z[r]|) * radius (:225-231); else the tangent projection
+ * Z[r] -= (1 / radius) (Z[r] . X[r]) X[r] (:214-223; the reference's own scale, 1 / radius). */
+int mde_sphere_rows(int64_t n, int32_t d, const float* X, float* Z, float radius, void* stream);
 /* Standardized tangent projection Z -= (1/n) X (Z^T X)  (constraints.py:186-192). */
 int mde_std_tangent(int64_t n, int32_t d, const float* X, float* Z, double* work, void* stream);
 /* Standardized retraction: Z <- sqrt(n) * polar factor of (Z - mean)  (util.py:129-161),

@@ -183,6 +183,20 @@ def anchor_retract(Z, anchors, values):
     return Z
 
 
+def sphere_tangent(X, Z, radius):
+    """Z - (1/radius) diag(Z X^T) X, row by row [ref: constraints.py:214-223 -- the reference's scale is
+    1/radius, not 1/radius^2]."""
+    X = np.asarray(X, dtype=np.float64)
+    Z = np.asarray(Z, dtype=np.float64)
+    return Z - (1.0 / radius) * (Z * X).sum(axis=1)[:, None] * X
+
+
+def sphere_retract(Z, radius):
+    """radius Z / |Z|, row by row [ref: constraints.py:225-231]."""
+    Z = np.asarray(Z, dtype=np.float64)
+    return radius * Z / np.linalg.norm(Z, axis=1)[:, None]
+
+
 # ---------------------------------------------------------------- edge plan (integer, bit-exact)
 def plan_csr(n, edges, row_lo=0, row_hi=None):
     """The symmetrised incidence CSR the HIP plan must produce: rows v in [row_lo, row_hi),

@@ -79,6 +79,7 @@ SYMBOLS = {
     "mde_scatter": (c_i32, [c_vp, c_vp, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp]),
     "mde_center": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_vp]),
     "mde_anchor_rows": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "mde_sphere_rows": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_f32, c_vp]),
     "mde_std_tangent": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "mde_std_retract": (c_i32, [c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "mde_center_step": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp]),

@@ -163,7 +163,8 @@ class _Standardized(Constraint):
 
 class _Sphere(Constraint):
     """Rows on a sphere of the given radius (private in the reference, unused by the recipes
-    [ref: constraints.py:203-231]); plain tensor arithmetic, takes the generic solver path."""
+    [ref: constraints.py:203-231]).  Both projections are one row-wise HIP kernel (``mde_sphere_rows``); the
+    solver reaches them through its generic (callback) path."""
 
     def __init__(self, radius):
         self.radius = radius
@@ -172,21 +173,29 @@ class _Sphere(Constraint):
     def name(self):
         return "sphere"
 
+    def _rows(self, W, device, X):
+        lib = _lib.load()
+        n, d = W.shape
+        with torch.no_grad(), torch.cuda.device(device):
+            _lib.check(lib.mde_sphere_rows(n, d, _lib.ptr(X) if X is not None else None, _lib.ptr(W),
+                                           float(self.radius), _lib.stream_ptr(device)))
+        return W
+
     def initialization(self, n_items, embedding_dim, device=None):
         X = _randn(n_items, embedding_dim, device)
-        return self.radius * (X / X.norm(dim=1)[:, None])
+        return self.project_onto_constraint(X, inplace=True)
 
     def project_onto_tangent_space(self, X, Z, inplace=True):
-        dual = (Z * X).sum(dim=1)
-        offset = (1.0 / self.radius) * dual[:, None] * X
-        return Z.sub_(offset) if inplace else Z - offset
+        # Z - (1/radius) diag(Z X^T) X   [ref: constraints.py:214-223]
+        W, device = _prepare(Z, inplace)
+        if X.dtype != torch.float32 or not X.is_contiguous() or X.device != W.device:
+            X = X.detach().to(device=W.device, dtype=torch.float32).contiguous()
+        return self._rows(W, device, X.detach())
 
     def project_onto_constraint(self, Z, inplace=True):
-        if inplace:
-            Z.div_(Z.norm(dim=1)[:, None])
-            Z.mul_(self.radius)
-            return Z
-        return self.radius * Z / Z.norm(dim=1)[:, None]
+        # radius Z / |Z| row by row   [ref: constraints.py:225-231]
+        W, device = _prepare(Z, inplace)
+        return self._rows(W, device, None)
 
 
 __Centered = _Centered()

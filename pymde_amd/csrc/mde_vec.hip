@@ -483,6 +483,69 @@ extern "C" int mde_anchor_rows(int64_t n_anchors, int32_t d, const int64_t* anch
   return MDE_OK;
 }
 
+// ---------------------------------------------------------------- rows on a sphere
+// [ref: constraints.py:203-231, `_Sphere`: private there, used by no recipe]  X == NULL: the retraction
+// Z[r] <- (Z[r] / |Z[r]|) radius (divide, then multiply, as the reference does); else the tangent projection
+// Z[r] -= (1 / radius) (Z[r] . X[r]) X[r] -- the reference's own scale, 1 / radius and not 1 / radius^2.
+// Narrow rows: one thread per row; wide rows: one wave per row, lanes strided over the columns.
+template <bool TANGENT>
+__global__ __launch_bounds__(MDE_BLOCK) void k_sphere_narrow(int64_t n, int d, const float* __restrict__ X,
+                                                             float* __restrict__ Z, float radius) {
+  for (int64_t r = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; r < n; r += (int64_t)gridDim.x * MDE_BLOCK) {
+    float* z = Z + r * d;
+    float s = 0.0f;
+    if (TANGENT) {
+      const float* x = X + r * d;
+      for (int c = 0; c < d; ++c) s = fmaf(z[c], x[c], s);
+      const float k = (1.0f / radius) * s;
+      for (int c = 0; c < d; ++c) z[c] -= k * x[c];
+    } else {
+      for (int c = 0; c < d; ++c) s = fmaf(z[c], z[c], s);
+      const float nrm = sqrtf(s);
+      for (int c = 0; c < d; ++c) z[c] = (z[c] / nrm) * radius;
+    }
+  }
+}
+template <bool TANGENT>
+__global__ __launch_bounds__(MDE_BLOCK) void k_sphere_wide(int64_t n, int d, const float* __restrict__ X,
+                                                           float* __restrict__ Z, float radius) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wpg = MDE_BLOCK / 64;
+  for (int64_t r = (int64_t)blockIdx.x * wpg + (threadIdx.x >> 6); r < n; r += (int64_t)gridDim.x * wpg) {
+    float* z = Z + r * d;
+    const float* x = TANGENT ? X + r * d : z;
+    double s = 0.0;
+    for (int c = lane; c < d; c += 64) s += (double)z[c] * (double)x[c];
+    s = mde_wave_sum(s);  // (a butterfly: every lane holds the sum)
+    if (TANGENT) {
+      const float k = (1.0f / radius) * (float)s;
+      for (int c = lane; c < d; c += 64) z[c] -= k * x[c];
+    } else {
+      const float nrm = sqrtf((float)s);
+      for (int c = lane; c < d; c += 64) z[c] = (z[c] / nrm) * radius;
+    }
+  }
+}
+extern "C" int mde_sphere_rows(int64_t n, int32_t d, const float* X, float* Z, float radius, void* stream) {
+  if (n <= 0 || d <= 0 || !Z || !(radius > 0.0f)) return MDE_E_INVALID;
+  hipStream_t st = mde_stream(stream);
+  if (d <= 32) {
+    const int nb = mde_grid(n, MDE_BLOCK);
+    if (X)
+      hipLaunchKernelGGL(k_sphere_narrow<true>, dim3(nb), dim3(MDE_BLOCK), 0, st, n, d, X, Z, radius);
+    else
+      hipLaunchKernelGGL(k_sphere_narrow<false>, dim3(nb), dim3(MDE_BLOCK), 0, st, n, d, X, Z, radius);
+  } else {
+    const int nb = mde_grid(n, MDE_BLOCK / 64);
+    if (X)
+      hipLaunchKernelGGL(k_sphere_wide<true>, dim3(nb), dim3(MDE_BLOCK), 0, st, n, d, X, Z, radius);
+    else
+      hipLaunchKernelGGL(k_sphere_wide<false>, dim3(nb), dim3(MDE_BLOCK), 0, st, n, d, X, Z, radius);
+  }
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
 // ---------------------------------------------------------------- Gram matrices  out = A^T B
 // (a) tiny widths: one thread per row, da*db register accumulators in double
 template <int DA, int DB>

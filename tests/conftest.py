@@ -29,6 +29,11 @@ def golden_constraints():
 
 
 @pytest.fixture(scope="session")
+def golden_sphere():
+    return load_golden("sphere")
+
+
+@pytest.fixture(scope="session")
 def golden_trajectories():
     return load_golden("trajectories")
 

@@ -20,6 +20,7 @@ Fixtures
   cycle.npz         BASELINE config 1 scaled down: preserve_distances on a cycle graph,
                     losses.Quadratic, all pairs
   linesearch.npz    trial sequences of _strong_wolfe on scalar problems (lbfgs.py:44-253)
+  sphere.npz        the private _Sphere constraint's two maps (constraints.py:203-231)
   api.npz           pca / align / rotate, k-NN with max_distance, graph k-NN (shortest-path and
                     direct), the graphs behind laplacian_embedding and preserve_neighbors(Graph)
 """
@@ -554,6 +555,26 @@ def gen_linesearch(pymde, torch):
     print("linesearch.npz:", {n: len(out[n + "__trials"]) for n in out["names"]})
 
 
+def gen_sphere(pymde, torch):
+    """The private `_Sphere` constraint (constraints.py:203-231): tangent projection and retraction."""
+    from pymde import constraints
+    rng = np.random.default_rng(11)
+    out = {}
+    cases = [(7, 2, 1.0), (300, 3, 2.5), (200, 40, 0.5), (100, 128, 3.0)]
+    out["cases"] = np.array(cases)
+    for (n, d, radius) in cases:
+        c = constraints._Sphere(radius)
+        Z = rng.standard_normal((n, d)).astype(np.float32)
+        X = c.project_onto_constraint(torch.tensor(rng.standard_normal((n, d)).astype(np.float32)), inplace=False)
+        tag = "%dx%d" % (n, d)
+        out["Z_" + tag] = Z
+        out["X_" + tag] = X.numpy()
+        out["retract_" + tag] = c.project_onto_constraint(torch.tensor(Z), inplace=False).numpy()
+        out["tangent_" + tag] = c.project_onto_tangent_space(X, torch.tensor(Z), inplace=False).numpy()
+    np.savez_compressed(os.path.join(HERE, "sphere.npz"), **out)
+    print("sphere.npz written")
+
+
 def main():
     pymde = import_reference()
     import torch
@@ -572,6 +593,7 @@ def main():
     gen_cycle(pymde, torch)
     gen_preprocess(pymde, torch)
     gen_api(pymde, torch)
+    gen_sphere(pymde, torch)
 
 
 if __name__ == "__main__":

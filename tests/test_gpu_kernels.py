@@ -387,6 +387,49 @@ def test_constraints_against_reference_golden(golden_constraints):
                                   g["anchor_retract"])
 
 
+def test_sphere_constraint_against_reference_golden_and_oracle(golden_sphere):
+    """`_Sphere` (private in the reference, constraints.py:203-231) on the HIP row kernel: the reference's own
+    outputs, then the oracle on a ragged set of shapes (one thread per row up to d = 32, one wave per row above),
+    and a solve through the generic path that stays on the sphere."""
+    import pymde_amd
+    from pymde_amd import constraints
+    g = golden_sphere
+    for n, d, radius in g["cases"]:
+        tag = "%dx%d" % (int(n), int(d))
+        c = constraints._Sphere(float(radius))
+        Z = torch.tensor(g["Z_" + tag], device=DEV)
+        X = torch.tensor(g["X_" + tag], device=DEV)
+        R = c.project_onto_constraint(Z, inplace=False)
+        np.testing.assert_allclose(R.cpu().numpy(), g["retract_" + tag], rtol=1e-5, atol=1e-6)
+        T = c.project_onto_tangent_space(X, Z, inplace=False)
+        np.testing.assert_allclose(T.cpu().numpy(), g["tangent_" + tag], rtol=1e-5, atol=1e-5)
+        assert torch.equal(Z, torch.tensor(g["Z_" + tag], device=DEV))   # inplace=False leaves Z alone
+        Zi = Z.clone()
+        assert c.project_onto_constraint(Zi, inplace=True) is Zi and torch.equal(Zi, R)
+    rng = np.random.default_rng(2)
+    for n, d, radius in [(1, 1, 1.0), (3, 32, 2.0), (5, 33, 0.25), (100001, 2, 1.5), (4097, 65, 1.0), (50, 200, 7.0)]:
+        c = constraints._Sphere(radius)
+        Zn = rng.standard_normal((n, d)).astype(np.float32)
+        Xn = oracle.sphere_retract(rng.standard_normal((n, d)), radius).astype(np.float32)
+        R = c.project_onto_constraint(torch.tensor(Zn, device=DEV), inplace=False).cpu().numpy()
+        np.testing.assert_allclose(R, oracle.sphere_retract(Zn, radius), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(np.linalg.norm(R.astype(np.float64), axis=1), radius, rtol=1e-5)
+        T = c.project_onto_tangent_space(torch.tensor(Xn, device=DEV), torch.tensor(Zn, device=DEV), inplace=False)
+        np.testing.assert_allclose(T.cpu().numpy(), oracle.sphere_tangent(Xn, Zn, radius), rtol=1e-5, atol=1e-5)
+    X0 = constraints._Sphere(2.0).initialization(1000, 3, device=DEV)
+    np.testing.assert_allclose(X0.norm(dim=1).cpu().numpy(), 2.0, rtol=1e-5)
+    n, p = 400, 3000
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    w = torch.tensor(rng.uniform(0.5, 2, p).astype(np.float32), device=DEV)
+    mde = pymde_amd.MDE(n, 3, np.stack([i, j], 1), pymde_amd.penalties.Quadratic(w), constraint=constraints._Sphere(1.0))
+    torch.manual_seed(1)
+    X = mde.embed(max_iter=30)
+    E = mde.solve_stats.average_distortions
+    assert E[-1] < E[0]
+    np.testing.assert_allclose(X.norm(dim=1).cpu().numpy(), 1.0, rtol=1e-5)
+
+
 @pytest.mark.parametrize("n,d", [(2, 2), (10, 3), (100, 3), (1000, 2), (1000, 3), (1000, 250), (5000, 128),
                                  (3000, 64), (777, 96), (600000, 2), (350001, 3)])
 def test_proj_standardized_property(n, d):
