@@ -80,10 +80,11 @@ class GradExchange(object):
         # NCCL / RCCL in-place all-gather form), so no staging copy; rows owned by other ranks
         # are overwritten and need not be zeroed first.  The loss shares are summed by the
         # collective itself (one float: no gather + torch.sum launch).
-        h1 = dist.all_gather_into_tensor(buf[:N], buf[lo:hi], group=self.group, async_op=True)
-        h2 = dist.all_reduce(buf[N:N + 1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        h1.wait()
-        h2.wait()
+        # (plain calls, not async_op=True + wait(): with RCCL both forms only make the current STREAM wait for the
+        # collective, but the handles cost the host 45 us per step against 17 -- and an 8-way shard of config 4 has
+        # 38 us of GPU work per step to hide the host behind; tools/exchange_host_cost.py)
+        dist.all_gather_into_tensor(buf[:N], buf[lo:hi], group=self.group)
+        dist.all_reduce(buf[N:N + 1], op=dist.ReduceOp.SUM, group=self.group)
         return buf
 
     def needs_zero(self):
@@ -329,10 +330,9 @@ class ShardedEvaluator(object):
         if not active:
             return gbuf
         if chunked:
-            h = dist.all_reduce(gbuf[N:N + 1], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            dist.all_reduce(gbuf[N:N + 1], op=dist.ReduceOp.SUM, group=self.group)
             for w in handles:
                 w.wait()
-            h.wait()
             return gbuf
         if not want_grad:
             dist.all_reduce(gbuf[N:N + 1], op=dist.ReduceOp.SUM, group=self.group)
