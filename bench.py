@@ -86,15 +86,42 @@ def pmc_traffic(key):
     return v, "profiles/r05_pmc_traffic.json (rocprofv3 --pmc, bytes/launch; the ring kernel, which adds its two column groups itself)"
 
 
-def make_workload(device, n=N_ITEMS, deg=OUT_DEGREE, d=DIM):
+def make_workload(device, n=N_ITEMS, deg=OUT_DEGREE, d=DIM, graph="uniform"):
     """SURVEY 8d config 4a, generated on the device from fixed seeds (torch's device generator
-    instead of numpy's default_rng(0): same distribution, different stream)."""
+    instead of numpy's default_rng(0): same distribution, different stream).
+
+    graph (round 6, secondary records): "uniform" -- the survey's graph; "hub" -- the same with 5e5 of its edges
+    re-pointed at ONE vertex (a hub of degree 5e5); "powerlaw" -- preferential attachment by the copy model: the
+    target of a link is, with probability 1/2, an endpoint of an EARLIER link (degrees follow a power law with
+    hubs of thousands of half-edges, and they FALL along the vertex order: the early vertices collect the edges)."""
     gen = torch.Generator(device=device)
     gen.manual_seed(0)
     p = n * deg
     src = torch.arange(n, device=device, dtype=torch.int64).repeat_interleave(deg)
     dst = torch.randint(0, n - 1, (p,), device=device, dtype=torch.int64, generator=gen)
     dst += (dst >= src).to(torch.int64)
+    if graph == "hub":
+        h = min(500_000, n // 2)
+        hub = n // 3
+        other = torch.randperm(n - 1, device=device, generator=gen)[:h]
+        other += (other >= hub).to(torch.int64)
+        idx = torch.randperm(p, device=device, generator=gen)[:h]
+        src[idx] = hub
+        dst[idx] = other
+    elif graph == "powerlaw":
+        r = torch.rand(p, device=device, generator=gen)
+        pos = (r * torch.arange(p, device=device, dtype=torch.float64).clamp_(min=1.0)).to(torch.int64)
+        coin = torch.rand(p, device=device, generator=gen) < 0.5
+        # four rounds of pointer chasing approximate the copy model (each: with probability 1/2 the source of an
+        # earlier link, else the current target)
+        base = torch.where(coin, src[pos], dst)
+        for _ in range(3):
+            base = torch.where(coin, base[pos], base)
+        dst = base
+        bad = dst == src
+        dst[bad] = (src[bad] + 1) % n
+    elif graph != "uniform":
+        raise SystemExit("unknown --graph " + graph)
     edges = torch.stack([torch.minimum(src, dst), torch.maximum(src, dst)], dim=1).contiguous()
     w = 1.0 + (torch.rand(p, device=device, generator=gen) < 0.3).to(torch.float32)
     gen.manual_seed(0)
@@ -235,9 +262,40 @@ def cpu_baseline(edges, w, X, p):
     return aten, E
 
 
-def time_launches(fn, count, device):
+SPINUP_LOG = []
+
+
+def spin_up(fn, device, group=20, tol=0.01, budget_s=0.2, label=None):
+    """Run `fn` back to back until the GPU has left its idle clocks: groups of `group` launches, each group timed with
+    one HIP-event pair, until three consecutive groups agree within `tol` or `budget_s` seconds have gone by.  (Round 5's
+    driver line -- `--steps 20` after an idle gap -- was still ramping: its 11 blocks fell from 0.207 to 0.167 ms per
+    step and a 20-launch secondary read 23 % high.)  Untimed; returns the launches it made."""
+    t0 = time.perf_counter()
+    times = []
+    n = 0
+    while True:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(group):
+            fn()
+        b.record()
+        b.synchronize()
+        n += group
+        times.append(a.elapsed_time(b))
+        if len(times) >= 3 and max(times[-3:]) <= (1.0 + tol) * min(times[-3:]):
+            break
+        if time.perf_counter() - t0 > budget_s:
+            break
+    SPINUP_LOG.append({"before": label or "timed launches", "launches": n,
+                       "last_groups_ms_per_launch": [round(t / group, 5) for t in times[-3:]]})
+    return n
+
+
+def time_launches(fn, count, device, spin=True):
     """Median / mean duration (ms) of `count` launches of fn, each bracketed by HIP events on
-    the current stream."""
+    the current stream (after a spin-up: see spin_up)."""
+    if spin:
+        spin_up(fn, device)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(count)]
     for a, b in ev:
         a.record()
@@ -271,9 +329,10 @@ def run_config4(args, world, rank, device):
     from pymde_amd import distributed
     from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
 
-    n, d = args.n, DIM
-    edges, w, X = make_workload_survey(device, n=n) if args.survey_seed else make_workload(device, n=n)
+    n, d = args.n, args.dim
+    edges, w, X = make_workload_survey(device, n=n, d=d) if args.survey_seed else make_workload(device, n=n, d=d, graph=args.graph)
     p = edges.shape[0]
+    headline_shape = n == N_ITEMS and d == DIM and args.graph == "uniform"
     if args.variant == "4b":
         # the last third of the edges repulsive (w = -1), PushAndPull(Log1p, Log)
         w = w.clone()
@@ -341,6 +400,9 @@ def run_config4(args, world, rank, device):
 
     for _ in range(args.warmup):
         step()
+    # spin-up (untimed, beside the caller's warm-up steps): until the step time has settled -- the blocks below are
+    # then steady state whatever --steps is
+    spinup = spin_up(step, device, label="headline blocks") if world == 1 else 0
     # the timed region (exactly `steps` steps between barrier + synchronize), repeated: the median
     # block is reported (a 5 ms region is at the mercy of one scheduler hiccup)
     block_s = timed_blocks(step, barrier, args.steps, max(args.blocks, 1), world, device)
@@ -370,28 +432,36 @@ def run_config4(args, world, rank, device):
     achieved = alg_bytes / (k_ms * 1e-3)
     layout = int(binding.struct(d).layout)
     fn_name = ("Log1p" if args.function == "log1p" else args.function) if args.variant == "4a" else "PushPull<Log1p,Log>"
-    kernel = ("k_fused_ring<2,%s,%s> (LDS-resident rows, chunk ring filled through the producers' VGPRs; loss and, with two "
+    ring = plan.ring_info()
+    kernel = ("k_fused_ring<%d,%s,%s> (LDS-resident rows, chunk ring filled through the producers' VGPRs; loss and, with two "
               "column groups per row block, the groups' rows added in the same launch; k_ring_combine behind it otherwise)"
-              % (fn_name, binding.stream_kind + " stream")) if layout == 1 \
-        else "k_fused_small<2,G,%s> (CSR) + 1-block loss finalize" % fn_name
+              % (d, fn_name, binding.stream_kind + " stream")) if layout == 1 \
+        else "k_fused_flat<%d,%s> (CSR, edge-balanced tiles) + k_flat_fixup" % (d, fn_name)
+    if layout == 1 and ring["hub_rows"]:
+        kernel += " + k_hub_rows / k_hub_finish for %d peeled hub rows (%d half-edges)" % (ring["hub_rows"], ring["hub_half_edges"])
+    if layout == 1 and ring["permuted"]:
+        kernel += "; row blocks dealt by degree"
     traffic, traffic_src = (None, None)
-    if world == 1 and args.emulate_world <= 1 and n == N_ITEMS and args.variant == "4a" and args.function == "log1p":
+    if world == 1 and args.emulate_world <= 1 and headline_shape and args.variant == "4a" and args.function == "log1p":
         traffic, traffic_src = pmc_traffic({"codebook": "ring_codebook", "byte index": "ring_bytes"}.get(binding.stream_kind, "ring_fp32")
                                            if layout == 1 else "csr")
 
     if rank != 0:
         return None
     out = {
-        "metric": "edges/sec/iter (avg_distortion fwd+bwd), n=1M |E|=50M d=2",
+        "metric": "edges/sec/iter (avg_distortion fwd+bwd), n=1M |E|=50M d=2" if headline_shape else
+                  "edges/sec/iter (avg_distortion fwd+bwd), n=%d |E|=%d d=%d, %s graph" % (n, p, d, args.graph),
         "value": p * args.steps / elapsed, "unit": "edges/s/iter",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "spinup_launches": spinup,
         "ms_per_step": 1e3 * elapsed / args.steps, "ms_per_step_median_events": float(np.median(step_ms)),
         "blocks": len(block_s), "ms_per_step_blocks": [round(1e3 * b / args.steps, 5) for b in block_s],
         "ms_per_step_fastest_block": 1e3 * min(block_s) / args.steps,
         "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[3] / SURVEY 8d config %s: n=%d, |E|=%d uniform-random edges "
-                               "(out-degree 50), d=2, %s; %s" % (args.variant, n, p, fname,
+        "config": {"workload": "BASELINE configs[3] / SURVEY 8d config %s%s: n=%d, |E|=%d %s edges "
+                               "(out-degree 50), d=%d, %s; %s" % (args.variant, "" if headline_shape else " at ANOTHER SHAPE (secondary record)",
+                                                                   n, p, {"uniform": "uniform-random", "hub": "uniform-random + one hub of degree 5e5",
+                                                                          "powerlaw": "preferential-attachment (copy model)"}[args.graph], d, fname,
                                "the survey's exact tensors: numpy default_rng(0) edges and weights, torch.manual_seed(0) "
                                "CPU randn X, built on the host and uploaded (--survey-seed)" if args.survey_seed else
                                "seeded on the device with torch.Generator(0) (the survey's recipe uses numpy "
@@ -405,13 +475,15 @@ def run_config4(args, world, rank, device):
                                         "(4 B/half-edge)" % (2 if args.variant == "4a" else 3) if binding.codebook
                                         else "byte index: one index byte per half-edge beside the packed word (5 B/half-edge)"
                                         if binding.byte_stream else "fp32 weight per half-edge (8 B/half-edge)"),
+                   "ring_layout": ring if layout == 1 else None,
+                   "ms_per_1e8_half_edges": 1e3 * elapsed / args.steps * 1e8 / max(plan.half_edges, 1),
                    "loss": gpu_loss},
         "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BPS / 1e9,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_BPS, "traffic": traffic,
                      "traffic_source": traffic_src, "kernel": kernel, "kernel_ms": k_ms,
                      "kernel_ms_mean": k_mean, "alg_bytes_per_launch": alg_bytes},
     }
-    if world == 1 and binding.codebook and not args.no_codebook and args.variant == "4a" and args.function == "log1p":
+    if world == 1 and binding.codebook and not args.no_codebook and args.variant == "4a" and args.function == "log1p" and headline_shape:
         # secondary: the general case (continuous per-edge parameters, configs 2 / 3) streams an
         # fp32 parameter per half-edge
         os.environ["MDE_CODEBOOK"] = "0"
@@ -445,11 +517,13 @@ def run_config4(args, world, rank, device):
         out["config"]["survey_seed"] = {"loss": gpu_loss, "oracle_loss": float(o_loss),
                                         "rel_diff": abs(gpu_loss - float(o_loss)) / abs(float(o_loss))}
         assert abs(float(o_loss) - gpu_loss) <= 1e-5 * abs(float(o_loss)), (o_loss, gpu_loss)
-    if world == 1 and args.emulate_world <= 1 and not args.no_cpu_baseline and args.variant == "4a" and args.function == "log1p":
+    if (world == 1 and args.emulate_world <= 1 and not args.no_cpu_baseline and args.variant == "4a" and args.function == "log1p"
+            and headline_shape):
         cb, cpu_loss = cpu_baseline(edges, w, X, p)
         out["cpu_baseline"] = cb
         out["config"]["oracle_loss"] = cpu_loss
         assert abs(cpu_loss - gpu_loss) <= 1e-5 * abs(cpu_loss), (cpu_loss, gpu_loss)
+    out["spinup"] = SPINUP_LOG
     return out
 
 
@@ -875,6 +949,11 @@ def main():
     ap.add_argument("--no-codebook", action="store_true",
                     help="stream the weights as fp32 (8 B/half-edge) even though they take 2 values")
     ap.add_argument("--n", type=int, default=N_ITEMS)
+    ap.add_argument("--dim", type=int, default=DIM, choices=(1, 2, 3, 4),
+                    help="config 4 only: embedding dimension (secondary records; the headline is d = 2)")
+    ap.add_argument("--graph", default="uniform", choices=("uniform", "hub", "powerlaw"),
+                    help="config 4 only: the survey's uniform-random graph, the same with one hub of degree 5e5, or a "
+                         "preferential-attachment graph (secondary records)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")
     ap.add_argument("--exchange-only", action="store_true",
                     help="no kernel: run only the [grad|loss] exchange of an N-rank job (CPU / gloo check of the launcher)")

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MDE_ABI_VERSION 1
+#define MDE_ABI_VERSION 2   /* 2 (round 6): mde_func.e0 / e1, mde_plan_ring_info */
 
 /* ------------------------------------------------------------------ error codes */
 #define MDE_OK 0
@@ -131,6 +131,11 @@ typedef struct mde_func {
   float n0, n1, n2;  /* scalars of `kind_neg`                                             */
   int32_t layout;    /* order of a0/a1 for mde_average_distortion: 0 = CSR plan order,
                         1 = LDS-ring order (mde_plan_layout / mde_plan_expand_layout)        */
+  const float* e0;   /* device; the per-edge arrays behind a0 / a1 in the CALLER'S edge order [p] (the   */
+  const float* e1;   /* order of the edge list given to mde_plan_create), or NULL.  Needed with layout 1
+                        when the plan's ring layout peels hub rows off to the CSR hub kernel
+                        (mde_plan_ring_info: those rows read their parameters through the plan's edge
+                        ids); ignored otherwise, and for parameters that are one broadcast scalar    */
 } mde_func;
 
 /* ------------------------------------------------------------------ the edge plan
@@ -206,6 +211,12 @@ int mde_plan_expand_bytes(const mde_plan* plan, const float* in_edge, float* out
                           int32_t* n_values_host, void* stream);
 int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in_edge,
                            float* out_half, void* stream);
+/* What the LDS-ring layout of the plan looks like (after mde_plan_layout returned 1), 16 HOST int64:
+ * [0] built (0 / 1), [1] embedding dimension, [2] rows (LDS slots) per row block, [3] row blocks, [4] column groups,
+ * [5] chunks, [6] ring slots, [7] wave iterations, [8] half-edges in the ring streams, [9] padded entries,
+ * [10] row blocks PERMUTED (rows dealt to the blocks by degree; every entry adds f / 2), [11] hub rows PEELED off to
+ * the CSR hub kernel, [12] their half-edges, [13] their segments, [14], [15] reserved (0). */
+int mde_plan_ring_info(const mde_plan* plan, int64_t* info_host);
 
 /* ------------------------------------------------------------------ edge-list preprocessing
  *  [ref: pymde/preprocess/preprocess.py:11-129]

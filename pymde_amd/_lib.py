@@ -26,7 +26,8 @@ class MdeFunc(ctypes.Structure):
     _fields_ = [("kind", c_i32), ("kind_neg", c_i32), ("a0", c_vp), ("a1", c_vp),
                 ("a0_scalar", c_i32), ("a1_scalar", c_i32),
                 ("s0", c_f32), ("s1", c_f32), ("s2", c_f32),
-                ("n0", c_f32), ("n1", c_f32), ("n2", c_f32), ("layout", c_i32)]
+                ("n0", c_f32), ("n1", c_f32), ("n2", c_f32), ("layout", c_i32),
+                ("e0", c_vp), ("e1", c_vp)]
 
 
 class MdeTurnDesc(ctypes.Structure):
@@ -58,6 +59,7 @@ SYMBOLS = {
     "mde_plan_expand": (c_i32, [c_vp, c_vp, c_vp, c_vp]),
     "mde_plan_layout": (c_i32, [c_vp, c_i32, c_vp]),
     "mde_plan_layout_half_edges": (c_i64, [c_vp, c_i32]),
+    "mde_plan_ring_info": (c_i32, [c_vp, ctypes.POINTER(c_i64)]),
     "mde_plan_expand_codebook": (c_i32, [c_vp, c_vp, c_vp, ctypes.POINTER(c_i32), c_vp]),
     "mde_plan_expand_bytes": (c_i32, [c_vp, c_vp, c_vp, ctypes.POINTER(c_i32), c_vp]),
     "mde_plan_expand_layout": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp]),
@@ -147,7 +149,7 @@ def load():
             fn = getattr(lib, name)  # AttributeError if the symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        if lib.mde_abi_version() != 1:
+        if lib.mde_abi_version() != 2:
             raise ImportError("pymde_amd: ABI version mismatch in %s" % LIB_PATH)
         _lib = lib
     return _lib

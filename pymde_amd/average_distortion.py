@@ -118,6 +118,18 @@ class EdgePlan(object):
                                                  ctypes.byref(nv), _lib.stream_ptr(self.device)))
         return out if nv.value > 0 else None
 
+    def ring_info(self):
+        """The LDS-ring layout of the plan as a dict (``mde_plan_ring_info``); ``built`` is False before the first
+        evaluation at a dimension that takes it."""
+        lib = _lib.load()
+        info = (ctypes.c_int64 * 16)()
+        _lib.check(lib.mde_plan_ring_info(self._handle, info))
+        names = ("built", "d", "rows_per_block", "row_blocks", "col_groups", "chunks", "ring_slots", "iterations",
+                 "ring_half_edges", "padded_entries", "permuted", "hub_rows", "hub_half_edges", "hub_segments")
+        out = {k: int(info[i]) for i, k in enumerate(names)}
+        out["built"], out["permuted"] = bool(out["built"]), bool(out["permuted"])
+        return out
+
     def csr(self):
         """(rowptr, nbr, eid) as int32 tensors (copies; for tests and debugging)."""
         lib = _lib.load()
@@ -194,8 +206,17 @@ class Binding(object):
             if a0 is None:
                 a0 = prep(spec.a0)
             a1 = prep(spec.a1)
-            self._keep = (a0, a1)
+            # the per-edge arrays in the caller's edge order as well: hub rows the ring layout peels off to the CSR hub
+            # kernel read their parameters through the plan's edge ids (mde_func.e0 / e1)
+            def edge_order(a):
+                if a is None or a.numel() == 1:
+                    return None
+                return a.detach().to(device=plan.device, dtype=torch.float32).contiguous().reshape(-1)
+            e0, e1 = (edge_order(spec.a0), edge_order(spec.a1)) if layout == 1 else (None, None)
+            self._keep = (a0, a1, e0, e1)
             self._struct = spec.to_struct(a0, a1)
+            self._struct.e0 = e0.data_ptr() if e0 is not None else None
+            self._struct.e1 = e1.data_ptr() if e1 is not None else None
             if self.codebook:
                 self._struct.a0_scalar = 2
             elif self.byte_stream:

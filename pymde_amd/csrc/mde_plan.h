@@ -20,7 +20,25 @@ struct mde_ring_layout {
   uint32_t* hdr = nullptr;      // [2 * n_iters] chunk window | padding flag and loss class of an iteration
   int32_t* wave_iter = nullptr; // [n_row_blocks * col_groups * NCW + 1]
   float* partial = nullptr;     // [Q * nloc * d] per-group gradient partials (Q > 1 only)
+  // Round 6 -- graphs the equal-rows, everybody-in-the-ring layout gave up on (mde_ring.hip, plan_rows):
+  //  * PERMUTED row blocks: slot_row[rb * rows_per_block + s] = local row whose x_v / accumulator live in LDS slot s
+  //    of row block rb (-1: unused), rows dealt to the blocks so that every block holds the same number of
+  //    half-edges whatever the degrees do along the vertex order; nullptr: slot s of block rb is row rb * R + s.
+  //    A permuted layout adds EVERY entry's loss term with weight 1/2 (the rows of a wave are no longer a range of
+  //    the vertex order, so "the entry whose row is the smaller vertex" would be a per-lane test everywhere).
+  //  * PEELED hub rows: rows with more half-edges than a wave's stream can take one per iteration are left out of
+  //    the ring streams; k_hub_rows / k_hub_finish (mde_ring.hip) evaluate them from the CSR plan in segments of
+  //    MDE_HUB_SEG positions, behind the ring kernel on the same stream (one writer per row, fixed order).
+  int32_t* slot_row = nullptr;
+  int count_all = 0;            // 1: every entry adds f / 2 (permuted layouts); 0: the smaller endpoint adds f
+  int n_hub_rows = 0, n_hub_segs = 0;
+  int64_t hub_half_edges = 0;
+  int32_t* hub_rows = nullptr;  // [n_hub_rows] local row ids, ascending
+  int32_t* hub_seg = nullptr;   // [n_hub_segs + 1][2]: index into hub_rows | first CSR position (segments of a row are consecutive; the extra entry closes the last one)
+  int32_t* hub_first = nullptr; // [n_hub_rows + 1] first segment of each hub row
+  double* hub_partial = nullptr;  // [n_hub_segs][8]: sum g (x_v - x_u) [<= 4] | loss
 };
+#define MDE_HUB_SEG 2048
 
 struct mde_plan {
   int64_t n = 0, p = 0, H = 0, row_lo = 0, row_hi = 0;

@@ -182,6 +182,64 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_keys(int nrows, const int32_
   }
 }
 
+// ---- round 6: layouts with PEELED hub rows and / or PERMUTED row blocks (plan_rows below)
+// row_slot[r] = rb * R + s: LDS slot s of row block rb holds local row r; -1: the row is peeled off to the hub
+// kernel.  slot_cum[t] = half-edges in the slots below t.  The builder kernels below are the slot-indexed twins of
+// k_ring_assign (contiguous mode) and k_ring_keys; downstream of them `hrow` holds SLOTS, and k_ring_meta /
+// k_ring_pack run unchanged (slot - rb * R is the address of the row's x_v and accumulator).
+__global__ __launch_bounds__(64) void k_ring_assign_slots(int R, int Q, const int32_t* __restrict__ slot_cum,
+                                                          uint32_t* __restrict__ wmap, int32_t* __restrict__ wrows) {
+  const int wg = blockIdx.x, rb = wg / Q, lane = threadIdx.x;
+  const int s0 = rb * R;
+  uint32_t* out = wmap + (size_t)wg * R;
+  const int64_t lo = slot_cum[s0], hi = slot_cum[s0 + R];
+  int bd[MDE_RING_NCW + 1];
+  for (int t = 0; t <= MDE_RING_NCW; ++t) {
+    const int64_t target = lo + ((hi - lo) * t) / MDE_RING_NCW;
+    int a = s0, b = s0 + R;
+    while (a < b) {
+      const int mid = (a + b) >> 1;
+      if (slot_cum[mid] >= target) b = mid; else a = mid + 1;
+    }
+    bd[t] = (t == MDE_RING_NCW) ? s0 + R : a;
+  }
+  for (int r = lane; r < R; r += 64) {
+    int ww = 0;
+    for (int t = 1; t < MDE_RING_NCW; ++t) ww += (bd[t] <= s0 + r);
+    out[r] = (uint32_t)ww | ((uint32_t)(s0 + r - bd[ww]) << 8);
+  }
+  if (lane < MDE_RING_NCW) wrows[wg * MDE_RING_NCW + lane] = bd[lane + 1] - bd[lane];
+}
+
+// in: hrow[q] = local row of CSR position q (k_ring_hrow).  out: the stream key of q (the sentinel stream `nseg`,
+// which no wave walks, for the entries of peeled rows), vals[q] = q, hrow[q] = the row's slot
+__global__ __launch_bounds__(MDE_BLOCK) void k_ring_keys_slots(int64_t H, const int32_t* __restrict__ nbr,
+                                                               const int32_t* __restrict__ row_slot,
+                                                               const uint32_t* __restrict__ wmap, int R, int Q, int NC, int C,
+                                                               int JB, uint32_t nseg, uint32_t* __restrict__ keys,
+                                                               uint32_t* __restrict__ vals, int32_t* __restrict__ hrow) {
+  for (int64_t q = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; q < H; q += (int64_t)gridDim.x * MDE_BLOCK) {
+    const int sl = row_slot[hrow[q]];
+    vals[q] = (uint32_t)q;
+    if (sl < 0) {
+      keys[q] = nseg << JB;
+      hrow[q] = 0;
+      continue;
+    }
+    const int rb = sl / R;
+    const uint32_t j = (uint32_t)(nbr[q] / C);
+    const uint32_t g = (uint32_t)(((uint64_t)j * (uint64_t)Q) / (uint64_t)NC);
+    const uint32_t w = wmap[((size_t)rb * Q + g) * R + (sl - rb * R)] & 0xffu;
+    keys[q] = ((((uint32_t)rb * (uint32_t)Q + g) * MDE_RING_NCW + w) << JB) | j;
+    hrow[q] = sl;
+  }
+}
+__global__ __launch_bounds__(MDE_BLOCK) void k_ring_rows_to_slots(int64_t H, const int32_t* __restrict__ row_slot,
+                                                                  int32_t* __restrict__ hrow) {
+  for (int64_t q = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; q < H; q += (int64_t)gridDim.x * MDE_BLOCK)
+    hrow[q] = max(row_slot[hrow[q]], 0);
+}
+
 __global__ __launch_bounds__(MDE_BLOCK) void k_ring_gather_u32(int64_t H, const uint32_t* __restrict__ idx,
                                                                const uint32_t* __restrict__ in,
                                                                uint32_t* __restrict__ out) {
@@ -480,7 +538,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, int nseg, 
                                                          const int32_t* __restrict__ hrow,
                                                          const int32_t* __restrict__ nbr,
                                                          const int32_t* __restrict__ eid, int R, int Q, int C, int S,
-                                                         int ring_off, int JB, int d, int row_lo, int place,
+                                                         int ring_off, int JB, int d, int row_lo, int place, int count_all,
                                                          uint32_t* __restrict__ packed,
                                                          int32_t* __restrict__ peid, uint32_t* __restrict__ hdr) {
   __shared__ uint8_t s_taken[MDE_BLOCK / 64][64], s_free[MDE_BLOCK / 64][64];
@@ -534,8 +592,9 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_pack(int64_t nit, int nseg, 
       if (fr) s_free[wv][__popcll(fm & ((1ull << lane) - 1ull))] = (uint8_t)lane;
     }
     __syncthreads();
-    // whose loss terms: the entry whose row is the smaller vertex of the edge
-    const bool counts = act && (uint32_t)(row_lo + grow) < col;
+    // whose loss terms: the entry whose row is the smaller vertex of the edge (grow is the local row there); a
+    // permuted layout (grow is a slot) adds every entry's with weight 1/2
+    const bool counts = act && (count_all || (uint32_t)(row_lo + grow) < col);
     const int ncount = __popcll(__ballot(counts));
     const uint32_t lclass = ncount == 0 ? 0u : (ncount == cnt ? 1u : 2u);
     // chunk window of the iteration: the oldest chunk its stream still needs (waiting entries
@@ -628,8 +687,22 @@ static int bits_for_u64(uint64_t maxval) {
 }
 
 struct RingSizes {
-  int R, NRB, Q, C, NC, S, JB, ring_off, span;
+  int R, NRB, Q, C, NC, S, JB, ring_off, span, qmax;
 };
+
+// What an evaluation costs on either kernel, in microseconds -- the rule that picks the layout since round 6.  A ring
+// workgroup takes whichever is longer: its consumer waves' iterations (~0.21 us each: config 4, 776 per wave,
+// 0.16 ms) or the chunks that pass through its ring (~0.14 us each -- the hand-shake rate, not the bytes: n = 2M at
+// degree 50 runs 3907 chunks per workgroup in 0.55 ms whatever the producers' depth or number, tools/r6_prod_sweep.sh);
+// the launch runs ceil(workgroups / 256) rounds of them.  The CSR kernels gather x_u from L2 / HBM: 1.1-1.7 ms per
+// 1e8 half-edges when the table overflows L2 (profiles/r06_cliff_probe.txt), ~0.6 when it does not.
+static double ring_time_us(double iters_per_wave, int NC, int Q, int nwg) {
+  const double rounds = std::ceil((double)nwg / 256.0);
+  return rounds * std::max(0.21 * iters_per_wave, 0.14 * (double)NC / (double)Q);
+}
+static double csr_time_us(const mde_plan* plan, int d) {
+  return (double)plan->H * ((int64_t)plan->n * d * 4 >= (6 << 20) ? 1.3e-5 : 0.6e-5);
+}
 
 // Decide the block height and the column groups for dimension d; false when the layout is not
 // worthwhile (the caller keeps the CSR kernel).
@@ -676,8 +749,16 @@ static bool choose_sizes(const mde_plan* plan, int d, RingSizes* z) {
   if (S < 6) return false;
   int span = ring_max_span(S);
   if (getenv("MDE_RING_SPAN")) span = std::min(S - 2, std::max(1, atoi(getenv("MDE_RING_SPAN"))));
-  // auto: a pair of 64-entry iterations must fit the ring window
-  if (mode != 1 && (double)plan->H / ((double)nrb * MDE_RING_NCW * (double)nc) < 128.0 / (0.8 * span)) return false;
+  // auto (rounds 3-5): "a pair of 64-entry iterations must fit the ring window", i.e. >= 128 / (0.8 span) entries
+  // per consumer wave and chunk -- which sent d = 3 at n = 1M, n >= 1.6M at degree 50 and everything sparser to
+  // the CSR kernels at 1.1-1.7 ms per 1e8 half-edges, although the ring kernel with half-filled iterations takes
+  // 0.27-0.5 there (profiles/r06_cliff_probe.txt).  Round 6: the cost model decides (sparse streams pad, so their
+  // iterations are priced at 1.4 x the minimum; the count after scheduling is checked again in build_ring).
+  if (mode != 1) {
+    const double its = 1.4 * (double)plan->H / ((double)nrb * Q * MDE_RING_NCW * 64.0);
+    if (ring_time_us(its, (int)nc, Q, (int)(nrb * Q)) > 0.75 * csr_time_us(plan, d)) return false;
+  }
+  z->qmax = qmax;
   z->R = (int)pr;
   z->NRB = (int)nrb;
   z->Q = Q;
@@ -696,29 +777,211 @@ static void ring_free(mde_ring_layout& L) {
   if (L.hdr) (void)hipFree(L.hdr);
   if (L.wave_iter) (void)hipFree(L.wave_iter);
   if (L.partial) (void)hipFree(L.partial);
+  void* extra[] = {L.slot_row, L.hub_rows, L.hub_seg, L.hub_first, L.hub_partial};
+  for (void* q : extra)
+    if (q) (void)hipFree(q);
   L = mde_ring_layout();
 }
 void mde_ring_release(mde_plan* plan) { ring_free(plan->ring); }
+
+// ---------------------------------------------------------------- round 6: which rows go where
+// The layout of rounds 3-5 cut the vertex order into blocks of R consecutive rows and put every row's entries into
+// the ring streams.  Two kinds of graph broke it (profiles/r06_cliff_probe.txt):
+//   * HUB rows.  The rows of a wave iteration are distinct (one lane = one accumulator), so a row with more
+//     entries than its wave's stream has iterations stretches that stream: one vertex of degree 5e5 in a
+//     config-4 graph made one wave run 250 336 iterations where the others run 772 (28 ms per evaluation, and auto
+//     mode gave the whole layout up for the CSR kernel at 1.4 ms).  Rows with more than T = max(256, H / (blocks x
+//     NCW x 128)) half-edges -- half a stream's iterations per column group -- are PEELED: no ring stream holds
+//     their entries (sentinel key), and k_hub_rows / k_hub_finish evaluate them from the CSR plan behind the ring
+//     kernel.  Their rows are disjoint from the ring's: still one writer per row, fixed order, no atomics.
+//   * degrees that DRIFT along the vertex order (preferential attachment: the early vertices collect the edges).
+//     Blocks of consecutive rows then hold unequal work and the launch runs as long as its heaviest workgroup
+//     (0.80 ms on a 1M-vertex preferential-attachment graph against 0.16 uniform).  When the heaviest block holds
+//     more than 1.08 x the mean, the rows are DEALT to the blocks instead: sorted by degree (counting sort) and
+//     handed out boustrophedon, every block gets the same number of rows and, to within one row's degree, the same
+//     number of half-edges; inside a block the rows keep ascending order.  slot_row records which row sits in which
+//     LDS slot; the kernel gathers x_v and scatters the gradient rows through it.
+// Host code: one pass over the row pointers (copied to the host: 4 bytes per row) -- the ring layout is built once
+// per edge list.
+struct RowPlan {
+  bool mapped = false, permuted = false;
+  int nrb = 0;
+  int64_t H_ring = 0;
+  std::vector<int32_t> row_slot;   // [nloc]
+  std::vector<int32_t> slot_row;   // [nrb * R] (permuted only)
+  std::vector<int32_t> slot_cum;   // [nrb * R + 1]
+  std::vector<int32_t> hub_rows, hub_first, hub_seg;  // hub_seg: [segments][4] = hub index, first position, end position, 0
+  int64_t hub_half_edges = 0;
+  int threshold = 0;
+};
+
+static int plan_rows(const mde_plan* plan, const RingSizes& z, hipStream_t st, RowPlan* rp) {
+  const int64_t nloc = plan->row_hi - plan->row_lo;
+  const int R = z.R;
+  rp->nrb = z.NRB;
+  rp->H_ring = plan->H;
+  const char* e_hub = getenv("MDE_RING_HUB");          // 0: never peel; N > 0: peel rows with more than N half-edges
+  const char* e_perm = getenv("MDE_RING_PERMUTE");     // 0 / 1: never / always deal the rows to the blocks
+  const int hub_env = e_hub ? atoi(e_hub) : -1, perm_env = e_perm ? atoi(e_perm) : -1;
+  if (hub_env == 0 && perm_env == 0) return MDE_OK;
+  std::vector<int32_t> rowptr((size_t)nloc + 1);
+  MDE_HIP(hipMemcpyAsync(rowptr.data(), plan->rowptr, rowptr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  MDE_HIP(hipStreamSynchronize(st));
+  const int64_t H = plan->H;
+  int T = (int)std::max<int64_t>(256, H / ((int64_t)z.NRB * MDE_RING_NCW * 128));
+  if (hub_env > 0) T = hub_env;
+  rp->threshold = T;
+  // hub rows
+  int64_t hub_he = 0;
+  int32_t max_deg = 0;
+  if (hub_env != 0) {
+    for (int64_t r = 0; r < nloc; ++r) {
+      const int32_t deg = rowptr[r + 1] - rowptr[r];
+      max_deg = std::max(max_deg, deg);
+      if (deg > T) {
+        rp->hub_rows.push_back((int32_t)r);
+        hub_he += deg;
+      }
+    }
+    if (2 * hub_he > H) {  // (most of the graph in "hub" rows: a dense problem, not a hub -- the ring takes it whole)
+      rp->hub_rows.clear();
+      hub_he = 0;
+    }
+  }
+  const bool peel = !rp->hub_rows.empty();
+  // work per block of R consecutive rows (peeled rows count nothing)
+  bool permute = perm_env == 1;
+  if (perm_env < 0) {
+    int64_t heaviest = 0;
+    size_t hi = 0;
+    for (int b = 0; b < z.NRB; ++b) {
+      const int64_t r0 = (int64_t)b * R, r1 = std::min<int64_t>(nloc, r0 + R);
+      int64_t w = rowptr[r1] - rowptr[r0];
+      while (hi < rp->hub_rows.size() && rp->hub_rows[hi] < r1) {
+        w -= rowptr[rp->hub_rows[hi] + 1] - rowptr[rp->hub_rows[hi]];
+        ++hi;
+      }
+      heaviest = std::max(heaviest, w);
+    }
+    permute = z.NRB > 1 && (double)heaviest > 1.08 * (double)(H - hub_he) / (double)z.NRB;
+  }
+  if (!peel && !permute) return MDE_OK;
+  rp->mapped = true;
+  rp->permuted = permute;
+  rp->hub_half_edges = hub_he;
+  rp->H_ring = H - hub_he;
+  rp->row_slot.assign((size_t)nloc, -1);
+  std::vector<uint8_t> is_hub((size_t)nloc, 0);
+  for (int32_t r : rp->hub_rows) is_hub[(size_t)r] = 1;
+  if (!permute) {
+    // slots = rows; the peeled ones hold nothing
+    rp->slot_cum.assign((size_t)z.NRB * R + 1, 0);
+    int64_t cum = 0;
+    for (int64_t r = 0; r < (int64_t)z.NRB * R; ++r) {
+      rp->slot_cum[(size_t)r] = (int32_t)cum;
+      if (r < nloc && !is_hub[(size_t)r]) {
+        rp->row_slot[(size_t)r] = (int32_t)r;
+        cum += rowptr[r + 1] - rowptr[r];
+      }
+    }
+    rp->slot_cum[(size_t)z.NRB * R] = (int32_t)cum;
+  } else {
+    // counting sort by degree, heaviest first; boustrophedon deal; rows ascending inside a block
+    const int64_t nring = nloc - (int64_t)rp->hub_rows.size();
+    const int nrb = (int)std::max<int64_t>(1, (nring + R - 1) / R);
+    rp->nrb = nrb;
+    int32_t dmax = 0;
+    for (int64_t r = 0; r < nloc; ++r)
+      if (!is_hub[(size_t)r]) dmax = std::max(dmax, rowptr[r + 1] - rowptr[r]);
+    std::vector<int64_t> start((size_t)dmax + 2, 0);
+    for (int64_t r = 0; r < nloc; ++r)
+      if (!is_hub[(size_t)r]) ++start[(size_t)(dmax - (rowptr[r + 1] - rowptr[r])) + 1];
+    for (size_t k = 1; k < start.size(); ++k) start[k] += start[k - 1];
+    std::vector<int32_t> block((size_t)nloc, -1);
+    for (int64_t r = 0; r < nloc; ++r) {
+      if (is_hub[(size_t)r]) continue;
+      const int64_t rank = start[(size_t)(dmax - (rowptr[r + 1] - rowptr[r]))]++;
+      const int64_t pos = rank % (2 * (int64_t)nrb);
+      block[(size_t)r] = (int32_t)(pos < nrb ? pos : 2 * (int64_t)nrb - 1 - pos);
+    }
+    std::vector<int32_t> fill((size_t)nrb, 0);
+    rp->slot_row.assign((size_t)nrb * R, -1);
+    std::vector<int32_t> slot_deg((size_t)nrb * R, 0);
+    for (int64_t r = 0; r < nloc; ++r) {
+      const int b = block[(size_t)r];
+      if (b < 0) continue;
+      const int sidx = fill[(size_t)b]++;
+      if (sidx >= R) {
+        mde_set_error("ring layout: a row block overflowed while the rows were dealt (internal error)");
+        return MDE_E_INVALID;
+      }
+      const size_t sl = (size_t)b * R + (size_t)sidx;
+      rp->slot_row[sl] = (int32_t)r;
+      rp->row_slot[(size_t)r] = (int32_t)sl;
+      slot_deg[sl] = rowptr[r + 1] - rowptr[r];
+    }
+    rp->slot_cum.assign((size_t)nrb * R + 1, 0);
+    int64_t cum = 0;
+    for (size_t t = 0; t < (size_t)nrb * R; ++t) {
+      rp->slot_cum[t] = (int32_t)cum;
+      cum += slot_deg[t];
+    }
+    rp->slot_cum[(size_t)nrb * R] = (int32_t)cum;
+  }
+  // segments of the hub rows
+  rp->hub_first.reserve(rp->hub_rows.size() + 1);
+  for (size_t i = 0; i < rp->hub_rows.size(); ++i) {
+    rp->hub_first.push_back((int32_t)(rp->hub_seg.size() / 4));
+    const int32_t r = rp->hub_rows[i];
+    for (int64_t b = rowptr[r]; b < rowptr[r + 1]; b += MDE_HUB_SEG) {
+      rp->hub_seg.push_back((int32_t)i);
+      rp->hub_seg.push_back((int32_t)b);
+      rp->hub_seg.push_back((int32_t)std::min<int64_t>(rowptr[r + 1], b + MDE_HUB_SEG));
+      rp->hub_seg.push_back(0);
+    }
+  }
+  rp->hub_first.push_back((int32_t)(rp->hub_seg.size() / 4));
+  if (getenv("MDE_RING_STATS"))
+    fprintf(stderr, "[mde ring] rows: threshold %d half-edges, max degree %d, %zu hub rows with %lld half-edges (%.2f%%) peeled into %zu "
+            "segments; blocks %s (%d)\n", T, max_deg, rp->hub_rows.size(), (long long)hub_he, 100.0 * (double)hub_he / (double)std::max<int64_t>(H, 1),
+            rp->hub_seg.size() / 4, permute ? "DEALT by degree" : "of consecutive rows", rp->nrb);
+  return MDE_OK;
+}
 
 static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   RingSizes z;
   if (!choose_sizes(plan, d, &z)) return 0;
   const int64_t nloc = plan->row_hi - plan->row_lo;
   const int64_t H = plan->H;
+  // which rows are peeled off to the hub kernel, and whether the rest are dealt to the row blocks (round 6)
+  RowPlan rp;
+  {
+    const int rc = plan_rows(plan, z, st, &rp);
+    if (rc != MDE_OK) return rc;
+    if (rp.mapped && rp.nrb != z.NRB) {
+      z.NRB = rp.nrb;
+      z.Q = (int)std::min<int64_t>(z.qmax, std::max<int64_t>(1, 256 / z.NRB));
+      if ((int64_t)z.NRB * z.Q > MDE_MAX_PARTIALS || bits_for_u64((uint64_t)((int64_t)z.NRB * z.Q * MDE_RING_NCW)) + z.JB > 32) return 0;
+    }
+  }
+  const int64_t H_ring = rp.H_ring;  // half-edges the ring streams hold (the rest belongs to peeled rows)
+  if (H_ring <= 0) return 0;
   const int nseg = z.NRB * z.Q * MDE_RING_NCW;
   const uint32_t JM = (1u << z.JB) - 1u;
   uint32_t *keys = nullptr, *vals = nullptr, *keys2 = nullptr, *vals2 = nullptr, *packed = nullptr, *hdr = nullptr, *wmap = nullptr;
   int32_t *hrow = nullptr, *wrows = nullptr, *seg = nullptr, *iters = nullptr, *iter_base = nullptr;
   int32_t *it_ent = nullptr, *it_cnt = nullptr, *it_m = nullptr, *peid = nullptr;
+  int32_t *row_slot = nullptr, *slot_cum = nullptr, *slot_row = nullptr, *hub_rows = nullptr, *hub_seg = nullptr, *hub_first = nullptr;
+  double* hub_partial = nullptr;
   float* partial = nullptr;
   void* tmp = nullptr;
   hipError_t e = hipSuccess;
   auto release = [&](bool all) {
-    void* scratch[] = {keys, vals, keys2, vals2, hrow, wrows, wmap, seg, iters, it_ent, it_cnt, it_m, tmp};
+    void* scratch[] = {keys, vals, keys2, vals2, hrow, wrows, wmap, seg, iters, it_ent, it_cnt, it_m, tmp, row_slot, slot_cum};
     for (void* p : scratch)
       if (p) (void)hipFree(p);
     if (all) {
-      void* outs[] = {packed, hdr, peid, iter_base, partial};
+      void* outs[] = {packed, hdr, peid, iter_base, partial, slot_row, hub_rows, hub_seg, hub_first, hub_partial};
       for (void* p : outs)
         if (p) (void)hipFree(p);
     }
@@ -757,13 +1020,39 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   // MDE_RING_ASSIGN=1: the greedy, sweep-balanced row -> wave map (14.6 ms at config 4, no faster: see k_ring_assign);
   // default: contiguous row ranges of equal half-edge count
   const int contiguous = getenv("MDE_RING_ASSIGN") ? atoi(getenv("MDE_RING_ASSIGN")) == 0 : 1;
-  hipLaunchKernelGGL(k_ring_assign, dim3(z.NRB * z.Q), dim3(64), 0, st, (int)nloc, z.R, z.Q, z.NC, z.C, contiguous, plan->rowptr,
-                     plan->nbr, wmap, wrows);
-  RB(hipGetLastError());
-  tick("row -> wave assignment");
-  hipLaunchKernelGGL(k_ring_keys, dim3(mde_grid(nloc * 16, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, (int)nloc,
-                     plan->rowptr, plan->nbr, wmap, z.R, z.Q, z.NC, z.C, z.JB, keys, vals, hrow);
-  RB(hipGetLastError());
+  auto upload = [&](int32_t** dst, const std::vector<int32_t>& src) -> hipError_t {
+    hipError_t er = hipMalloc(dst, std::max<size_t>(src.size(), 1) * sizeof(int32_t));
+    if (er == hipSuccess && !src.empty()) er = hipMemcpyAsync(*dst, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice, st);
+    return er;
+  };
+  if (rp.mapped) {
+    // (the host vectors stay alive until the build's last synchronisation)
+    RB(upload(&row_slot, rp.row_slot));
+    RB(upload(&slot_cum, rp.slot_cum));
+    if (rp.permuted) RB(upload(&slot_row, rp.slot_row));
+    if (!rp.hub_rows.empty()) {
+      RB(upload(&hub_rows, rp.hub_rows));
+      RB(upload(&hub_seg, rp.hub_seg));
+      RB(upload(&hub_first, rp.hub_first));
+      RB(hipMalloc(&hub_partial, (rp.hub_seg.size() / 4) * 8 * sizeof(double)));
+    }
+    hipLaunchKernelGGL(k_ring_assign_slots, dim3(z.NRB * z.Q), dim3(64), 0, st, z.R, z.Q, slot_cum, wmap, wrows);
+    RB(hipGetLastError());
+    tick("slot -> wave assignment");
+    hipLaunchKernelGGL(k_ring_hrow, dim3(mde_grid(nloc * 16, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, (int)nloc, plan->rowptr, hrow);
+    RB(hipGetLastError());
+    hipLaunchKernelGGL(k_ring_keys_slots, dim3(mde_grid(H, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st, H, plan->nbr, row_slot, wmap, z.R,
+                       z.Q, z.NC, z.C, z.JB, (uint32_t)nseg, keys, vals, hrow);
+    RB(hipGetLastError());
+  } else {
+    hipLaunchKernelGGL(k_ring_assign, dim3(z.NRB * z.Q), dim3(64), 0, st, (int)nloc, z.R, z.Q, z.NC, z.C, contiguous, plan->rowptr,
+                       plan->nbr, wmap, wrows);
+    RB(hipGetLastError());
+    tick("row -> wave assignment");
+    hipLaunchKernelGGL(k_ring_keys, dim3(mde_grid(nloc * 16, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, (int)nloc,
+                       plan->rowptr, plan->nbr, wmap, z.R, z.Q, z.NC, z.C, z.JB, keys, vals, hrow);
+    RB(hipGetLastError());
+  }
   tick("keys kernel");
   size_t tmp_bytes = 0, scan_bytes = 0;
   const int end_bit = std::min(32, bits_for_u64((uint64_t)nseg) + z.JB);
@@ -780,7 +1069,7 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   // look-ahead.  Order the entries by column first (stable): inside a (stream, chunk) they then come
   // column by column, and the rows adjacent to one column are distinct.
   const bool by_column = getenv("MDE_RING_BYCOL") ? atoi(getenv("MDE_RING_BYCOL")) != 0
-                                                  : (double)H > 0.5 * (double)nloc * (double)z.NC;
+                                                  : (double)H_ring > 0.5 * (double)nloc * (double)z.NC;
   if (by_column) {
     // keys2 = columns, sorted with vals -> (keys, vals2); then keys2 = stream keys in that order
     RB(hipMemcpyAsync(keys2, plan->nbr, hb, hipMemcpyDeviceToDevice, st));
@@ -794,6 +1083,10 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     hipLaunchKernelGGL(k_ring_hrow, dim3(mde_grid(nloc * 16, MDE_BLOCK, 4096)), dim3(MDE_BLOCK), 0, st, (int)nloc,
                        plan->rowptr, hrow);
     RB(hipGetLastError());
+    if (rp.mapped) {
+      hipLaunchKernelGGL(k_ring_rows_to_slots, dim3(mde_grid(H, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st, H, row_slot, hrow);
+      RB(hipGetLastError());
+    }
   }
   RB(mde_sort_pairs_u32(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)H, 0, end_bit, st));
   tick("radix sort");
@@ -809,7 +1102,8 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   const int span = z.span;
   // (keys is free from here on: it holds the scheduler's meta words)
   uint32_t* meta = keys;
-  hipLaunchKernelGGL(k_ring_meta, dim3(mde_grid(H, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st, H, keys2, vals2, hrow, plan->nbr,
+  // (the sorted positions [0, H_ring) are the ring's entries; the entries of peeled rows sort behind them)
+  hipLaunchKernelGGL(k_ring_meta, dim3(mde_grid(H_ring, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st, H_ring, keys2, vals2, hrow, plan->nbr,
                      wmap, z.JB, z.R, z.Q, d, meta);
   RB(hipGetLastError());
   // rows of the largest wave range (the scheduler keeps one LDS word per row of its wave)
@@ -903,11 +1197,18 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     release(true);
     return 0;  // too large for 32-bit positions: the caller keeps the CSR layout
   }
-  if (panel_mode() != 1 && (double)Hp > 1.35 * (double)H) {
-    // distinct rows per iteration cost too much padding on this graph (hub rows): CSR kernel
-    drop_caps();
-    release(true);
-    return 0;
+  if (panel_mode() != 1) {
+    // Auto mode, with the iterations counted: is the layout still worth it?  (Rounds 3-5 gave up beyond 35 % padding --
+    // hub rows, which are peeled now, and sparse streams, whose half-filled iterations still beat the CSR kernel's
+    // gathers several times over.)  The streams' mean length is priced; a stream far beyond it would be a hub the
+    // threshold let through, and 4 x padding says as much.
+    const double t_ring = ring_time_us((double)total_iters / (double)nseg, z.NC, z.Q, z.NRB * z.Q) +
+                          (double)rp.hub_half_edges * 1.3e-5;
+    if ((double)Hp > 4.0 * (double)H_ring || t_ring > 0.9 * csr_time_us(plan, d)) {
+      drop_caps();
+      release(true);
+      return 0;
+    }
   }
   e = hipSuccess;
   if (!single) {
@@ -935,7 +1236,8 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   if (e == hipSuccess) {
     hipLaunchKernelGGL(k_ring_pack, dim3(mde_grid((int64_t)total_iters * 64, MDE_BLOCK, 8192)), dim3(MDE_BLOCK), 0, st,
                        (int64_t)total_iters, nseg, iter_base, single ? cap_base : nullptr, it_ent, it_cnt, it_m, keys2, vals2, hrow,
-                       plan->nbr, plan->eid, z.R, z.Q, z.C, z.S, z.ring_off, z.JB, d, (int)plan->row_lo, place, packed, peid, hdr);
+                       plan->nbr, plan->eid, z.R, z.Q, z.C, z.S, z.ring_off, z.JB, d, (int)plan->row_lo, place, rp.permuted ? 1 : 0,
+                       packed, peid, hdr);
     e = hipGetLastError();
   }
   if (e == hipSuccess) e = hipStreamSynchronize(st);  // (cap_base is read by the pack kernel)
@@ -1015,8 +1317,8 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     }
     fprintf(stderr, "[mde ring] d=%d R=%d NRB=%d Q=%d chunks=%d x %d cols, window %d, cap %d, placement %d: %d iterations for %lld half-edges "
             "(%.1f%% padding), %.1f%% with padding lanes; loss terms: %.1f%% of the iterations add all, %.2f%% test per lane\n",
-            d, z.R, z.NRB, z.Q, z.NC, z.C, span, cap, place, total_iters, (long long)H,
-            100.0 * ((double)Hp - (double)H) / (double)H, 100.0 * hstat[0] / total_iters, 100.0 * hstat[1] / total_iters,
+            d, z.R, z.NRB, z.Q, z.NC, z.C, span, cap, place, total_iters, (long long)H_ring,
+            100.0 * ((double)Hp - (double)H_ring) / (double)H_ring, 100.0 * hstat[0] / total_iters, 100.0 * hstat[1] / total_iters,
             100.0 * hstat[2] / total_iters);
   }
 #undef RB
@@ -1040,6 +1342,15 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   L.hdr = hdr;
   L.wave_iter = iter_base;
   L.partial = partial;
+  L.slot_row = slot_row;
+  L.count_all = rp.permuted ? 1 : 0;
+  L.n_hub_rows = (int)rp.hub_rows.size();
+  L.n_hub_segs = (int)(rp.hub_seg.size() / 4);
+  L.hub_half_edges = rp.hub_half_edges;
+  L.hub_rows = hub_rows;
+  L.hub_seg = hub_seg;
+  L.hub_first = hub_first;
+  L.hub_partial = hub_partial;
   return 1;
 }
 
@@ -1377,6 +1688,28 @@ extern "C" int mde_plan_expand_bytes(const mde_plan* plan, const float* in_edge,
   return MDE_OK;
 }
 
+extern "C" int mde_plan_ring_info(const mde_plan* plan, int64_t* info) {
+  if (!plan || !info) return MDE_E_INVALID;
+  const mde_ring_layout& L = plan->ring;
+  for (int i = 0; i < 16; ++i) info[i] = 0;
+  if (!L.packed) return MDE_OK;
+  info[0] = 1;
+  info[1] = L.d;
+  info[2] = L.rows_per_block;
+  info[3] = L.n_row_blocks;
+  info[4] = L.col_groups;
+  info[5] = L.n_chunks;
+  info[6] = L.slots;
+  info[7] = L.n_iters;
+  info[8] = plan->H - L.hub_half_edges;
+  info[9] = L.H;
+  info[10] = L.slot_row ? 1 : 0;
+  info[11] = L.n_hub_rows;
+  info[12] = L.hub_half_edges;
+  info[13] = L.n_hub_segs;
+  return MDE_OK;
+}
+
 extern "C" int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in_edge,
                                       float* out_half, void* stream) {
   if (!plan || !in_edge || !out_half) return MDE_E_INVALID;
@@ -1390,6 +1723,128 @@ extern "C" int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, cons
                      mde_stream(stream), plan->ring.H, plan->ring.eid, in_edge, out_half);
   MDE_LAUNCH_CHECK();
   return MDE_OK;
+}
+
+// ---------------------------------------------------------------- round 6: the peeled hub rows
+// One workgroup per segment of MDE_HUB_SEG consecutive CSR positions of ONE hub row: gather x_u, evaluate (run-time
+// functor; the parameters come from the caller's per-edge arrays through the plan's edge ids -- mde_func.e0 / e1 --,
+// the ring-order streams do not hold these entries), sum g (x_v - x_u) and the loss terms over the segment in a fixed
+// order (lane-strided partial sums, wave butterflies, waves in order; double).  k_hub_finish adds a row's segments in
+// order, writes the gradient row (overwriting the zeros the ring kernel's epilogue left there) and adds the hub rows'
+// loss to the ring kernel's: same stream, behind it.  count_all: the layout's rule for who adds an edge's loss term.
+template <int D>
+__global__ __launch_bounds__(MDE_BLOCK) void k_hub_rows(const int32_t* __restrict__ hub_rows, const int32_t* __restrict__ hub_seg,
+                                                        int row_lo, const int32_t* __restrict__ nbr,
+                                                        const int32_t* __restrict__ eid, const float* __restrict__ e0,
+                                                        const float* __restrict__ e1, int e0_scalar, int e1_scalar,
+                                                        const float* __restrict__ X, FnRuntime fn, float inv_p, int count_all,
+                                                        double* __restrict__ partial) {
+  __shared__ double smem[8];
+  const int sgi = blockIdx.x;
+  const int hi = hub_seg[4 * sgi], beg = hub_seg[4 * sgi + 1], end = hub_seg[4 * sgi + 2];
+  const int64_t v = (int64_t)row_lo + hub_rows[hi];
+  float xv[D];
+#pragma unroll
+  for (int c = 0; c < D; ++c) xv[c] = X[v * D + c];
+  const float e0s = e0_scalar ? e0[0] : 0.0f;
+  const float e1s = (e1 && e1_scalar) ? e1[0] : 0.0f;
+  double acc[D], loss = 0.0;
+#pragma unroll
+  for (int c = 0; c < D; ++c) acc[c] = 0.0;
+  for (int h = beg + (int)threadIdx.x; h < end; h += MDE_BLOCK) {
+    const int u = nbr[h], k = eid[h];
+    const float p0 = e0_scalar ? e0s : e0[k];
+    const float p1 = (e1 && !e1_scalar) ? e1[k] : e1s;
+    float diff[D], ss = 0.0f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      diff[c] = xv[c] - X[(size_t)u * D + c];
+      ss = fmaf(diff[c], diff[c], ss);
+    }
+    float f, gd;
+    fn.eval(ss, p0, p1, f, gd);
+    const float g = mde_fix_g(gd * inv_p);
+    if (count_all || v < (int64_t)u) loss += (double)f;
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] += (double)(g * diff[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    const double t = mde_block_sum(acc[c], smem);
+    if (threadIdx.x == 0) partial[(size_t)sgi * 8 + c] = t;
+  }
+  const double tl = mde_block_sum(loss, smem);
+  if (threadIdx.x == 0) partial[(size_t)sgi * 8 + 4] = tl;
+}
+
+// blocks 0 .. gridDim.x - 2: one thread per hub row; the last block: the loss
+template <int D>
+__global__ __launch_bounds__(MDE_BLOCK) void k_hub_finish(int n_hub, int n_seg, const int32_t* __restrict__ hub_rows,
+                                                          const int32_t* __restrict__ hub_first,
+                                                          const double* __restrict__ partial, int row_lo, float grad_scale,
+                                                          float* __restrict__ grad, double loss_scale, float* __restrict__ loss_out) {
+  __shared__ double smem[8];
+  if (blockIdx.x + 1 < gridDim.x) {
+    const int i = blockIdx.x * MDE_BLOCK + threadIdx.x;
+    if (i >= n_hub || !grad) return;
+    double a[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) a[c] = 0.0;
+    for (int sg = hub_first[i]; sg < hub_first[i + 1]; ++sg) {
+#pragma unroll
+      for (int c = 0; c < D; ++c) a[c] += partial[(size_t)sg * 8 + c];
+    }
+    const int64_t v = (int64_t)row_lo + hub_rows[i];
+#pragma unroll
+    for (int c = 0; c < D; ++c) grad[v * D + c] = (float)a[c] * grad_scale;
+    return;
+  }
+  double t = 0.0;
+  for (int sg = threadIdx.x; sg < n_seg; sg += MDE_BLOCK) t += partial[(size_t)sg * 8 + 4];
+  const double tot = mde_block_sum(t, smem);
+  if (threadIdx.x == 0) *loss_out = (float)((double)*loss_out + tot * loss_scale);
+}
+
+template <int D>
+static int hub_launch_d(const mde_plan* plan, const float* X, const mde_func* f, const float* e0, const float* e1, int e0_scalar,
+                        int e1_scalar, float grad_scale, float* grad, float inv_p, hipStream_t st, float* loss_out, double loss_scale) {
+  const mde_ring_layout& L = plan->ring;
+  FnRuntime fn{ring_func_args(f)};
+  hipLaunchKernelGGL(k_hub_rows<D>, dim3(L.n_hub_segs), dim3(MDE_BLOCK), 0, st, L.hub_rows, L.hub_seg, (int)plan->row_lo, plan->nbr,
+                     plan->eid, e0, e1, e0_scalar, e1_scalar, X, fn, inv_p, L.count_all, L.hub_partial);
+  MDE_LAUNCH_CHECK();
+  const int nb = (L.n_hub_rows + MDE_BLOCK - 1) / MDE_BLOCK + 1;
+  // (the ring kernel's rule: the smaller endpoint adds f -> 2 x the caller's half-weight; count_all: every entry f / 2)
+  hipLaunchKernelGGL(k_hub_finish<D>, dim3(nb), dim3(MDE_BLOCK), 0, st, L.n_hub_rows, L.n_hub_segs, L.hub_rows, L.hub_first,
+                     L.hub_partial, (int)plan->row_lo, grad_scale, grad, (L.count_all ? 1.0 : 2.0) * loss_scale, loss_out);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
+static int hub_launch(const mde_plan* plan, const float* X, int d, const mde_func* f, float grad_scale, float* grad, float inv_p,
+                      hipStream_t st, float* loss_out, double loss_scale) {
+  // the hub rows read their parameters in the caller's edge order
+  const float *e0 = f->e0, *e1 = f->e1;
+  int e0_scalar = 0, e1_scalar = 0;
+  if (f->a0_scalar == 1) {
+    e0 = f->a0;
+    e0_scalar = 1;
+  }
+  if (f->a1 && f->a1_scalar) {
+    e1 = f->a1;
+    e1_scalar = 1;
+  }
+  if (!e0 || (f->a1 && !e1)) {
+    mde_set_error("this plan's LDS-ring layout peels %d hub rows off to the CSR hub kernel: mde_func.e0 (and e1 for two-parameter "
+                  "functions) must point at the per-edge arrays in the caller's edge order", plan->ring.n_hub_rows);
+    return MDE_E_INVALID;
+  }
+  switch (d) {
+    case 1: return hub_launch_d<1>(plan, X, f, e0, e1, e0_scalar, e1_scalar, grad_scale, grad, inv_p, st, loss_out, loss_scale);
+    case 2: return hub_launch_d<2>(plan, X, f, e0, e1, e0_scalar, e1_scalar, grad_scale, grad, inv_p, st, loss_out, loss_scale);
+    case 3: return hub_launch_d<3>(plan, X, f, e0, e1, e0_scalar, e1_scalar, grad_scale, grad, inv_p, st, loss_out, loss_scale);
+    default: return hub_launch_d<4>(plan, X, f, e0, e1, e0_scalar, e1_scalar, grad_scale, grad, inv_p, st, loss_out, loss_scale);
+  }
 }
 
 // ---------------------------------------------------------------- dispatch
@@ -1419,6 +1874,10 @@ int mde_ring_try(mde_plan* plan, const float* X, int d, const mde_func* f, float
     rc = mde_ring_launch_penalty2(A, f, nblocks);
   else
     rc = mde_ring_launch_penalty(A, f, nblocks);
-  if (rc != 0) return rc;
-  return mde_ring_launch_runtime(A, f, nblocks);
+  if (rc == 0) rc = mde_ring_launch_runtime(A, f, nblocks);
+  if (rc == 1 && plan->ring.n_hub_rows > 0) {
+    const int hrc = hub_launch(plan, X, d, f, grad_scale, grad, inv_p, st, loss_out, loss_scale);
+    if (hrc != MDE_OK) return hrc;
+  }
+  return rc;
 }

@@ -142,7 +142,8 @@ template <int D, class Fn, bool HAS_GRAD, int PS, bool LIN>
 __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     int nloc, int row_lo, int n, int R, int Q, int NC, int ring_off, int S, const int32_t* __restrict__ wave_iter,
     const uint32_t* __restrict__ hdr, const uint32_t* __restrict__ packed, const uint32_t* __restrict__ bidx,
-    const float* __restrict__ a0, const float* __restrict__ a1, int a0_scalar, int a1_scalar, const float* __restrict__ X,
+    const int32_t* __restrict__ slot_row, const float* __restrict__ a0, const float* __restrict__ a1, int a0_scalar, int a1_scalar,
+    const float* __restrict__ X,
     float* __restrict__ grad, float* __restrict__ partial, double* __restrict__ loss_partials, Fn fn,
     float fix_value, float grad_scale, float* __restrict__ loss_out, double loss_scale, int fold, int dbg_arg) {
 #if MDE_RING_ABLATE
@@ -182,7 +183,19 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     const int nz = ((R + 32) * 4 * D + 15) / 16;
     for (int i = tid; i < nz; i += BS) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* Xrow = X + (size_t)(row_lo + r0) * D;
-    if ((reinterpret_cast<uintptr_t>(Xrow) & 15) == 0) {
+    if (slot_row) {
+      // permuted row blocks (round 6): slot s holds local row slot_row[rb * R + s] (-1: nobody; such a slot has no
+      // entries, its x_v is never read)
+      const int32_t* sr = slot_row + (size_t)rb * R;
+      for (int sl = tid; sl < R; sl += BS) {
+        const int r = sr[sl];
+        float xv[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) xv[c] = r >= 0 ? X[(size_t)(row_lo + r) * D + c] : 0.0f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) XR[sl * D + c] = xv[c];
+      }
+    } else if ((reinterpret_cast<uintptr_t>(Xrow) & 15) == 0) {
       // 16-byte loads, eight in flight per thread
       const ring_f4* X4 = reinterpret_cast<const ring_f4*>(Xrow);
       ring_f4* XR4 = reinterpret_cast<ring_f4*>(L);
@@ -695,7 +708,59 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     __builtin_amdgcn_s_waitcnt(0x0F70);
   }
   __syncthreads();
-  if (HAS_GRAD && fold) {
+  if (HAS_GRAD && slot_row) {
+    // permuted row blocks (round 6): the same three endings as below, row by row through slot_row -- slot sl of
+    // this block is local row sr[sl] (-1: nobody)
+    const int32_t* sr = slot_row + (size_t)rb * R;
+    if (fold) {
+      unsigned int* sync = reinterpret_cast<unsigned int*>(partial + (size_t)Q * nloc * D) + 2 * rb;
+      int* tk = reinterpret_cast<int*>(L + 512);
+      if (tid == 0) *tk = (int)__hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const bool second = *tk != 0;
+      float* mine = partial + (size_t)qg * nloc * D;
+      const float* other = partial + (size_t)(1 - qg) * nloc * D;
+      if (!second) {
+        for (int sl = tid; sl < R; sl += BS) {
+          const int r = sr[sl];
+          if (r < 0) continue;
+#pragma unroll
+          for (int c = 0; c < D; ++c)
+            __hip_atomic_store(mine + (size_t)r * D + c, GR[sl * D + c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the rows have completed
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        if (tid == 0) {
+          while (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+          __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        for (int sl = tid; sl < R; sl += BS) {
+          const int r = sr[sl];
+          if (r < 0) continue;
+#pragma unroll
+          for (int c = 0; c < D; ++c) {
+            const float o = __hip_atomic_load(other + (size_t)r * D + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float m = GR[sl * D + c];
+            grad[(size_t)(row_lo + r) * D + c] = (qg == 0 ? m + o : o + m) * grad_scale;  // (group order)
+          }
+        }
+      }
+      __syncthreads();
+    } else {
+      float* dst = (Q == 1) ? grad + (size_t)row_lo * D : partial + (size_t)qg * nloc * D;
+      const float sc = (Q == 1) ? grad_scale : 1.0f;
+      for (int sl = tid; sl < R; sl += BS) {
+        const int r = sr[sl];
+        if (r < 0) continue;
+#pragma unroll
+        for (int c = 0; c < D; ++c) dst[(size_t)r * D + c] = GR[sl * D + c] * sc;
+      }
+    }
+  } else if (HAS_GRAD && fold) {
     // Q == 2, one launch (round 5): the two column groups of a row block meet at a ticket.  The group that
     // arrives FIRST leaves its unscaled rows in `partial` (relaxed device-scope stores: write-through, the
     // XCDs' L2s are not coherent) and raises a flag once they have completed; the SECOND adds them to the
@@ -874,9 +939,9 @@ static int launch_ring(const RingArgs& A, const Fn& fn, int* nblocks) {
   // (every edge adds its loss term once here, not once per endpoint: twice the caller's scale)
   hipLaunchKernelGGL(kern, dim3(L.n_row_blocks * Q), dim3(MDE_RING_BS), 0, A.st,
                      (int)(A.plan->row_hi - A.plan->row_lo), (int)A.plan->row_lo, (int)A.plan->n,
-                     L.rows_per_block, Q, L.n_chunks, L.ring_off, L.slots, L.wave_iter, L.hdr, stream, bidx, a0, A.a1, A.a0_scalar,
-                     A.a1_scalar, A.X, A.grad, L.partial, A.plan->partials, fn, fix_value, out_scale,
-                     A.loss_out, 2.0 * A.loss_scale, fold, dbg);
+                     L.rows_per_block, Q, L.n_chunks, L.ring_off, L.slots, L.wave_iter, L.hdr, stream, bidx, L.slot_row, a0, A.a1,
+                     A.a0_scalar, A.a1_scalar, A.X, A.grad, L.partial, A.plan->partials, fn, fix_value, out_scale,
+                     A.loss_out, (L.count_all ? 1.0 : 2.0) * A.loss_scale, fold, dbg);
   MDE_LAUNCH_CHECK();
 #if MDE_RING_ABLATE
   {

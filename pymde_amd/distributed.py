@@ -397,7 +397,30 @@ class ShardedMDE(problem.MDE):
         self._d_hint = int(embedding_dim)
         super(ShardedMDE, self).__init__(n_items, embedding_dim, edges, distortion_function,
                                          constraint=constraint, device=device)
+        self._check_layout_agreement()
         self._reducer = self._make_evaluator()
+
+    def _check_layout_agreement(self):
+        """Every rank must have derived the SAME ownership (slices, ranges): it follows from the edge list and from
+        ``MDE_SHARD_SLICES`` in each process's own environment, and ranks that disagree would gather rows at wrong
+        offsets or hang.  One MIN / MAX all-reduce of a fingerprint at construction; raises on a mismatch."""
+        if not _active(self._group, False):
+            return
+        L = self._layout
+        h = 1469598103934665603
+        for r in range(L.world):
+            for lo, hi in L.ranges[r]:
+                h = ((h ^ (lo * 1000003 + hi)) * 1099511628211) % (1 << 61)
+        backend = dist.get_backend(self._group)
+        dev = self.device if backend == "nccl" else torch.device("cpu")
+        v = torch.tensor([L.slices, L.n, L.world, h], dtype=torch.int64, device=dev)
+        lo_t, hi_t = v.clone(), v.clone()
+        dist.all_reduce(lo_t, op=dist.ReduceOp.MIN, group=self._group)
+        dist.all_reduce(hi_t, op=dist.ReduceOp.MAX, group=self._group)
+        if not torch.equal(lo_t, hi_t):
+            raise RuntimeError("pymde_amd.distributed: the ranks derived different shard layouts (slices %d here; is "
+                               "MDE_SHARD_SLICES set differently per rank, or do the ranks hold different edge lists?)"
+                               % L.slices)
 
     def _make_plan(self, edges):
         self._layout = shard_layout(self._n, edges, self._world, d=self._d_hint, slices=self._slices)
@@ -414,9 +437,18 @@ class ShardedMDE(problem.MDE):
         ev = getattr(self, "_reducer", None)
         if ev is None:
             return super(ShardedMDE, self)._binding()
-        if ev.function is not self.distortion_function:
+        # rebuilt when the distortion function was replaced OR the problem moved (MDE.to rebuilds self._plan on
+        # the new device; the evaluator's plans, bindings and buffers must not stay behind on the old one)
+        if (ev.function is not self.distortion_function or ev.plans[0] is not self._plan
+                or str(ev.device) != str(self.device)):
             self._reducer = ev = self._make_evaluator()
         return ev.bindings[0]
+
+    def to(self, device):
+        """Move the problem to another GPU: plan, evaluator (its plans, bindings, side stream, buffers) and all."""
+        super(ShardedMDE, self).to(device)
+        if getattr(self, "_reducer", None) is not None:
+            self._reducer = self._make_evaluator()
 
     def average_distortion(self, X=None):
         """E(X) with gradient, computed from this rank's shard and exchanged."""

@@ -62,7 +62,9 @@ def read_scalars(module, names):
     function.py:22-26, so ``mde.to(device)`` moves them) costs a device-to-host copy AND a stream
     synchronisation per ``.item()``; the fused path asks for the scalars on every evaluation (has a parameter
     changed?), so the value is remembered per attribute and read again only when the attribute holds another
-    tensor, another storage, or the tensor's version counter says it was written in place."""
+    tensor, another storage, or the tensor's version counter says it was written in place.  A write that bypasses
+    the version counter (``f.exponent.data.fill_(3)``) is NOT seen -- the reference re-reads the tensor on every
+    call --: ``invalidate_scalars(f)`` drops the remembered values, and ``MDE.embed`` calls it once per solve."""
     cache = module.__dict__.setdefault("_scalar_values", {})
     out = []
     for name in names:
@@ -79,6 +81,14 @@ def read_scalars(module, names):
             cache[name] = hit
         out.append(hit[3])
     return out
+
+
+def invalidate_scalars(module):
+    """Forget the scalar values ``read_scalars`` remembers for ``module`` and its sub-modules (after a write that
+    bypassed the tensors' version counters, e.g. through ``.data``)."""
+    seen = [module] + (list(module.modules()) if isinstance(module, torch.nn.Module) else [])
+    for m in seen:
+        getattr(m, "__dict__", {}).pop("_scalar_values", None)
 
 
 def _as_param(t, device):

@@ -354,8 +354,10 @@ def _make_problem(engine, objective_fn, constraint):
     with a built-in constraint; otherwise the generic (callback) path."""
     owner = getattr(objective_fn, "__self__", None)
     if _is_native(objective_fn, constraint):
-        reducer = getattr(owner, "_reducer", None)
+        # (binding first: a sharded owner replaces its evaluator in _binding() when the distortion function or the
+        # device has changed -- the reducer read before that call would be the stale one)
         binding = owner._binding()
+        reducer = getattr(owner, "_reducer", None)
         if reducer is not None and not binding.fused and not hasattr(reducer, "evaluate"):
             # the unfused path evaluates the full mean on every rank and fills only the owned
             # gradient rows: a bare exchange would produce garbage (ShardedEvaluator handles it)

@@ -240,6 +240,10 @@ class MDE(torch.nn.Module):
                         f"max_iter={max_iter}, memory_size={memory_size}")
         if print_every is None:
             print_every = max(1, max_iter // 10)
+        # scalar parameters that live on the GPU are remembered between evaluations (functions/function.py
+        # read_scalars); a solve starts from what the tensors hold now, however they were written
+        from pymde_amd.functions import function as _function
+        _function.invalidate_scalars(self.distortion_function)
 
         X_star, solve_stats = optim.lbfgs(
             X=X, objective_fn=self.average_distortion, constraint=self.constraint, eps=eps,

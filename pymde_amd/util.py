@@ -133,10 +133,15 @@ def work_buffer(device, d):
         old = _WORK.pop(old_key)
         # an evicted buffer may still be read by kernels in flight on ITS stream (callers pass the pointer of a
         # temporary to asynchronous launches): tell the allocator, whatever stream is current at the free
-        try:
-            old.record_stream(torch.cuda.ExternalStream(old_key[1], device=device))
-        except Exception:  # (a stream that no longer exists: nothing is in flight on it)
-            pass
+        # (the stream handle belongs to the device of the EVICTED buffer, old_key[0], not to this call's device;
+        # ExternalStream cannot tell a destroyed handle from a live one, so a buffer of another device -- whose
+        # stream this process may have dropped -- is simply released: its block returns to that device's allocator
+        # and is reused on the allocating stream's order only)
+        if old_key[0] == str(device):
+            try:
+                old.record_stream(torch.cuda.ExternalStream(old_key[1], device=old.device))
+            except Exception:  # (a stream that no longer exists: nothing is in flight on it)
+                pass
     return buf
 
 

@@ -308,14 +308,14 @@ def test_config5_full_size_against_oracle():
         assert_grad_close(buf[:n * d].view(n, d).cpu().numpy(), wgrad)
 
 
-def _ring_full_size_case(n, deg, d, make_f, oracle_func, runs=3):
+def _ring_full_size_case(n, deg, d, make_f, oracle_func, runs=3, graph="uniform"):
     """>= 5e7 half-edge entries through the LDS-ring kernel: against the OpenMP oracle at the kernel
     tolerances, `runs` evaluations bitwise equal (a race in the ring protocol shows up as a few rows that
     differ from run to run -- the round-4 d = 3 race was invisible below ~1e7 entries)."""
     import bench
     from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
     dev = torch.device(DEV, 0)
-    edges, w, X = bench.make_workload(dev, n=n, deg=deg, d=d)
+    edges, w, X = bench.make_workload(dev, n=n, deg=deg, d=d, graph=graph)
     p = edges.shape[0]
     assert 2 * p >= 5 * 10 ** 7
     f, fd = make_f(w, p, dev), None
@@ -420,3 +420,47 @@ def test_ring_units_full_size_against_oracle_and_bitwise(case):
         # one scalar weight for every edge (the LIN = false form: padding lanes are masked)
         _ring_full_size_case(n, deg, 2, lambda w, p, dev: pen.Cubic(torch.tensor([1.5], device=dev)),
                              lambda f, w: oracle.func("CUBIC", np.array([1.5], np.float32)))
+
+
+@pytest.mark.parametrize("case", ["d3_n1m", "n2m", "hub", "powerlaw", "powerlaw_d3_pushpull"])
+def test_ring_beyond_the_old_feasibility_rule_full_size(case):
+    """Round 6: the regimes the ring layout's feasibility rule of rounds 3-5 sent to the CSR kernels (>= 1.1 ms per
+    1e8 half-edges) now run on the ring kernel in AUTO mode -- each at full size against the OpenMP oracle, three
+    evaluations bitwise equal:
+      d3_n1m    d = 3 at n = 1M, 50M edges (22 entries per consumer wave and chunk against the old threshold of 32)
+      n2m       n = 2M at out-degree 50, 100M edges (25 against 32): half-filled wave iterations
+      hub       the config-4 graph with one vertex of degree 5e5: the hub row is peeled off to k_hub_rows
+      powerlaw  preferential attachment at n = 1M, 50M edges (degrees fall along the vertex order, hubs of
+                thousands of half-edges): hubs peeled, row blocks dealt by degree (every entry adds f / 2)
+      powerlaw_d3_pushpull  the same graph at d = 3 with PushAndPull weights {1, 2, -1}."""
+    import pymde_amd
+    pen = pymde_amd.penalties
+    log1p = (lambda w, p, dev: pen.Log1p(w), lambda f, w: oracle.func("LOG1P", w, None, (1.5,)))
+    if case == "d3_n1m":
+        b = _ring_full_size_case(1_000_000, 50, 3, *log1p)
+        info = b.plan.ring_info()
+        assert not info["permuted"] and info["hub_rows"] == 0
+    elif case == "n2m":
+        b = _ring_full_size_case(2_000_000, 50, 2, *log1p)
+        info = b.plan.ring_info()
+        assert info["row_blocks"] == 256 and not info["permuted"] and info["hub_rows"] == 0
+    elif case == "hub":
+        b = _ring_full_size_case(1_000_000, 50, 2, *log1p, graph="hub")
+        info = b.plan.ring_info()
+        assert info["hub_rows"] == 1 and info["hub_half_edges"] >= 500_000 and not info["permuted"]
+    elif case == "powerlaw":
+        b = _ring_full_size_case(1_000_000, 50, 2, *log1p, graph="powerlaw")
+        info = b.plan.ring_info()
+        assert info["hub_rows"] > 10 and info["permuted"]
+    else:
+        holder = {}
+
+        def mk(w, p, dev):
+            holder["w"] = w.clone()
+            holder["w"][(2 * p) // 3:] = -1.0
+            return pen.PushAndPull(holder["w"], pen.Log1p, pen.Log)
+        b = _ring_full_size_case(1_000_000, 50, 3, mk,
+                                 lambda f, w: oracle.func("LOG1P", holder["w"].cpu().numpy(), None, (1.5,), "LOG", (1.0,)),
+                                 graph="powerlaw")
+        info = b.plan.ring_info()
+        assert info["hub_rows"] > 10 and info["permuted"] and b.codebook

@@ -739,11 +739,12 @@ def test_ring_kernel_on_dense_graphs_sharded(monkeypatch):
         assert_grad_close(total[:n * d].view(n, d).cpu().numpy(), wgrad)
 
 
-def test_ring_layout_gives_way_on_hub_graphs():
-    """Auto layout choice at a size where the LDS-ring kernel would normally run (n d 4 >= 6 MB): a hub
-    vertex with half a million half-edges would need one wave iteration per entry (rows are distinct
-    inside an iteration), so the layout builder gives the ring up and the CSR kernel runs -- same
-    results, against the oracle."""
+def test_ring_layout_peels_hub_rows():
+    """Auto layout choice at a size where the LDS-ring kernel runs (n d 4 >= 6 MB) on a graph with a hub vertex
+    of half a million half-edges.  Rounds 3-5: the rows of a wave iteration are distinct, the hub would need one
+    iteration per entry, and the builder gave the whole layout up for the CSR kernel.  Round 6: the hub row is
+    PEELED -- the ring streams hold everybody else's entries, k_hub_rows / k_hub_finish evaluate the hub from the CSR
+    plan behind the ring kernel -- same results, against the oracle, bitwise reproducible."""
     import pymde_amd
     rng = np.random.default_rng(11)
     n, p, hub = 800_000, 8_000_000, 500_000
@@ -759,10 +760,93 @@ def test_ring_layout_gives_way_on_hub_graphs():
     Xt = torch.tensor(X, device=DEV, requires_grad=True)
     E = mde.average_distortion(Xt)
     E.backward()
-    assert mde._binding().struct(2).layout == 0          # the ring layout was tried and given up
+    assert mde._binding().struct(2).layout == 1
+    info = mde._plan.ring_info()
+    assert info["hub_rows"] == 1 and info["hub_half_edges"] >= hub and not info["permuted"], info
     wE, wgrad = oracle.average_distortion(edges, X, oracle.func("LOG1P", w, None, (1.5,)))
     assert float(E) == pytest.approx(wE, rel=1e-5)
     assert_grad_close(Xt.grad.cpu().numpy(), wgrad)
+    Xt2 = torch.tensor(X, device=DEV, requires_grad=True)
+    E2 = mde.average_distortion(Xt2)
+    E2.backward()
+    assert torch.equal(Xt2.grad, Xt.grad) and torch.equal(E2.detach(), E.detach())
+
+
+def _skewed_graph(rng, n, p, hubs):
+    """Random graph whose degrees fall along the vertex order (endpoint ~ n u^3) plus a few hub vertices."""
+    i = np.minimum((n * rng.random(p) ** 3).astype(np.int64), n - 1)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    for k, (v, deg) in enumerate(hubs):
+        sel = rng.choice(p, deg, replace=False)
+        i[sel] = v
+        j[sel] = (v + 1 + rng.choice(n - 1, deg, replace=False)) % n
+    key = np.unique(np.minimum(i, j).astype(np.int64) * n + np.maximum(i, j))
+    return np.stack([key // n, key % n], 1)
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4])
+@pytest.mark.parametrize("mode", ["peel", "deal", "peel+deal"])
+def test_ring_layout_peeled_and_dealt_rows_against_oracle(monkeypatch, d, mode):
+    """The round-6 layouts forced on at a size the oracle checks fast: hub rows peeled off to the hub kernel
+    (threshold 300 half-edges), row blocks dealt by degree, both; d = 1..4 (run-time and compile-time functors);
+    one GPU (Q = 2 at d = 2: the in-launch sum of the two column groups) and a 3-way vertex-range shard (more
+    column groups: k_ring_combine behind the kernel) -- loss and gradient against the oracle, two evaluations
+    bitwise equal.  Functions: Log1p on a codebook stream, PushAndPull on continuous weights (mde_func.e0 feeds the hub
+    rows), WeightedQuadratic (two per-edge arrays: e0 and e1), Quadratic with ONE scalar weight."""
+    import pymde_amd
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    pen, los = pymde_amd.penalties, pymde_amd.losses
+    monkeypatch.setenv("MDE_PANEL", "1")
+    monkeypatch.setenv("MDE_RING_HUB", "300" if "peel" in mode else "0")
+    monkeypatch.setenv("MDE_RING_PERMUTE", "1" if "deal" in mode else "0")
+    rng = np.random.default_rng(100 + d)
+    n, p = 40000, 500000
+    edges = _skewed_graph(rng, n, p, [(7, 20000), (n // 2, 3000), (n - 3, 900)])
+    p = len(edges)
+    et = torch.tensor(edges, device=DEV)
+    X = (rng.standard_normal((n, d)) * 1.5).astype(np.float32)
+    Xd = torch.tensor(X, device=DEV)
+    w2 = rng.choice(np.array([1.0, 2.0], dtype=np.float32), size=p)
+    wc = np.where(rng.random(p) < 0.3, -rng.uniform(0.5, 1.5, p), rng.uniform(0.5, 2.0, p)).astype(np.float32)
+    dev_ = rng.uniform(0.5, 3.0, p).astype(np.float32)
+    wq = rng.uniform(0.2, 1.0, p).astype(np.float32)
+    t = lambda a: torch.tensor(a, device=DEV)
+    cases = [
+        ("log1p codebook", pen.Log1p(t(w2)), oracle.func("LOG1P", w2, None, (1.5,))),
+        ("pushpull fp32", pen.PushAndPull(t(wc), pen.Log1p, pen.Log), oracle.func("LOG1P", wc, None, (1.5,), "LOG", (1.0,))),
+        ("weighted quadratic", los.WeightedQuadratic(t(dev_), t(wq)), oracle.func("L_WEIGHTED_QUADRATIC", dev_, wq, ())),
+        ("scalar weight", pen.Quadratic(t(np.array([0.7], dtype=np.float32))),
+         oracle.func("QUADRATIC", np.full(p, 0.7, dtype=np.float32), None, ())),
+    ]
+    for name, f, of in cases:
+        wE, wgrad = oracle.average_distortion(edges, X, of)
+        plan = EdgePlan(n, et)
+        b = Binding(plan, f)
+        buf = torch.zeros(n * d + 1, device=DEV)
+        fused_evaluate(b, Xd, buf[:n * d].view(n, d), buf[n * d:])
+        assert b.struct(d).layout == 1, name
+        info = plan.ring_info()
+        assert (info["hub_rows"] >= 3) == ("peel" in mode) and info["permuted"] == ("deal" in mode), (name, info)
+        assert float(buf[n * d]) == pytest.approx(wE, rel=2e-5), (name, mode)
+        assert_grad_close(buf[:n * d].view(n, d).cpu().numpy(), wgrad)
+        buf2 = torch.zeros_like(buf)
+        fused_evaluate(b, Xd, buf2[:n * d].view(n, d), buf2[n * d:])
+        assert torch.equal(buf2, buf), name
+        # forward only (no gradient buffer)
+        lonly = torch.zeros(1, device=DEV)
+        fused_evaluate(b, Xd, None, lonly)
+        assert float(lonly) == pytest.approx(wE, rel=2e-5), name
+        if name != "log1p codebook":
+            continue
+        # 3-way vertex-range shard: every rank's plan peels / deals its own rows
+        total = torch.zeros_like(buf)
+        bounds = [0, n // 5, n // 2, n]
+        for r in range(3):
+            part = torch.zeros_like(buf)
+            fused_evaluate(Binding(EdgePlan(n, et, bounds[r], bounds[r + 1]), f), Xd, part[:n * d].view(n, d), part[n * d:])
+            total += part
+        assert float(total[n * d]) == pytest.approx(wE, rel=2e-5)
+        assert_grad_close(total[:n * d].view(n, d).cpu().numpy(), wgrad)
 
 
 @pytest.mark.parametrize("d", [2, 3])

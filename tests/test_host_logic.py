@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libmde_hip.so does not export %s" % name
     # and the ctypes table binds exactly the declared set
     assert sorted(_lib.SYMBOLS) == declared
-    assert lib.mde_abi_version() == 1
+    assert lib.mde_abi_version() == 2
     assert lib.mde_work_doubles(2) > 0
 
 
@@ -74,11 +74,24 @@ def test_ctypes_signatures_match_the_header_prototypes():
     assert seen == set(_lib.SYMBOLS)
 
 
-def test_mde_func_struct_layout_matches_header():
-    # struct mde_func: 2 x int32, 2 x pointer, 2 x int32, 6 x float, int32 (+4 pad) (include/mde_hip.h)
-    assert ctypes.sizeof(_lib.MdeFunc) == 8 + 16 + 8 + 24 + 4 + 4
-    assert _lib.MdeFunc.a0.offset == 8 and _lib.MdeFunc.s0.offset == 32
-    assert _lib.MdeFunc.layout.offset == 56
+def test_mde_func_struct_layout_matches_header(tmp_path):
+    """struct mde_func as gcc lays it out from include/mde_hip.h against the ctypes mirror (ABI 2: e0 / e1 at the end)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fields = [f for f, _ in _lib.MdeFunc._fields_]
+    src = tmp_path / "f.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mde_hip.h"\nint main(void){\n'
+                   'printf("%zu", sizeof(mde_func));\n'
+                   + "".join('printf(" %%zu", offsetof(mde_func, %s));\n' % f for f in fields)
+                   + 'return 0;}\n')
+    exe = tmp_path / "f"
+    subprocess.run(["gcc", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    assert got[0] == ctypes.sizeof(_lib.MdeFunc) == 80
+    assert got[1:] == [getattr(_lib.MdeFunc, f).offset for f in fields]
+    assert _lib.MdeFunc.a0.offset == 8 and _lib.MdeFunc.s0.offset == 32 and _lib.MdeFunc.layout.offset == 56
+    assert _lib.MdeFunc.e0.offset == 64 and _lib.MdeFunc.e1.offset == 72
 
 
 def test_turn_desc_layout_matches_header(tmp_path):
