@@ -138,6 +138,11 @@ static __device__ int g_ring_ndiag;
 // (value index in the packed word's spare bits, <= 7 / 3 values), 2 = byte index (one byte per entry beside the
 // packed words -- 5 B per half-edge --, a 256-entry value table in the 1 KB behind the ring; round 5: the hop
 // counts of a distance-preserving problem on a graph are tens of distinct integers, which streamed 8 B until now)
+#ifdef MDE_RING_EVAL2
+constexpr bool defined_MDE_RING_EVAL2 = true;
+#else
+constexpr bool defined_MDE_RING_EVAL2 = false;
+#endif
 template <int D, class Fn, bool HAS_GRAD, int PS, bool LIN>
 __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     int nloc, int row_lo, int n, int R, int Q, int NC, int ring_off, int S, const int32_t* __restrict__ wave_iter,
@@ -463,6 +468,9 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       // the LDS operands of an entry: x_v, x_u, the parameter
       struct Pre {
         float xr[D], xc[D], p0;
+#ifdef MDE_RING_KEEPROW
+        uint32_t row;  // (round 6 probe: the row address kept from the operand read to the accumulator update)
+#endif
       };
       // packed word -> LDS byte addresses (ring_pack_word)
       // (MDE_RING_PROBE_ROWLIN / _COLLIN: timing probes with wrong results -- the row / column side of every entry at
@@ -488,7 +496,12 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           r.p0 = *reinterpret_cast<const float*>(L + tab_off + bi4);
         else
           r.p0 = CB ? *reinterpret_cast<const float*>(L + CTRL_CB + ((w & (D == 2 ? 7u : 3u)) << 2)) : p0 * Fn::kParamScale;
+#ifdef MDE_RING_KEEPROW
+        r.row = row_of(w);
+        ring_ld_operand<D>(L, r.row, r.xr);
+#else
         ring_ld_operand<D>(L, row_of(w), r.xr);
+#endif
         ring_ld_operand<D>(L, col_of(w), r.xc);
         return r;
       };
@@ -510,8 +523,12 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       auto finish = [&](auto lc_tag, uint32_t w, const Pre& x, float (&acc)[D], float p1, uint32_t hm)
           __attribute__((always_inline)) {
         constexpr int LC = decltype(lc_tag)::value;
+#ifdef MDE_RING_KEEPROW
+        const uint32_t rowaddr = x.row;
+#else
         const uint32_t rowaddr = row_of(w);
-        float v[D], ss = 0.0f;
+#endif
+        float v[D], ss = (defined_MDE_RING_EVAL2 && Fn::kRingFused) ? 1.0e-30f : 0.0f;
 #pragma unroll
         for (int c = 0; c < D; ++c) {
           v[c] = x.xr[c] - x.xc[c];
@@ -523,7 +540,9 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           // one reciprocal; r stays finite at d = 0, where v = 0 anyway.
           const float d = mde_sqrt(ss), sd = mde_sqrt(d);
           const float t = fmaf(d, sd, 1.0f);
-          const float r = mde_rcp(fmaf(sd, t, 1.0e-30f));
+          // (round 6 probe MDE_RING_EVAL2: sd t = sd + d sd sd = sd + ss, so the reciprocal's argument needs neither t
+          // nor a constant of its own once 1e-30 sits in ss -- one VALU instruction less where no loss term is added)
+          const float r = defined_MDE_RING_EVAL2 ? mde_rcp(sd + ss) : mde_rcp(fmaf(sd, t, 1.0e-30f));
           gd = x.p0 * r;
           if constexpr (LC != 0) {
             // w log1p(u) = w ln2 log2(t) + (w / t) (u - (t - 1)), 1 / t = sqrt(d) r: the two sums are
