@@ -15,6 +15,8 @@ Fixtures
   constraints.npz   Centered / Standardized / Anchored maps   -> pins constraints.py, util.py:129-171
   trajectories.npz  per-iteration SolveStats of short embed() runs (optim.py / lbfgs.py)
   trajectories_mid.npz  the same at n = 20k, p ~ 300k (two problems x 4 perturbation levels, 8 iterations)
+  trajectories_clusters.npz  the same on a structured problem: n = 100k in 100 planted clusters, p ~ 1.8M,
+                    PushAndPull(Log1p, Log), Standardized (3 perturbation levels, 6 iterations)
   spectral.npz      quadratic.spectral on small graphs         -> pins quadratic.py
   preprocess.npz    deduplicate_edges / sample_edges of the reference
   cycle.npz         BASELINE config 1 scaled down: preserve_distances on a cycle graph,
@@ -351,6 +353,67 @@ def gen_trajectories_mid(pymde, torch):
     print("trajectories_mid.npz written")
 
 
+def cluster_problem_arrays():
+    """A STRUCTURED problem of config-4 kind at a size the reference runs in seconds: n = 100k items in 100 planted
+    clusters of 1000; every item draws 12 'neighbour' edges inside its cluster (weights 1 / 2) and 6 'dissimilar'
+    edges anywhere (weight -1); PushAndPull(Log1p, Log), Standardized.  (The uniform-random graph of SURVEY 8d has
+    nothing to learn under unit covariance -- its Standardized solve is flat; this one separates the clusters.)"""
+    n, csize = 100_000, 1000
+    rng = np.random.default_rng(777)
+    src = np.repeat(np.arange(n), 12)
+    dst = (src // csize) * csize + rng.integers(0, csize - 1, src.size)
+    dst += dst >= src
+    rs = np.repeat(np.arange(n), 6)
+    rd = rng.integers(0, n - 1, rs.size)
+    rd += rd >= rs
+    a = np.concatenate([src, rs])
+    b = np.concatenate([dst, rd])
+    w = np.concatenate([1.0 + (rng.random(src.size) < 0.3), -np.ones(rs.size)]).astype(np.float32)
+    key = np.minimum(a, b).astype(np.int64) * n + np.maximum(a, b)
+    _, first = np.unique(key, return_index=True)   # (a pair drawn twice keeps its first weight)
+    first.sort()
+    edges = np.stack([np.minimum(a, b)[first], np.maximum(a, b)[first]], 1)
+    return n, edges, w[first]
+
+
+def gen_trajectories_clusters(pymde, torch):
+    """First 6 iterations of the reference's embed() on the planted-cluster problem (n = 100k, p ~ 1.8M), from X0
+    and from X0 perturbed by 1e-7 / 1e-6.  X0 is regenerated by the test (numpy seed, Standardized by the float64
+    recipe below); the fixture keeps a checksum of it."""
+    torch.set_num_threads(8)
+    n, edges, w = cluster_problem_arrays()
+    X0 = cluster_X0(n)
+    out = {"edge_checksum": np.array([int(edges[:, 0].sum()), int(edges[:, 1].sum()), len(edges)]),
+           "param_checksum": np.array([float(np.abs(w).astype(np.float64).sum())]),
+           "X0_checksum": np.array([float(np.abs(X0).astype(np.float64).sum())])}
+    NOISE = [0.0, 1e-7, 1e-6]
+    E, R, S = [], [], []
+    for trial, noise in enumerate(NOISE):
+        gen = torch.Generator().manual_seed(300 + trial)
+        Xs = torch.tensor(X0) * (1 + noise * torch.randn((n, 2), generator=gen))
+        f = pymde.penalties.PushAndPull(torch.tensor(w), pymde.penalties.Log1p, pymde.penalties.Log)
+        mde = pymde.MDE(n, 2, torch.tensor(edges), f, constraint=pymde.Standardized())
+        mde.embed(X=Xs, max_iter=6, eps=1e-12, memory_size=10)
+        st = mde.solve_stats
+        pad = lambda v: np.pad(np.array(v, dtype=np.float64), (0, 6 - len(v)), constant_values=np.nan)
+        E.append(pad(st.average_distortions))
+        R.append(pad(st.residual_norms))
+        S.append(pad(st.step_size_percents))
+        print("clusters noise", noise, E[-1])
+    out.update(distortions=np.stack(E), residuals=np.stack(R), steps=np.stack(S), noise=np.array(NOISE))
+    np.savez_compressed(os.path.join(HERE, "trajectories_clusters.npz"), **out)
+    print("trajectories_clusters.npz written")
+
+
+def cluster_X0(n):
+    """A Standardized starting point from a numpy seed: centred, then X (X^T X / n)^{-1/2} in float64."""
+    rng = np.random.default_rng(778)
+    X = rng.standard_normal((n, 2))
+    X -= X.mean(0)
+    lam, Q = np.linalg.eigh(X.T @ X / n)
+    return (X @ (Q / np.sqrt(lam)) @ Q.T).astype(np.float32)
+
+
 def gen_spectral(pymde, torch):
     from pymde import quadratic
     out = {}
@@ -589,6 +652,7 @@ def main():
     gen_constraints(pymde, torch)
     gen_trajectories(pymde, torch)
     gen_trajectories_mid(pymde, torch)
+    gen_trajectories_clusters(pymde, torch)
     gen_spectral(pymde, torch)
     gen_cycle(pymde, torch)
     gen_preprocess(pymde, torch)

@@ -464,3 +464,22 @@ def test_ring_beyond_the_old_feasibility_rule_full_size(case):
                                  graph="powerlaw")
         info = b.plan.ring_info()
         assert info["hub_rows"] > 10 and info["permuted"] and b.codebook
+
+
+def test_config4_survey_seed_tensors_loss_and_gradient_against_oracle():
+    """SURVEY 8d's config 4a EXACTLY as the survey writes it (bench.py --survey-seed: numpy default_rng(0) edges and
+    weights, torch.manual_seed(0) CPU randn X -- the tensors a reference-side run of the recipe builds): loss AND
+    gradient of the HIP path against the oracle on all 50M edges (round 5's --survey-seed record compared the loss)."""
+    import bench
+    import pymde_amd
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    dev = torch.device(DEV, 0)
+    edges, w, X = bench.make_workload_survey(dev)
+    n, d = X.shape
+    b = Binding(EdgePlan(n, edges), pymde_amd.penalties.Log1p(w))
+    buf = torch.zeros(n * d + 1, device=dev)
+    fused_evaluate(b, X, buf[:n * d].view(n, d), buf[n * d:])
+    assert b.struct(d).layout == 1 and b.codebook
+    wE, wgrad = oracle.average_distortion(edges.cpu().numpy(), X.cpu().numpy(), oracle.func("LOG1P", w.cpu().numpy(), None, (1.5,)))
+    assert float(buf[n * d]) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(buf[:n * d].view(n, d).cpu().numpy(), wgrad)
