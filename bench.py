@@ -120,10 +120,23 @@ def make_workload(device, n=N_ITEMS, deg=OUT_DEGREE, d=DIM, graph="uniform"):
         dst = base
         bad = dst == src
         dst[bad] = (src[bad] + 1) % n
+    elif graph == "clusters":
+        # planted clusters of 1000 consecutive items: 2/3 of an item's links stay inside its cluster ('neighbours'),
+        # the rest go anywhere ('dissimilar' pairs; weight -1 below) -- a problem with something to learn under a
+        # Standardized constraint, unlike the uniform graph
+        csize = 1000
+        inside = (torch.arange(p, device=device) % deg) < (2 * deg) // 3
+        dst_in = (src // csize) * csize + torch.randint(0, csize - 1, (p,), device=device, dtype=torch.int64, generator=gen)
+        dst_in += (dst_in >= src).to(torch.int64)
+        dst_in.clamp_(max=n - 1)
+        dst = torch.where(inside, dst_in, dst)
+        dst = torch.where(dst == src, (src + 1) % n, dst)
     elif graph != "uniform":
         raise SystemExit("unknown --graph " + graph)
     edges = torch.stack([torch.minimum(src, dst), torch.maximum(src, dst)], dim=1).contiguous()
     w = 1.0 + (torch.rand(p, device=device, generator=gen) < 0.3).to(torch.float32)
+    if graph == "clusters":
+        w = torch.where((torch.arange(p, device=device) % deg) < (2 * deg) // 3, w, -torch.ones_like(w))
     gen.manual_seed(0)
     X = torch.randn((n, d), device=device, generator=gen)
     X -= X.mean(0)
@@ -461,7 +474,8 @@ def run_config4(args, world, rank, device):
         "config": {"workload": "BASELINE configs[3] / SURVEY 8d config %s%s: n=%d, |E|=%d %s edges "
                                "(out-degree 50), d=%d, %s; %s" % (args.variant, "" if headline_shape else " at ANOTHER SHAPE (secondary record)",
                                                                    n, p, {"uniform": "uniform-random", "hub": "uniform-random + one hub of degree 5e5",
-                                                                          "powerlaw": "preferential-attachment (copy model)"}[args.graph], d, fname,
+                                                                          "powerlaw": "preferential-attachment (copy model)",
+                                                                          "clusters": "planted-cluster"}[args.graph], d, fname,
                                "the survey's exact tensors: numpy default_rng(0) edges and weights, torch.manual_seed(0) "
                                "CPU randn X, built on the host and uploaded (--survey-seed)" if args.survey_seed else
                                "seeded on the device with torch.Generator(0) (the survey's recipe uses numpy "
@@ -743,10 +757,12 @@ def run_config4_embed(args, device):
     import pymde_amd
     from pymde_amd import _lib
     from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
-    n, d = args.n, DIM
-    edges, w, _ = make_workload(device, n=n)
+    n, d = args.n, args.dim
+    edges, w, _ = make_workload(device, n=n, d=d, graph=args.graph)
     p = edges.shape[0]
     lib = _lib.load()
+    pen = pymde_amd.penalties
+    make_f = (lambda: pen.PushAndPull(w, pen.Log1p, pen.Log)) if args.graph == "clusters" else (lambda: pen.Log1p(w))
 
     def timed(fn):
         torch.cuda.synchronize(device)
@@ -759,7 +775,7 @@ def run_config4_embed(args, device):
     # evaluation make)
     plan, t_plan = timed(lambda: EdgePlan(n, edges))
     _, t_layout = timed(lambda: lib.mde_plan_layout(plan.handle, d, _lib.stream_ptr(device)))
-    f = pymde_amd.penalties.Log1p(w)
+    f = make_f()
     binding, t_bind = timed(lambda: Binding(plan, f))
     _, t_struct = timed(lambda: binding.struct(d))
     del binding, plan
@@ -768,7 +784,14 @@ def run_config4_embed(args, device):
     iters = max(args.steps if args.steps != 200 else 100, 1)
     records = {}
     for cname, c in (("Centered", pymde_amd.Centered()), ("Standardized", pymde_amd.Standardized())):
-        mde, t_mde = timed(lambda: pymde_amd.MDE(n, d, edges, pymde_amd.penalties.Log1p(w), constraint=c, device=device))
+        if args.emulate_world > 1:
+            # rank 0 of a W-way row-sharded solve, no collectives (a world of one): the per-rank kernels of an iteration --
+            # the edge kernel on an eighth of the rows, the optimiser's vector work on the owned rows only
+            from pymde_amd import distributed
+            mde, t_mde = timed(lambda: distributed.ShardedMDE(n, d, edges, make_f(), constraint=c, device=device, rank=0,
+                                                              world_size=args.emulate_world))
+        else:
+            mde, t_mde = timed(lambda: pymde_amd.MDE(n, d, edges, make_f(), constraint=c, device=device))
         torch.manual_seed(0)
         X0 = c.initialization(n, d, device=device).contiguous()
         _, t_first = timed(lambda: mde.embed(X=X0.clone(), max_iter=5, eps=0.0))     # warm-up (builds layout + binding)
@@ -786,6 +809,48 @@ def run_config4_embed(args, device):
         grad, loss = buf[:n * d].view(n, d), buf[n * d:]
         b = mde._binding()
         t_eval, _ = time_launches(lambda: fused_evaluate(b, X, grad, loss), 20, device)
+        if args.emulate_world > 1:
+            # The solve above cannot tell what an iteration costs: without the other ranks the iterate's foreign rows
+            # are never refreshed, the objective stops making sense and every line search runs long.  So the kernels
+            # and host calls of ONE steady-state iteration (first trial accepted: direction update, trial point,
+            # evaluation, statistics, one read-back) are timed in a loop on rank 0's engine.
+            from pymde_amd import optim as _optim
+            sargs = _optim._sharded_solver_args(mde.average_distortion, mde.constraint)
+            iter_ms = None
+            if sargs is not None:
+                with torch.no_grad():
+                    eng = _optim._ShardedEngine(X0.clone(), 10, *sargs[1:])
+                    prob = _optim._ShardedProblem(eng, sargs[0], mde.constraint)
+                    prob.value_and_grad(eng.X)
+                    eng.reset_memory()
+                    eng.axpy(-2.0, eng.g, eng.g, eng.dir)
+                    eng.axpy(0.0, eng.g, eng.g, eng.g_prev)
+
+                    def one_iteration():
+                        eng.update_direction(1e-3)
+                        prob.retract_step(1e-3, eng.X_trial)
+                        prob.value_grad_stats(eng.X_trial)
+                        eng.read_board(24)
+                    for _ in range(30):
+                        one_iteration()
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    for _ in range(200):
+                        one_iteration()
+                    torch.cuda.synchronize(device)
+                    iter_ms = 1e3 * (time.perf_counter() - t0) / 200
+                    eng.close()
+            records[cname] = {
+                "steady_state_iteration_ms": iter_ms,
+                "s_per_iter": dt / n_it, "ms_per_iter": 1e3 * dt / n_it, "iterations": n_it,
+                "ms_per_iter_after_5_iterations": 1e3 * late, "evaluations": st.evaluations,
+                "evaluations_per_iteration": (st.evaluations or 0) / n_it,
+                "component_ms": {"average_distortion fwd+bwd, rank 0's rows": t_eval},
+                "note": "rank 0 of a %d-way row-sharded solve in a world of one: kernels and host loop of ONE rank, no collective "
+                        "(the other ranks' rows of the iterate are never refreshed, so the numbers of the solve mean nothing)"
+                        % args.emulate_world}
+            del mde
+            continue
         Z = torch.randn((n, d), device=device)
         t_tan, _ = time_launches(lambda: c.project_onto_tangent_space(X, Z, inplace=True), 20, device)
         Y = X.clone()
@@ -797,6 +862,7 @@ def run_config4_embed(args, device):
             "evaluations": st.evaluations, "evaluations_per_iteration": (st.evaluations or 0) / n_it,
             "first_embed_5_iterations_s": t_first, "mde_constructor_s": t_mde,
             "average_distortions": [float(v) for v in st.average_distortions[:8]],
+            "average_distortion_after_the_longer_solve": float(st2.average_distortions[-1]),
             "component_ms": {"average_distortion fwd+bwd (ring kernel + combine)": t_eval,
                              "tangent projection": t_tan, "retraction": t_ret},
         }
@@ -806,10 +872,16 @@ def run_config4_embed(args, device):
         "metric": "seconds/iteration of MDE.embed(), n=1M |E|=50M d=2 Log1p", "value": main["s_per_iter"], "unit": "s/iter",
         "n_gpus": 1, "steps": main["iterations"], "warmup": 5, "ms_per_step": main["ms_per_iter"], "higher_is_better": False,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[3] / SURVEY 8d config 4a as an embed(): n=%d, |E|=%d uniform-random edges "
-                               "(out-degree 50), d=2, penalties.Log1p(1.5), weights in {1,2}, L-BFGS memory 10, "
-                               "X0 = constraint.initialization; value = the Centered solve" % (n, p),
-                   "parallelism": "single GPU", "edges_per_s_per_iter": p / main["s_per_iter"],
+        "config": {"workload": "BASELINE configs[3] / SURVEY 8d config 4a as an embed(): n=%d, |E|=%d %s edges "
+                               "(out-degree 50), d=%d, %s, L-BFGS memory 10, "
+                               "X0 = constraint.initialization; value = the Centered solve"
+                               % (n, p, {"uniform": "uniform-random", "clusters": "planted-cluster (1000 items per cluster, 2/3 of the links inside)",
+                                         "hub": "uniform-random + one hub", "powerlaw": "preferential-attachment"}[args.graph], d,
+                                  "PushAndPull(Log1p(1.5), Log(1)): weights {1,2} inside the clusters, -1 across" if args.graph == "clusters"
+                                  else "penalties.Log1p(1.5), weights in {1,2}"),
+                   "parallelism": "single GPU" if args.emulate_world <= 1 else
+                                  "rank 0 of a %d-way ROW-SHARDED solve (optim._ShardedEngine), kernels + host loop only" % args.emulate_world,
+                   "edges_per_s_per_iter": p / main["s_per_iter"],
                    "embed": records,
                    "problem_build_s": {"edge plan (validate, sort, CSR)": t_plan, "ring layout": t_layout,
                                        "parameters (expand + codebook)": t_bind + t_struct,
@@ -951,7 +1023,7 @@ def main():
     ap.add_argument("--n", type=int, default=N_ITEMS)
     ap.add_argument("--dim", type=int, default=DIM, choices=(1, 2, 3, 4),
                     help="config 4 only: embedding dimension (secondary records; the headline is d = 2)")
-    ap.add_argument("--graph", default="uniform", choices=("uniform", "hub", "powerlaw"),
+    ap.add_argument("--graph", default="uniform", choices=("uniform", "hub", "powerlaw", "clusters"),
                     help="config 4 only: the survey's uniform-random graph, the same with one hub of degree 5e5, or a "
                          "preferential-attachment graph (secondary records)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL)")

@@ -217,6 +217,10 @@ int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in
  * [10] row blocks PERMUTED (rows dealt to the blocks by degree; every entry adds f / 2), [11] hub rows PEELED off to
  * the CSR hub kernel, [12] their half-edges, [13] their segments, [14], [15] reserved (0). */
 int mde_plan_ring_info(const mde_plan* plan, int64_t* info_host);
+/* dst[0] (DEVICE double) <- the loss the plan's last mde_average_distortion wrote to loss_out, in double, before the
+ * rounding to float.  A solve whose rows are sharded across ranks sums the ranks' shares in double and rounds once,
+ * like the single-GPU kernel does (the reference's line search branches on the last bit of the loss).  ASYNC. */
+int mde_plan_loss_double(const mde_plan* plan, double* dst, void* stream);
 
 /* ------------------------------------------------------------------ edge-list preprocessing
  *  [ref: pymde/preprocess/preprocess.py:11-129]
@@ -397,6 +401,22 @@ int mde_lbfgs_dev_reset(mde_lbfgs* o, void* stream);
 int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, const float* d, float t,
                        float* d_out, double* stats, double* work, void* stream);
 int mde_lbfgs_dev_info(const mde_lbfgs* o, int32_t* count_host, int32_t* accepted_host, void* stream);
+/* The same step in two halves, for a solve whose vectors are SHARDED BY ROWS across ranks (every rank keeps the
+ * history of its own rows: mde_lbfgs_create(N = its elements)) [ref: lbfgs.py:461-507, the loop being sharded]:
+ * mde_lbfgs_dev_stage stages the pair and leaves the mde_lbfgs_dev_dots(o) = 4 + 5 * history inner products over the
+ * rank's elements in work[0 ..) (device doubles); the caller sums them across the ranks IN PLACE (one small
+ * all-reduce); mde_lbfgs_dev_finish takes the accept / drop-oldest decision and runs the two-loop recursion on the
+ * sums (every rank: the same arithmetic on the same numbers) and writes the rank's elements of the new direction to
+ * d_out and the statistics of (g, d_out) over ITS elements to stats (partial: see mde_rank_reduce).  In a world of
+ * one, stage + finish = mde_lbfgs_dev_step's four-launch form.  ASYNC. */
+int mde_lbfgs_dev_stage(mde_lbfgs* o, const float* g, float* g_prev, const float* d, float t, double* work, void* stream);
+int mde_lbfgs_dev_finish(mde_lbfgs* o, const float* g, float* d_out, double* stats, double* work, void* stream);
+int32_t mde_lbfgs_dev_dots(const mde_lbfgs* o);
+/* out[q] = sum -- or max, where bit q of max_mask is set -- over the ranks r (in rank order) of in[r * count + q],
+ * q < count <= 64, device doubles; loss_slot >= 0: that result is also written to *loss_out as a float.  Reduces the
+ * per-rank records of a sharded solve (statistics boards + loss shares, exchanged with ONE all-gather) in one launch. */
+int mde_rank_reduce(int32_t world, int32_t count, uint64_t max_mask, const double* in, double* out,
+                    int32_t loss_slot, float* loss_out, void* stream);
 /* Which form mde_lbfgs_dev_step takes (process-wide; read from the environment on first use:
  * MDE_LB_UNFUSED, MDE_LB_DEBUG = "blocks,spins,lds_bytes").  For N <= 2^18 the step is ONE launch whose
  * workgroups meet at grid-wide arrival points; an ordinary launch cannot guarantee that they are all

@@ -60,6 +60,11 @@ SYMBOLS = {
     "mde_plan_layout": (c_i32, [c_vp, c_i32, c_vp]),
     "mde_plan_layout_half_edges": (c_i64, [c_vp, c_i32]),
     "mde_plan_ring_info": (c_i32, [c_vp, ctypes.POINTER(c_i64)]),
+    "mde_plan_loss_double": (c_i32, [c_vp, c_vp, c_vp]),
+    "mde_lbfgs_dev_stage": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp]),
+    "mde_lbfgs_dev_finish": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "mde_lbfgs_dev_dots": (c_i32, [c_vp]),
+    "mde_rank_reduce": (c_i32, [c_i32, c_i32, ctypes.c_uint64, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "mde_plan_expand_codebook": (c_i32, [c_vp, c_vp, c_vp, ctypes.POINTER(c_i32), c_vp]),
     "mde_plan_expand_bytes": (c_i32, [c_vp, c_vp, c_vp, ctypes.POINTER(c_i32), c_vp]),
     "mde_plan_expand_layout": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp]),

@@ -10,6 +10,11 @@
 #define MDE_WAVE 64          // CDNA wavefront
 #define MDE_BLOCK 256        // default workgroup: 4 waves, one per SIMD
 #define MDE_MAX_PARTIALS 4096  // upper bound on workgroups that write reduction partials
+// mde_plan.partials: [0, MDE_MAX_PARTIALS) loss partials | [MAX] arrival ticket | [MAX + 1] scratch flag |
+// [MAX + 2] the loss of the last evaluation in DOUBLE (round 6: every finaliser writes it beside the float -- a
+// row-sharded solve sums the ranks' shares before the one rounding to float, mde_plan_loss_double)
+#define MDE_PARTIALS_LOSS_D (MDE_MAX_PARTIALS + 2)
+#define MDE_PARTIALS_DOUBLES (MDE_MAX_PARTIALS + 4)
 
 void mde_set_error(const char* fmt, ...);
 int mde_hip_fail(hipError_t e, const char* what, const char* file, int line);

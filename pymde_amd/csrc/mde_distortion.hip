@@ -286,14 +286,17 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_flat_fixup(int64_t n_tiles, int p
                                                           const int32_t* __restrict__ rowptr,
                                                           const float* __restrict__ rec,
                                                           float* __restrict__ grad, float grad_scale,
-                                                          const double* __restrict__ loss_partials, int nparts,
+                                                          double* __restrict__ loss_partials, int nparts,
                                                           double loss_scale, float* __restrict__ loss_out) {
   if (loss_out && blockIdx.x == gridDim.x - 1) {
     __shared__ double smem[8];
     double s = 0.0;
     for (int i = threadIdx.x; i < nparts; i += MDE_BLOCK) s += loss_partials[i];
     const double tot = mde_block_sum(s, smem);
-    if (threadIdx.x == 0) *loss_out = (float)(tot * loss_scale);
+    if (threadIdx.x == 0) {
+      *loss_out = (float)(tot * loss_scale);
+      loss_partials[MDE_PARTIALS_LOSS_D] = tot * loss_scale;
+    }
     return;
   }
   const int64_t t = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x;
@@ -562,13 +565,16 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4(
 }
 
 // loss = scale * sum(partials[0..nb)) in a fixed order (one block)
-__global__ void k_finalize_loss(const double* __restrict__ partials, int nb, double scale,
+__global__ void k_finalize_loss(double* __restrict__ partials, int nb, double scale,
                                 float* __restrict__ loss_out) {
   __shared__ double smem[8];
   double s = 0.0;
   for (int i = threadIdx.x; i < nb; i += blockDim.x) s += partials[i];
   const double t = mde_block_sum(s, smem);
-  if (threadIdx.x == 0) *loss_out = (float)(t * scale);
+  if (threadIdx.x == 0) {
+    *loss_out = (float)(t * scale);
+    partials[MDE_PARTIALS_LOSS_D] = t * scale;
+  }
 }
 
 // ---------------------------------------------------------------- functors of the unfused paths

@@ -322,8 +322,8 @@ extern "C" int mde_plan_create(int64_t n, int64_t p, const int64_t* edges, int64
   PLAN_HIP(hipMalloc(&plan->rowptr, (nloc + 1) * sizeof(int32_t)));
   // (+2: the slot after the partials is the arrival counter of the in-kernel loss reduction, the
   // one after it a scratch flag of mde_plan_expand_codebook)
-  PLAN_HIP(hipMalloc(&plan->partials, (MDE_MAX_PARTIALS + 2) * sizeof(double)));
-  PLAN_HIP(hipMemsetAsync(plan->partials + MDE_MAX_PARTIALS, 0, 2 * sizeof(double), st));
+  PLAN_HIP(hipMalloc(&plan->partials, MDE_PARTIALS_DOUBLES * sizeof(double)));
+  PLAN_HIP(hipMemsetAsync(plan->partials + MDE_MAX_PARTIALS, 0, 4 * sizeof(double), st));
   int32_t Hlocal = 0;
   if (H2 > 0) {
     const size_t bytes = (size_t)H2 * sizeof(uint32_t);

@@ -1688,6 +1688,13 @@ extern "C" int mde_plan_expand_bytes(const mde_plan* plan, const float* in_edge,
   return MDE_OK;
 }
 
+// dst[0] (device double) <- the loss of the plan's last mde_average_distortion in double, before its rounding to float
+extern "C" int mde_plan_loss_double(const mde_plan* plan, double* dst, void* stream) {
+  if (!plan || !dst) return MDE_E_INVALID;
+  MDE_HIP(hipMemcpyAsync(dst, plan->partials + MDE_PARTIALS_LOSS_D, sizeof(double), hipMemcpyDeviceToDevice, mde_stream(stream)));
+  return MDE_OK;
+}
+
 extern "C" int mde_plan_ring_info(const mde_plan* plan, int64_t* info) {
   if (!plan || !info) return MDE_E_INVALID;
   const mde_ring_layout& L = plan->ring;
@@ -1782,7 +1789,8 @@ template <int D>
 __global__ __launch_bounds__(MDE_BLOCK) void k_hub_finish(int n_hub, int n_seg, const int32_t* __restrict__ hub_rows,
                                                           const int32_t* __restrict__ hub_first,
                                                           const double* __restrict__ partial, int row_lo, float grad_scale,
-                                                          float* __restrict__ grad, double loss_scale, float* __restrict__ loss_out) {
+                                                          float* __restrict__ grad, double loss_scale, float* __restrict__ loss_out,
+                                                          double* __restrict__ loss_d) {
   __shared__ double smem[8];
   if (blockIdx.x + 1 < gridDim.x) {
     const int i = blockIdx.x * MDE_BLOCK + threadIdx.x;
@@ -1802,7 +1810,11 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_hub_finish(int n_hub, int n_seg, 
   double t = 0.0;
   for (int sg = threadIdx.x; sg < n_seg; sg += MDE_BLOCK) t += partial[(size_t)sg * 8 + 4];
   const double tot = mde_block_sum(t, smem);
-  if (threadIdx.x == 0) *loss_out = (float)((double)*loss_out + tot * loss_scale);
+  // (the ring kernel left its part of the loss in *loss_d in double: the hub rows' part is added before the one rounding)
+  if (threadIdx.x == 0) {
+    *loss_d += tot * loss_scale;
+    *loss_out = (float)*loss_d;
+  }
 }
 
 template <int D>
@@ -1816,7 +1828,8 @@ static int hub_launch_d(const mde_plan* plan, const float* X, const mde_func* f,
   const int nb = (L.n_hub_rows + MDE_BLOCK - 1) / MDE_BLOCK + 1;
   // (the ring kernel's rule: the smaller endpoint adds f -> 2 x the caller's half-weight; count_all: every entry f / 2)
   hipLaunchKernelGGL(k_hub_finish<D>, dim3(nb), dim3(MDE_BLOCK), 0, st, L.n_hub_rows, L.n_hub_segs, L.hub_rows, L.hub_first,
-                     L.hub_partial, (int)plan->row_lo, grad_scale, grad, (L.count_all ? 1.0 : 2.0) * loss_scale, loss_out);
+                     L.hub_partial, (int)plan->row_lo, grad_scale, grad, (L.count_all ? 1.0 : 2.0) * loss_scale, loss_out,
+                     plan->partials + MDE_PARTIALS_LOSS_D);
   MDE_LAUNCH_CHECK();
   return MDE_OK;
 }

@@ -876,6 +876,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     double s = 0.0;
     for (int i = 0; i < BS / 64; ++i) s += red[i];
     *loss_out = (float)(s * loss_scale);
+    loss_partials[MDE_PARTIALS_LOSS_D] = s * loss_scale;  // (the same in double: mde_plan_loss_double)
   }
 }
 

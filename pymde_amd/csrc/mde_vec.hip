@@ -2495,6 +2495,80 @@ extern "C" int mde_lbfgs_dev_step(mde_lbfgs* o, const float* g, float* g_prev, c
   return lbfgs_dev_step_impl(o, g, g_prev, d, t, d_out, stats, work, stream, MdeGate{nullptr, 0u});
 }
 
+// ---- round 6: the same step in two halves, for a solve whose vectors are sharded by rows across ranks
+// (pymde_amd/optim.py, _ShardedEngine).  Every rank keeps the history of ITS rows only (o->N = its elements):
+// mde_lbfgs_dev_stage stages the pair and leaves the 4 + 5 * history inner products over the rank's elements in
+// work[0 ..); the caller sums them across the ranks in place (one small all-reduce of doubles); mde_lbfgs_dev_finish
+// takes the accept / drop-oldest decision and runs the two-loop recursion on those sums -- every rank the same
+// arithmetic on the same numbers -- and writes the rank's rows of the new direction, with the statistics of (g, d_out)
+// over its elements (partial: the caller reduces them, mde_rank_reduce).  Always the four-launch form's kernels.
+extern "C" int mde_lbfgs_dev_stage(mde_lbfgs* o, const float* g, float* g_prev, const float* d, float t, double* work,
+                                   void* stream) {
+  if (!o || !o->dev || !g || !g_prev || !d || !work) return MDE_E_INVALID;
+  hipStream_t st = mde_stream(stream);
+  const int64_t N = o->N;
+  double* partial = work + MDE_SMALL_DOUBLES;
+  const MdeGate gate{nullptr, 0u};
+  const int nb = mde_grid(N, MDE_BLOCK * 2, 1024);
+  if (o->history > MDE_LB_GROUP && o->history <= 12)
+    hipLaunchKernelGGL(k_lb_stage_all<12>, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t, o->buf, o->dev, partial, gate);
+  else
+    hipLaunchKernelGGL(k_lb_stage_all<MDE_LB_GROUP>, dim3(nb), dim3(MDE_BLOCK), 0, st, N, g, g_prev, d, t, o->buf,
+                       o->dev, partial, gate);
+  MDE_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_lb_reduce, dim3(4 + 5 * o->history), dim3(MDE_BLOCK), 0, st, nb, partial, o->dev, work, gate);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+extern "C" int mde_lbfgs_dev_finish(mde_lbfgs* o, const float* g, float* d_out, double* stats, double* work, void* stream) {
+  if (!o || !o->dev || !g || !d_out || !stats || !work) return MDE_E_INVALID;
+  hipStream_t st = mde_stream(stream);
+  const int64_t N = o->N;
+  double* partial = work + MDE_SMALL_DOUBLES;
+  double* dots = work;
+  const MdeGate gate{nullptr, 0u};
+  if (o->history < 16) {
+    hipLaunchKernelGGL(k_lbfgs_direction<16>, dim3(1), dim3(64), MDE_LB_DIR_LDS(16), st, o->dev, dots, o->history, gate);
+  } else {
+    MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lbfgs_direction<MDE_LB_LD>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)MDE_LB_DIR_LDS(MDE_LB_LD)));
+    hipLaunchKernelGGL(k_lbfgs_direction<MDE_LB_LD>, dim3(1), dim3(64), MDE_LB_DIR_LDS(MDE_LB_LD), st, o->dev, dots,
+                       o->history, gate);
+  }
+  MDE_LAUNCH_CHECK();
+  const int nbc = mde_grid(N, MDE_BLOCK * 2, MDE_RED_BLOCKS);
+  hipLaunchKernelGGL(k_lb_combine_all, dim3(nbc), dim3(MDE_BLOCK), 0, st, N, g, o->buf, o->dev, d_out, partial,
+                     stats, work_ticket(work, TK_LB_COMBINE), gate);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+extern "C" int32_t mde_lbfgs_dev_dots(const mde_lbfgs* o) { return o ? 4 + 5 * o->history : 0; }
+
+// out[q] = sum (or max, bit q of max_mask) over the ranks r, in rank order, of in[r * count + q]  (q < count <= 64);
+// loss_slot >= 0: that slot's result also goes to *loss_out as a float.  The per-rank records of a sharded solve --
+// statistics boards and loss shares, gathered with one all-gather -- reduced with mixed operations in one launch.
+__global__ void k_rank_reduce(int world, int count, unsigned long long max_mask, const double* __restrict__ in,
+                              double* __restrict__ out, int loss_slot, float* __restrict__ loss_out) {
+  const int q = threadIdx.x;
+  if (q >= count) return;
+  const bool is_max = (max_mask >> q) & 1ull;
+  double a = in[q];
+  for (int r = 1; r < world; ++r) {
+    const double v = in[(size_t)r * count + q];
+    a = is_max ? (v > a ? v : a) : a + v;
+  }
+  out[q] = a;
+  if (q == loss_slot && loss_out) *loss_out = (float)a;
+}
+extern "C" int mde_rank_reduce(int32_t world, int32_t count, uint64_t max_mask, const double* in, double* out,
+                               int32_t loss_slot, float* loss_out, void* stream) {
+  if (world < 1 || count < 1 || count > 64 || !in || !out) return MDE_E_INVALID;
+  hipLaunchKernelGGL(k_rank_reduce, dim3(1), dim3(64), 0, mde_stream(stream), (int)world, (int)count,
+                     (unsigned long long)max_mask, in, out, (int)loss_slot, loss_out);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
+
 // copies of the device bookkeeping for tests: count, accepted
 extern "C" int mde_lbfgs_dev_info(const mde_lbfgs* o, int32_t* count_host, int32_t* accepted_host,
                                   void* stream) {

@@ -385,8 +385,15 @@ class ShardedMDE(problem.MDE):
     """An MDE problem whose edges are sharded across the ranks of a process group."""
 
     def __init__(self, n_items, embedding_dim, edges, distortion_function, constraint=None,
-                 device=None, group=None, rank=None, world_size=None, slices=None, force_exchange=False):
+                 device=None, group=None, rank=None, world_size=None, slices=None, force_exchange=False,
+                 shard_solver=True):
         # (force_exchange: issue the collectives even in a world of one -- single-GPU RCCL tests)
+        # shard_solver (round 6): embed() keeps its vectors sharded by rows (optim._ShardedEngine: no gradient
+        # exchange, the trial point's owned rows are gathered instead, the L-BFGS history is 1 / world per rank).
+        # That solver wants ONE row range per rank, so the slice-major layout (the gather of one slice under the
+        # kernel of the next: evaluation-only use at large d) is chosen only when slices is given explicitly.
+        if slices is None and shard_solver:
+            slices = 1
         self._force = bool(force_exchange)
         self._group = group
         self._rank = dist.get_rank(group) if rank is None else int(rank)

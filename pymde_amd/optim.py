@@ -69,7 +69,7 @@ _DIR = 16  # offset (doubles) of the direction statistics written by update_dire
 class _Engine(object):
     """Device state of one solve and the kernels that act on it."""
 
-    def __init__(self, X, memory_size):
+    def __init__(self, X, memory_size, history_elements=None):
         self.lib = _lib.load()
         self.device = util.require_cuda_device(X.device)
         if X.dtype != torch.float32:
@@ -123,7 +123,8 @@ class _Engine(object):
                              "pair statistics in one wave); got %d" % int(memory_size))
         handle = ctypes.c_void_p()
         with torch.cuda.device(dev):  # the history buffer must live on X's GPU, not the current one
-            _lib.check(self.lib.mde_lbfgs_create(self.N, int(memory_size), ctypes.byref(handle)))
+            _lib.check(self.lib.mde_lbfgs_create(self.N if history_elements is None else int(history_elements),
+                                                 int(memory_size), ctypes.byref(handle)))
         self.lbfgs = handle
 
     def close(self):
@@ -296,6 +297,195 @@ class _NativeProblem(object):
             raise util.SolverError("Standardized retraction failed: X^T X is singular")
 
 
+class _ShardedEngine(_Engine):
+    """The device state of a solve whose VECTORS ARE SHARDED BY ROWS across the ranks of a process group (round 6).
+
+    Every rank keeps a replica of the iterate (the edge kernel gathers x_u from anywhere) but owns one contiguous row
+    range [lo, hi): the kernel writes the gradient rows of that range only -- final, owner-computes -- and the
+    gradient is NEVER exchanged.  The optimiser's vector work runs on the owned rows: the L-BFGS history is this
+    rank's rows of (s, y) (160 MB / world at config 4), statistics, direction and trial point are formed for the owned
+    rows.  What crosses the ranks per iteration [ref: the loop being sharded, lbfgs.py:461-507 and optim.py:100-175]:
+      * the 4 + 5 m partial inner products of the history update: one all-reduce of doubles (``update_direction``);
+      * the owned rows of the trial point: one in-place all-gather into the replica (``_ShardedProblem.retract_step``)
+        -- the bytes the gradient all-gather of rounds 2-5 moved;
+      * d column sums (and, Standardized, two d x d Gram matrices) for the constraint: small all-reduces;
+      * ONE all-gather of a 25-double record per rank -- statistics of (g, dir, X) over its rows, the statistics
+        of the new direction, its loss share -- reduced with sums and maxima by ``mde_rank_reduce``.
+    In a world of one (``bench.py --emulate-world``: rank 0 of a W-way shard, kernels only) the collectives are
+    skipped.  ``_solve`` drives this engine unchanged, call by call."""
+
+    _MAXMASK = (1 << _GMAX) | (1 << _DMAX) | (1 << (_DIR + _GMAX)) | (1 << (_DIR + _DMAX))
+    _REC = _DIR + 8 + 1        # board[0:8] | (unused) | direction board[16:24] | loss share
+
+    def __init__(self, X, memory_size, lo, hi, group, rank, world, active):
+        super(_ShardedEngine, self).__init__(X, memory_size, history_elements=(int(hi) - int(lo)) * int(X.shape[1]))
+        import torch.distributed as dist
+        self.dist = dist
+        self.lo, self.hi, self.group, self.rank, self.world, self.active = int(lo), int(hi), group, int(rank), int(world), bool(active)
+        self.n_own = self.hi - self.lo
+        self.N_own = self.n_own * self.d
+        dev = self.device
+        # this rank's record and the gathered records of all ranks (doubles)
+        self.rec = torch.zeros(self._REC, dtype=torch.float64, device=dev)
+        self.rec_all = torch.zeros((self.world if self.active else 1) * self._REC, dtype=torch.float64, device=dev)
+        self.ndots = int(self.lib.mde_lbfgs_dev_dots(self.lbfgs))
+        self.ones = torch.ones(max(self.n_own, 1), dtype=torch.float32, device=dev)
+        self.small = torch.zeros(max(self.d * self.d, 8), dtype=torch.float64, device=dev)
+        # (MDE_SHARD_XGATHER=0: exchange the trial point's rows as a zero-padded all-reduce -- what a backend without the
+        # in-place all-gather gets anyway)
+        self._gather_ok = False if os.environ.get("MDE_SHARD_XGATHER") == "0" else None
+        self.loss_fresh = False   # loss_dev holds THIS RANK'S share (set by the evaluation, cleared by the reduction)
+
+    def own(self, t):
+        """This rank's rows of a full [n, d] tensor (a view); tensors of the owned shape pass through."""
+        return t[self.lo:self.hi] if t.shape[0] == self.n else t
+
+    # ---- vector kernels on the owned rows
+    def axpy(self, alpha, x, y, out):
+        _lib.check(self.lib.mde_axpy(self.N_own, float(alpha), _lib.ptr(self.own(x)), _lib.ptr(self.own(y)),
+                                     _lib.ptr(self.own(out)), self.stream()))
+
+    def all_reduce_small(self, t):
+        if self.active:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def stats(self, g, d, x):
+        """Statistics of (g, d, x) over ALL rows: this rank's part over its rows, then the ranks' records -- this
+        board, the direction board of the last ``update_direction`` and the loss share the edge kernel left in
+        ``loss_dev`` -- meet in one all-gather and are reduced by ``mde_rank_reduce`` into the board and ``loss_dev``."""
+        part = self.rec
+        _lib.check(self.lib.mde_vec_stats(self.N_own, _lib.ptr(self.own(g)), None if d is None else _lib.ptr(self.own(d)),
+                                          None if x is None else _lib.ptr(self.own(x)), _lib.ptr(part), self.p(self.work),
+                                          self._stream))
+        # the loss travels only when loss_dev holds a fresh share (an evaluation since the last reduction): after the
+        # reduction it holds the TOTAL, which must not be summed again by a statistics pass without an evaluation
+        fresh = self.loss_fresh
+        if fresh:
+            # (the share in DOUBLE, straight from the plan: the ranks' shares are summed before the one rounding to float)
+            _lib.check(self.lib.mde_plan_loss_double(self.plan_handle, ctypes.c_void_p(part.data_ptr() + 8 * (self._REC - 1)),
+                                                     self._stream))
+        src = part
+        if self.active:
+            self.dist.all_gather_into_tensor(self.rec_all, part, group=self.group)
+            src = self.rec_all
+        _lib.check(self.lib.mde_rank_reduce(self.world if self.active else 1, self._REC, self._MAXMASK, _lib.ptr(src),
+                                            self.p(self.board), self._REC - 1 if fresh else -1,
+                                            self.p(self.loss_dev) if fresh else None, self._stream))
+        self.loss_fresh = False
+
+    def update_direction(self, t_prev):
+        go, gp, dr = self.own(self.g), self.own(self.g_prev), self.own(self.dir)
+        _lib.check(self.lib.mde_lbfgs_dev_stage(self.lbfgs, _lib.ptr(go), _lib.ptr(gp), _lib.ptr(dr), float(t_prev),
+                                                self.p(self.work), self._stream))
+        self.all_reduce_small(self.work[:self.ndots])
+        # (the statistics of (g, dir) over the owned rows go into the record's direction slots; the next stats() call
+        # carries them across)
+        dirrec = self.rec[_DIR:_DIR + 8]
+        _lib.check(self.lib.mde_lbfgs_dev_finish(self.lbfgs, _lib.ptr(go), _lib.ptr(dr), _lib.ptr(dirrec), self.p(self.work),
+                                                 self._stream))
+
+    def gather_rows(self, Z):
+        """Every rank's owned rows of Z -> the replica Z (in place: this rank's rows already sit at their offset)."""
+        if not self.active:
+            return
+        flat = Z.view(-1)
+        mine = flat[self.lo * self.d:self.hi * self.d]
+        if self._gather_ok is not False:
+            try:
+                self.dist.all_gather_into_tensor(flat, mine, group=self.group)
+                self._gather_ok = True
+                return
+            except (RuntimeError, NotImplementedError, ValueError):
+                if self._gather_ok:
+                    raise
+                self._gather_ok = False
+        # a backend without the in-place all-gather: zero the other ranks' rows and sum
+        flat[:self.lo * self.d].zero_()
+        flat[self.hi * self.d:].zero_()
+        self.dist.all_reduce(flat, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+class _ShardedProblem(_NativeProblem):
+    """Objective + constraint of a row-sharded solve: the edge kernel on this rank's plan (no gradient exchange),
+    the constraint maps on the owned rows with their small reductions summed across the ranks."""
+
+    def __init__(self, engine, binding, constraint):
+        super(_ShardedProblem, self).__init__(engine, binding, constraint, reducer=None)
+
+    def turn_desc(self):
+        return None
+
+    def _colshift(self, Z):
+        """Z_own -= column mean of the whole Z (partial column sums: Z_own^T 1, summed across the ranks)."""
+        e, lib = self.e, self.e.lib
+        cs = e.small[:e.d]
+        _lib.check(lib.mde_gram(e.n_own, e.d, 1, _lib.ptr(e.own(Z)), _lib.ptr(e.ones), _lib.ptr(cs), e.p(e.work), e._stream))
+        e.all_reduce_small(cs)
+        cs.mul_(-1.0 / e.n)
+        _lib.check(lib.mde_shift_rows(e.n_own, e.d, _lib.ptr(cs), _lib.ptr(e.own(Z)), e._stream))
+
+    def _standardize(self, Z):
+        """Z_own <- sqrt(n) Z_own C^{-1/2}, C = Z^T Z over all rows (Z centred).  The d x d factor is formed on the
+        host in float64 from the summed Gram matrix (one small read-back; the single-GPU path iterates on the device)."""
+        e, lib = self.e, self.e.lib
+        C = e.small[:e.d * e.d]
+        Zo = e.own(Z)
+        _lib.check(lib.mde_gram(e.n_own, e.d, e.d, _lib.ptr(Zo), _lib.ptr(Zo), _lib.ptr(C), e.p(e.work), e._stream))
+        e.all_reduce_small(C)
+        Ch = C.view(e.d, e.d).cpu().numpy()
+        lam, Q = np.linalg.eigh(0.5 * (Ch + Ch.T))
+        if not np.all(np.isfinite(lam)) or lam.min() <= 1e-12 * max(lam.max(), 1e-300):
+            raise util.SolverError("Standardized retraction failed: X^T X is singular")
+        M = math.sqrt(e.n) * (Q / np.sqrt(lam)) @ Q.T
+        Md = torch.from_numpy(np.ascontiguousarray(M)).to(e.device)
+        _lib.check(lib.mde_right_multiply_add(e.n_own, e.d, e.d, _lib.ptr(Zo), _lib.ptr(Md), 1.0, None, _lib.ptr(Zo), e._stream))
+        e._keep_M = Md   # (alive until the kernel has read it)
+
+    def retract(self, X):
+        e = self.e
+        if self.kind == "anchored":
+            return super(_ShardedProblem, self).retract(X)
+        self._colshift(X)
+        if self.kind == "standardized":
+            self._standardize(X)
+        e.gather_rows(X)
+
+    def retract_step(self, t, out):
+        e = self.e
+        e.axpy(t, e.dir, e.X, out)
+        if self.kind == "anchored":
+            # (anchor rows are rewritten wherever they live; every rank then gathers everybody's rows)
+            super(_ShardedProblem, self).retract(out)
+            e.gather_rows(out)
+            return
+        self.retract(out)
+
+    def value_and_grad(self, X, project=True):
+        e, lib = self.e, self.e.lib
+        _lib.check(lib.mde_average_distortion(self._plan_handle, e.p(X), e.d, self._fref, 1.0, e.p(e.g), e.p(e.loss_dev),
+                                              e._stream))
+        e.loss_fresh = True
+        e.plan_handle = self._plan_handle
+        if self.kind == "standardized" and project:
+            # g_own -= (1 / n) X_own (g^T X), g^T X summed over all rows
+            G = e.small[:e.d * e.d]
+            go, Xo = e.own(e.g), e.own(X)
+            _lib.check(lib.mde_gram(e.n_own, e.d, e.d, _lib.ptr(go), _lib.ptr(Xo), _lib.ptr(G), e.p(e.work), e._stream))
+            e.all_reduce_small(G)
+            _lib.check(lib.mde_right_multiply_add(e.n_own, e.d, e.d, _lib.ptr(Xo), _lib.ptr(G), -1.0 / e.n, _lib.ptr(go),
+                                                  _lib.ptr(go), e._stream))
+        elif self.kind == "anchored":
+            _lib.check(lib.mde_anchor_rows(self.anchors.numel(), e.d, _lib.ptr(self.anchors), None, _lib.ptr(e.g), e.stream()))
+
+    def value_grad_stats(self, X):
+        self.value_and_grad(X)
+        self.e.stats(self.e.g, self.e.dir, X)
+
+    def check_status(self):
+        pass
+
+
 class _GenericProblem(object):
     """Arbitrary ``objective_fn`` (torch autograd) and/or custom ``Constraint`` object: the
     callbacks run in Python exactly as in the reference's closure (optim.py:100-105); vectors
@@ -349,6 +539,25 @@ def _is_native(objective_fn, constraint, require_fused_single_gpu=False):
     return native
 
 
+def _sharded_solver_args(objective_fn, constraint):
+    """(binding, lo, hi, group, rank, world, active) when the solve can run with its vectors sharded by rows
+    (``_ShardedEngine``): ``objective_fn`` is ``ShardedMDE.average_distortion`` of a problem with a built-in
+    constraint and a built-in distortion function whose evaluator owns ONE contiguous row range per rank.
+    ``MDE_SHARD_SOLVER=0`` keeps the replicated optimiser of rounds 2-5 (gradient all-gather, every rank runs the
+    whole vector work)."""
+    if os.environ.get("MDE_SHARD_SOLVER", "1") == "0" or not _is_native(objective_fn, constraint):
+        return None
+    owner = objective_fn.__self__
+    binding = owner._binding()
+    ev = getattr(owner, "_reducer", None)
+    if ev is None or not hasattr(ev, "plans") or len(ev.plans) != 1 or not binding.fused:
+        return None
+    plan = ev.plans[0]
+    if plan.is_full and not getattr(ev, "force", False) and ev.world <= 1:
+        return None
+    return (binding, plan.row_lo, plan.row_hi, ev.group, ev.rank, ev.world, ev._is_active())
+
+
 def _make_problem(engine, objective_fn, constraint):
     """Pick the native path when ``objective_fn`` is ``MDE.average_distortion`` of a problem
     with a built-in constraint; otherwise the generic (callback) path."""
@@ -384,10 +593,12 @@ def lbfgs(X, objective_fn, constraint, eps, max_iter, memory_size, use_line_sear
     device = util.require_cuda_device(X.device)
     caller_stream = torch.cuda.current_stream(device)
     with torch.cuda.device(device), torch.cuda.stream(caller_stream):
-        engine = _Engine(X, memory_size)
+        sh = _sharded_solver_args(objective_fn, constraint)
+        engine = _Engine(X, memory_size) if sh is None else _ShardedEngine(X, memory_size, *sh[1:])
         try:
             with torch.no_grad():
-                problem = _make_problem(engine, objective_fn, constraint)
+                problem = (_make_problem(engine, objective_fn, constraint) if sh is None
+                           else _ShardedProblem(engine, sh[0], constraint))
                 _solve(engine, problem, eps, max_iter, use_line_search, use_cached_loss, verbose,
                        print_every, snapshot_every, logger, average_distortions, grad_norms,
                        step_size_percents, times, snapshots, n_evals)

@@ -53,7 +53,19 @@ def main():
         sharded = distributed.ShardedMDE(n, d, edges, pymde_amd.penalties.PushAndPull(torch.tensor(w, device=dev)),
                                          constraint=pymde_amd.Centered(), device=dev, slices=slices, force_exchange=True)
         assert sharded._layout.slices == slices and len(sharded._reducer.plans) == slices
+        if slices == 1:
+            # the ROW-SHARDED solver (round 6) with its collectives on RCCL: the all-reduce of the history update's
+            # inner products, the in-place all-gather of the trial point's rows, the all-gather of the per-rank records
+            from pymde_amd import optim
+            assert optim._sharded_solver_args(sharded.average_distortion, sharded.constraint) is not None
+            Xr = sharded.embed(X=X0.clone(), max_iter=20)
+            np.testing.assert_allclose(sharded.solve_stats.average_distortions[:3],
+                                       single.solve_stats.average_distortions[:3], rtol=1e-5)
+            assert abs(sharded.value - single.value) <= 2e-2 * abs(single.value)
+            assert float(Xr.double().mean(0).abs().max()) < 1e-4
+            os.environ["MDE_SHARD_SOLVER"] = "0"   # ... and the replicated optimiser behind the gradient exchange
         Xd = sharded.embed(X=X0.clone(), max_iter=20)
+        os.environ.pop("MDE_SHARD_SOLVER", None)
         # (one slice: the in-place all-gather of GradExchange; four: the sliced gathers on the side stream, each
         # behind its slice's kernel, with the loss share as a one-float all-reduce)
         assert sharded._reducer.mode == "all_gather", (slices, sharded._reducer.mode)

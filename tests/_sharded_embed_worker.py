@@ -55,7 +55,28 @@ def main():
                 assert float((xd.grad - xs.grad).abs().max()) <= 1e-5 * scale, (rank, cname)
             np.testing.assert_allclose(float(Ed), float(Es), rtol=2e-6)
             Xs = single.embed(X=x0.clone(), max_iter=15).clone()
+            # (1) the ROW-SHARDED solver (round 6, the default): no gradient exchange, every rank keeps the L-BFGS
+            # history of its own rows, the trial point's owned rows are gathered.  Every rank must end with the same
+            # iterate, bit for bit (the host-side line search branches on numbers every rank reduces identically);
+            # against the single process the inner products are summed in another order, so: the start of the
+            # trajectory and the value reached
+            from pymde_amd import optim as _optim
+            assert _optim._sharded_solver_args(sharded.average_distortion, sharded.constraint) is not None
+            Xr = sharded.embed(X=x0.clone(), max_iter=15)
+            ref = Xr.clone()
+            dist.broadcast(ref, src=0)
+            assert torch.equal(ref, Xr), (rank, cname, "row-sharded solver: ranks disagree")
+            np.testing.assert_allclose(sharded.solve_stats.average_distortions[:3],
+                                       single.solve_stats.average_distortions[:3], rtol=1e-4)
+            assert abs(sharded.value - single.value) <= 2e-2 * abs(single.value), (cname, sharded.value, single.value)
+            Zr = Xr.double()
+            assert float(Zr.mean(0).abs().max()) < 1e-4
+            if cname == "standardized":
+                assert float((Zr.T @ Zr / n - torch.eye(2, device=dev, dtype=torch.float64)).abs().max()) < 1e-4
+            # (2) the replicated optimiser of rounds 2-5 (gradient exchange, MDE_SHARD_SOLVER=0)
+            os.environ["MDE_SHARD_SOLVER"] = "0"
             Xd = sharded.embed(X=x0.clone(), max_iter=15)
+            os.environ.pop("MDE_SHARD_SOLVER")
             # every rank holds the same iterate (the optimiser runs replicated on identical data)
             ref = Xd.clone()
             dist.broadcast(ref, src=0)
@@ -72,6 +93,55 @@ def main():
                 np.testing.assert_allclose(sharded.solve_stats.average_distortions[:3],
                                            single.solve_stats.average_distortions[:3], rtol=1e-4)
                 assert abs(sharded.value - single.value) <= 2e-2 * abs(single.value)
+    # ---- the row-sharded solver against the REFERENCE: the config-2 stand-in at n = 20k (PushAndPull(Log1p, Log),
+    # Standardized) from tests/golden/trajectories_mid.npz -- the reference's own four runs agree to 1e-4 there, and
+    # the sharded solve must follow the unperturbed one for the first 5 iterations like the single process does
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = np.load(os.path.join(here, "golden", "trajectories_mid.npz"))
+    os.environ.pop("MDE_PANEL", None)
+    n, e_mid, par = mg.mid_problem_arrays("neighbors")
+    pen = pymde_amd.penalties
+    f = pen.PushAndPull(torch.tensor(par, device=dev), pen.Log1p, pen.Log)
+    sharded = distributed.ShardedMDE(n, 2, torch.tensor(e_mid, device=dev), f, constraint=pymde_amd.Standardized(), device=dev)
+    sharded.embed(X=torch.tensor(g["neighbors__X0"], device=dev), max_iter=8, eps=1e-12, memory_size=10)
+    E_ref = g["neighbors__distortions"]
+    got = np.array(sharded.solve_stats.average_distortions[:5])
+    assert np.allclose(got, E_ref[0, :5], rtol=1e-3, atol=1e-7), (rank, got, E_ref[0, :5])
+    np.testing.assert_allclose(sharded.solve_stats.residual_norms[:5], g["neighbors__residuals"][0, :5], rtol=2e-3, atol=1e-6)
+    # ---- d = 128 with the row-sharded solver (one range per rank: the default)
+    n, p, d = 4096, 60000, 128
+    i = rng.integers(0, n, p)
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    e = np.unique(np.sort(np.stack([i, j], 1), 1), axis=0)
+    w = (1.0 + (rng.random(len(e)) < 0.3)).astype(np.float32) * 1.0e3
+    edges = torch.tensor(e, device=dev)
+    for make in (pymde_amd.Standardized, pymde_amd.Centered):
+        c = make()
+        torch.manual_seed(0)
+        x0 = c.initialization(n, d, device=dev)
+        f = pymde_amd.penalties.Log1p(torch.tensor(w, device=dev))
+        single = pymde_amd.MDE(n, d, edges, f, constraint=c, device=dev)
+        sharded = distributed.ShardedMDE(n, d, edges, f, constraint=make(), device=dev)
+        assert len(sharded._reducer.plans) == 1
+        single.embed(X=x0.clone(), max_iter=40)
+        Xr = sharded.embed(X=x0.clone(), max_iter=40)
+        ref = Xr.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(ref, Xr), (rank, "d = 128 row-sharded: ranks disagree")
+        ds, dd = np.array(single.solve_stats.average_distortions), np.array(sharded.solve_stats.average_distortions)
+        np.testing.assert_allclose(dd[0], ds[0], rtol=1e-6)
+        assert (np.diff(dd) <= 1e-6 * np.abs(dd[:-1])).all() and dd[-1] < 0.95 * dd[0], dd
+        # (the two line searches part ways within the first steps -- a near-zero discriminant in the cubic interpolation
+        # amplifies the last bit of the loss --: after 40 iterations both have descended to the same level)
+        assert abs(sharded.value - single.value) <= 0.10 * single.value, (sharded.value, single.value)
+        Zr = Xr.double()
+        assert float(Zr.mean(0).abs().max()) < 1e-4
+        if make is pymde_amd.Standardized:
+            assert float((Zr.T @ Zr / n - torch.eye(d, device=dev, dtype=torch.float64)).abs().max()) < 2e-4
     # ---- d = 128 (config-5 shape, small): four slices per rank, the all-gather of one slice under the kernel of
     # the next; bit-equal to the single-process evaluation and solve (CSR kernel: a row is summed in edge order
     # whoever owns it)
@@ -99,8 +169,8 @@ def main():
         assert torch.equal(xd.grad, xs.grad), (rank, "d = 128", float((xd.grad - xs.grad).abs().max()))
         np.testing.assert_allclose(float(Ed), float(Es), rtol=2e-6)
     assert sharded._reducer.mode in ("all_gather", "all_reduce")
-    Xs = single.embed(X=x0.clone(), max_iter=8).clone()
-    Xd = sharded.embed(X=x0.clone(), max_iter=8)
+    Xs = single.embed(X=x0.clone(), max_iter=40).clone()
+    Xd = sharded.embed(X=x0.clone(), max_iter=40)
     ref = Xd.clone()
     dist.broadcast(ref, src=0)
     assert torch.equal(ref, Xd), (rank, "d = 128: ranks disagree")
@@ -110,9 +180,9 @@ def main():
     ds, dd = np.array(single.solve_stats.average_distortions), np.array(sharded.solve_stats.average_distortions)
     np.testing.assert_allclose(dd[0], ds[0], rtol=1e-6)
     assert (np.diff(dd) <= 1e-6 * np.abs(dd[:-1])).all() and dd[-1] < 0.95 * dd[0], dd
-    # (eight iterations from a random start are far from converged and the two line searches part ways early:
-    # the sharded solve must descend as well as the single-process one, not along the same path)
-    assert sharded.value <= 1.15 * single.value, (sharded.value, single.value)
+    # (the two line searches part ways early: the sharded solve must descend as well as the single-process one, not
+    # along the same path -- after 40 iterations both are at the same level)
+    assert abs(sharded.value - single.value) <= 0.10 * single.value, (sharded.value, single.value)
     mode128 = sharded._reducer.mode
     # ---- an arbitrary callable, sharded: distances and f replicated, the scatter over the owned rows
     n, p, d = 3000, 30000, 3
