@@ -331,6 +331,13 @@ int mde_center_step(int64_t n, int32_t d, const float* X, const float* dir, floa
                     void* stream);
 int mde_std_retract_step(int64_t n, int32_t d, const float* X, const float* dir, float t, float* Z,
                          int32_t demean, double* work, int32_t* status_dev, void* stream);
+/* mde_center_step in two halves, for a solve whose rows are sharded across ranks: _begin forms this rank's n rows of
+ * Z = X + t dir (dir == NULL: Z as it is) and leaves the column MEANS over those rows in work[0 .. d) (device doubles);
+ * the caller sums them across the ranks in place (one small all-reduce); _end subtracts scale x work[0 .. d) from the
+ * rows (scale = n / n_total, this rank's share of the rows).  In a world of one: _begin + _end(scale 1) = mde_center_step. */
+int mde_center_step_begin(int64_t n, int32_t d, const float* X, const float* dir, float t, float* Z, double* work,
+                          void* stream);
+int mde_center_step_end(int64_t n, int32_t d, float* Z, double* work, double scale, void* stream);
 /* mde_std_tangent(X, Z) followed by mde_vec_stats(Z, dir, X) (dir may be NULL): the projected gradient
  * and the statistics the line search reads, with the statistics folded into the projection's second
  * pass at d <= 4.  ASYNC. */

@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64) void k_colsum_final(int nb, int d, int64_t n, c
   if (threadIdx.x == 0) mean[c] = s / (double)n;
 }
 __global__ __launch_bounds__(MDE_BLOCK) void k_sub_mean(int64_t N, int d, float* __restrict__ Z,
-                                                        const double* __restrict__ mean) {
+                                                        const double* __restrict__ mean, double scale = 1.0) {
   const int64_t stride = (int64_t)gridDim.x * MDE_BLOCK;
   for (int64_t i0 = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x; i0 < N; i0 += 4 * stride) {
     float z[4];
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_sub_mean(int64_t N, int d, float*
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      if (in[u]) Z[i0 + u * stride] = (float)((double)z[u] - mean[(i0 + u * stride) % d]);
+      if (in[u]) Z[i0 + u * stride] = (float)((double)z[u] - scale * mean[(i0 + u * stride) % d]);  // (scale = 1: exact)
   }
 }
 
@@ -424,8 +424,9 @@ static int pow2_ge(int x) {
   return p;
 }
 
+// halves: 1 = the column means only (left in work[0 .. d)), 2 = the subtraction only (of scale x work[0 .. d)), 3 = both
 static int center_impl(int64_t n, int d, float* Z, double* work, hipStream_t st, const float* X0 = nullptr,
-                       const float* DIR = nullptr, float t = 0.0f) {
+                       const float* DIR = nullptr, float t = 0.0f, int halves = 3, double scale = 1.0) {
   double* mean = work;  // d doubles (d <= 2048 fits the small area)
   double* partial = work_partials(work, d);
   int dp = pow2_ge(d);
@@ -434,6 +435,11 @@ static int center_impl(int64_t n, int d, float* Z, double* work, hipStream_t st,
   int nb = mde_grid(n, rpp * 8, MDE_RED_BLOCKS);
   // (a last workgroup adding d columns of nb partials one after the other only pays for a few columns)
   const bool fused_final = d <= 16;
+  if (!(halves & 1)) {
+    hipLaunchKernelGGL(k_sub_mean, dim3(mde_grid(n * d, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, n * d, d, Z, mean, scale);
+    MDE_LAUNCH_CHECK();
+    return MDE_OK;
+  }
   if (DIR)
     hipLaunchKernelGGL(k_colsum<true>, dim3(nb), dim3(MDE_BLOCK), 0, st, n, d, dp, Z, X0, DIR, t, partial, mean,
                        fused_final ? work_ticket(work, TK_CENTER) : (unsigned int*)nullptr);
@@ -445,10 +451,24 @@ static int center_impl(int64_t n, int d, float* Z, double* work, hipStream_t st,
     hipLaunchKernelGGL(k_colsum_final, dim3(d), dim3(64), 0, st, nb, d, n, partial, mean);
     MDE_LAUNCH_CHECK();
   }
+  if (!(halves & 2)) return MDE_OK;
   hipLaunchKernelGGL(k_sub_mean, dim3(mde_grid(n * d, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, n * d, d, Z,
-                     mean);
+                     mean, scale);
   MDE_LAUNCH_CHECK();
   return MDE_OK;
+}
+
+// The two halves of mde_center_step for a row-sharded solve (round 6): _begin forms this rank's rows of Z = X + t dir
+// (dir == NULL: Z as it is) and leaves the column MEANS over these n rows in work[0 .. d); the caller sums them across
+// the ranks in place; _end subtracts scale x work[0 .. d) (scale = this rank's share of the rows, n / n_total).
+extern "C" int mde_center_step_begin(int64_t n, int32_t d, const float* X, const float* dir, float t, float* Z, double* work,
+                                     void* stream) {
+  if (n <= 0 || d <= 0 || d > 2048 || !Z || !work || (dir && !X)) return MDE_E_INVALID;
+  return center_impl(n, d, Z, work, mde_stream(stream), dir ? X : nullptr, dir, t, 1);
+}
+extern "C" int mde_center_step_end(int64_t n, int32_t d, float* Z, double* work, double scale, void* stream) {
+  if (n <= 0 || d <= 0 || d > 2048 || !Z || !work) return MDE_E_INVALID;
+  return center_impl(n, d, Z, work, mde_stream(stream), nullptr, nullptr, 0.0f, 2, scale);
 }
 
 extern "C" int mde_center(int64_t n, int32_t d, float* Z, double* work, void* stream) {

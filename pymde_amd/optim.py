@@ -329,7 +329,6 @@ class _ShardedEngine(_Engine):
         self.rec = torch.zeros(self._REC, dtype=torch.float64, device=dev)
         self.rec_all = torch.zeros((self.world if self.active else 1) * self._REC, dtype=torch.float64, device=dev)
         self.ndots = int(self.lib.mde_lbfgs_dev_dots(self.lbfgs))
-        self.ones = torch.ones(max(self.n_own, 1), dtype=torch.float32, device=dev)
         self.small = torch.zeros(max(self.d * self.d, 8), dtype=torch.float64, device=dev)
         # (MDE_SHARD_XGATHER=0: exchange the trial point's rows as a zero-padded all-reduce -- what a backend without the
         # in-place all-gather gets anyway)
@@ -416,14 +415,19 @@ class _ShardedProblem(_NativeProblem):
     def turn_desc(self):
         return None
 
-    def _colshift(self, Z):
-        """Z_own -= column mean of the whole Z (partial column sums: Z_own^T 1, summed across the ranks)."""
+    def _colshift(self, Z, step=None):
+        """Z_own -= column mean of the whole Z (mde_center_step in two halves: this rank's column means, summed
+        across the ranks in place, subtracted with the rank's share of the rows as the scale).  step = t: Z_own is
+        first formed as X_own + t dir_own in the same pass."""
         e, lib = self.e, self.e.lib
-        cs = e.small[:e.d]
-        _lib.check(lib.mde_gram(e.n_own, e.d, 1, _lib.ptr(e.own(Z)), _lib.ptr(e.ones), _lib.ptr(cs), e.p(e.work), e._stream))
-        e.all_reduce_small(cs)
-        cs.mul_(-1.0 / e.n)
-        _lib.check(lib.mde_shift_rows(e.n_own, e.d, _lib.ptr(cs), _lib.ptr(e.own(Z)), e._stream))
+        Zo = e.own(Z)
+        if step is None:
+            _lib.check(lib.mde_center_step_begin(e.n_own, e.d, None, None, 0.0, _lib.ptr(Zo), e.p(e.work), e._stream))
+        else:
+            _lib.check(lib.mde_center_step_begin(e.n_own, e.d, _lib.ptr(e.own(e.X)), _lib.ptr(e.own(e.dir)), float(step),
+                                                 _lib.ptr(Zo), e.p(e.work), e._stream))
+        e.all_reduce_small(e.work[:e.d])
+        _lib.check(lib.mde_center_step_end(e.n_own, e.d, _lib.ptr(Zo), e.p(e.work), float(e.n_own) / float(e.n), e._stream))
 
     def _standardize(self, Z):
         """Z_own <- sqrt(n) Z_own C^{-1/2}, C = Z^T Z over all rows (Z centred).  The d x d factor is formed on the
@@ -442,24 +446,24 @@ class _ShardedProblem(_NativeProblem):
         _lib.check(lib.mde_right_multiply_add(e.n_own, e.d, e.d, _lib.ptr(Zo), _lib.ptr(Md), 1.0, None, _lib.ptr(Zo), e._stream))
         e._keep_M = Md   # (alive until the kernel has read it)
 
-    def retract(self, X):
+    def retract(self, X, step=None):
         e = self.e
         if self.kind == "anchored":
             return super(_ShardedProblem, self).retract(X)
-        self._colshift(X)
+        self._colshift(X, step)
         if self.kind == "standardized":
             self._standardize(X)
         e.gather_rows(X)
 
     def retract_step(self, t, out):
         e = self.e
-        e.axpy(t, e.dir, e.X, out)
         if self.kind == "anchored":
             # (anchor rows are rewritten wherever they live; every rank then gathers everybody's rows)
+            e.axpy(t, e.dir, e.X, out)
             super(_ShardedProblem, self).retract(out)
             e.gather_rows(out)
             return
-        self.retract(out)
+        self.retract(out, step=t)
 
     def value_and_grad(self, X, project=True):
         e, lib = self.e, self.e.lib
