@@ -723,14 +723,7 @@ static int launch_wide(FusedArgs& A, const Fn& fn) {
     if (d4 <= 4) return launch_wide4_gk<4, 1, IND, Fn>(A, fn);
     if (d4 <= 8) return launch_wide4_gk<8, 1, IND, Fn>(A, fn);
     if (d4 <= 16) return launch_wide4_gk<16, 1, IND, Fn>(A, fn);
-    if (d4 <= 32) {
-      // (MDE_WIDE_GL, design probe: fewer lanes per half-edge -- 16 x 2 or 8 x 4 float4s -- i.e. more half-edges per wave
-      // step and a shorter cross-lane sum, against the fully coalesced 512-byte row of a half wave)
-      static const int gl = getenv("MDE_WIDE_GL") ? atoi(getenv("MDE_WIDE_GL")) : 32;
-      if (d4 > 16 && gl == 16) return launch_wide4_gk<16, 2, IND, Fn>(A, fn);
-      if (d4 > 16 && gl == 8) return launch_wide4_gk<8, 4, IND, Fn>(A, fn);
-      return launch_wide4_gk<32, 1, IND, Fn>(A, fn);
-    }
+    if (d4 <= 32) return launch_wide4_gk<32, 1, IND, Fn>(A, fn);
     if (d4 <= 64) return launch_wide4_gk<64, 1, IND, Fn>(A, fn);
     if (d4 <= 128) return launch_wide4_gk<64, 2, IND, Fn>(A, fn);
     if (d4 <= 256) return launch_wide4_gk<64, 4, IND, Fn>(A, fn);
