@@ -69,21 +69,24 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(key):
+def pmc_traffic(key, tag=""):
     """HBM bytes per launch recorded by the PMC passes (tools/pmc_traffic.sh), or None when the
-    record is missing or belongs to another version of the kernel source."""
-    path = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+    record is missing or belongs to another version of the kernel source.  tag: "" the headline workload, "_4b",
+    "_d3", "_n2m" the secondary records of round 6."""
+    name = "r06_pmc_traffic%s.json" % tag
+    path = os.path.join(ROOT, "profiles", name)
     try:
         rec = json.load(open(path))
     except Exception:
         return None, None
     if rec.get("source_sha") != source_sha():
-        return None, "profiles/r05_pmc_traffic.json is from another kernel source (stale): ignored"
+        return None, "profiles/%s is from another kernel source (stale): ignored" % name
     b = rec.get("bytes_per_launch", {})
     v = b.get(key)
-    if v is not None and key.startswith("ring") and "ring_combine" in b:
-        v += b["ring_combine"]  # (the 2 column groups per row block: their partial rows are added by a second launch)
-    return v, "profiles/r05_pmc_traffic.json (rocprofv3 --pmc, bytes/launch; the ring kernel, which adds its two column groups itself)"
+    if v is not None and key.startswith("ring"):
+        # (whatever else the evaluation launches behind the ring kernel: the combine of > 2 column groups, the hub rows)
+        v += sum(b.get(k, 0.0) for k in ("ring_combine", "hub_rows", "hub_finish"))
+    return v, "profiles/%s (rocprofv3 --pmc, bytes/launch of the evaluation's kernels)" % name
 
 
 def make_workload(device, n=N_ITEMS, deg=OUT_DEGREE, d=DIM, graph="uniform"):
@@ -455,9 +458,15 @@ def run_config4(args, world, rank, device):
     if layout == 1 and ring["permuted"]:
         kernel += "; row blocks dealt by degree"
     traffic, traffic_src = (None, None)
-    if world == 1 and args.emulate_world <= 1 and headline_shape and args.variant == "4a" and args.function == "log1p":
-        traffic, traffic_src = pmc_traffic({"codebook": "ring_codebook", "byte index": "ring_bytes"}.get(binding.stream_kind, "ring_fp32")
-                                           if layout == 1 else "csr")
+    if world == 1 and args.emulate_world <= 1 and args.function == "log1p":
+        tag = None
+        if headline_shape:
+            tag = "" if args.variant == "4a" else "_4b"
+        elif args.variant == "4a" and args.graph == "uniform":
+            tag = {(N_ITEMS, 3): "_d3", (2 * N_ITEMS, 2): "_n2m"}.get((n, d))
+        if tag is not None:
+            traffic, traffic_src = pmc_traffic({"codebook": "ring_codebook", "byte index": "ring_bytes"}.get(binding.stream_kind, "ring_fp32")
+                                               if layout == 1 else "csr", tag)
 
     if rank != 0:
         return None

@@ -38,7 +38,7 @@ struct mde_ring_layout {
   int32_t* hub_first = nullptr; // [n_hub_rows + 1] first segment of each hub row
   double* hub_partial = nullptr;  // [n_hub_segs][8]: sum g (x_v - x_u) [<= 4] | loss
 };
-#define MDE_HUB_SEG 2048
+#define MDE_HUB_SEG 512
 
 struct mde_plan {
   int64_t n = 0, p = 0, H = 0, row_lo = 0, row_hi = 0;

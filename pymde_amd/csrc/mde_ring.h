@@ -69,7 +69,10 @@ __host__ __device__ constexpr int ring_gr_off(int d) { return ring_ctrl_off(d) +
 #ifndef MDE_RING_C2
 #define MDE_RING_C2 512
 #endif
-__host__ __device__ constexpr int ring_chunk_cols(int d) { return d == 1 ? 1024 : (d == 2 ? MDE_RING_C2 : 256); }
+#ifndef MDE_RING_C3
+#define MDE_RING_C3 256
+#endif
+__host__ __device__ constexpr int ring_chunk_cols(int d) { return d == 1 ? 1024 : (d == 2 ? MDE_RING_C2 : (d == 3 ? MDE_RING_C3 : 256)); }
 __host__ __device__ constexpr int ring_chunk_bytes(int d) { return ring_chunk_cols(d) * 4 * d; }
 // ring placement for row blocks of R rows
 __host__ __device__ constexpr int ring_off_for(int d, int R) { return (ring_gr_off(d) + (R + 32) * 4 * d + 255) / 256 * 256; }

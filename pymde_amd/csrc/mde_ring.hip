@@ -706,6 +706,29 @@ static double csr_time_us(const mde_plan* plan, int d) {
 
 // Decide the block height and the column groups for dimension d; false when the layout is not
 // worthwhile (the caller keeps the CSR kernel).
+// Column groups per row block.  Default: one workgroup per CU (256 / row blocks).  Round 6: more than that when the
+// cost model says so -- 193 row blocks (d = 3 at n = 1M) leave a quarter of the CUs idle with Q = 1 and need two
+// rounds with Q = 2; with Q = 5 the 965 workgroups run 4 rounds of a fifth of the table each: 0.496 -> 0.444 ms
+// (tools/r6_d3_sweep.sh), which the model predicts (547 -> 452 us).  A workgroup's fixed cost (prologue, epilogue,
+// partial rows) is priced at 4 us; the default stays unless another Q is 5 % better.  MDE_RING_Q: design probe.
+static int choose_col_groups(const mde_plan* plan, int64_t nrb, int qmax, int64_t nc) {
+  int Q = (int)std::min<int64_t>(qmax, std::max<int64_t>(1, 256 / nrb));
+  const double its1 = 1.4 * (double)plan->H / ((double)nrb * MDE_RING_NCW * 64.0);
+  auto cost = [&](int q) {
+    const double rounds = std::ceil((double)(nrb * q) / 256.0);
+    return ring_time_us(its1 / q, (int)nc, q, (int)(nrb * q)) + 4.0 * rounds;
+  };
+  const double base = cost(Q);
+  double best = base;
+  for (int q = 1; q <= qmax; ++q)
+    if ((int64_t)nrb * q <= MDE_MAX_PARTIALS && cost(q) < 0.95 * base && cost(q) < best) {
+      best = cost(q);
+      Q = q;
+    }
+  if (getenv("MDE_RING_Q")) Q = std::max(1, std::min(qmax, atoi(getenv("MDE_RING_Q"))));
+  return Q;
+}
+
 static bool choose_sizes(const mde_plan* plan, int d, RingSizes* z) {
   const int64_t nloc = plan->row_hi - plan->row_lo;
   if (d < 1 || d > 4 || nloc <= 0 || plan->H <= 0) return false;
@@ -734,7 +757,7 @@ static bool choose_sizes(const mde_plan* plan, int d, RingSizes* z) {
   const int64_t pr_max = ring_row_cap(d);
   if (pr > pr_max) pr = pr_max;
   const int64_t nrb = (nloc + pr - 1) / pr;
-  int Q = (int)std::min<int64_t>(qmax, std::max<int64_t>(1, 256 / nrb));
+  int Q = choose_col_groups(plan, nrb, qmax, nc);
   if (nrb * Q > MDE_MAX_PARTIALS) return false;
   const int jb = bits_for_u64((uint64_t)nc - 1);
   if (bits_for_u64((uint64_t)(nrb * Q * MDE_RING_NCW)) + jb > 32) return false;
@@ -960,7 +983,7 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     if (rc != MDE_OK) return rc;
     if (rp.mapped && rp.nrb != z.NRB) {
       z.NRB = rp.nrb;
-      z.Q = (int)std::min<int64_t>(z.qmax, std::max<int64_t>(1, 256 / z.NRB));
+      z.Q = choose_col_groups(plan, z.NRB, z.qmax, z.NC);
       if ((int64_t)z.NRB * z.Q > MDE_MAX_PARTIALS || bits_for_u64((uint64_t)((int64_t)z.NRB * z.Q * MDE_RING_NCW)) + z.JB > 32) return 0;
     }
   }
@@ -1784,34 +1807,40 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_hub_rows(const int32_t* __restric
   if (threadIdx.x == 0) partial[(size_t)sgi * 8 + 4] = tl;
 }
 
-// blocks 0 .. gridDim.x - 2: one thread per hub row; the last block: the loss
+// One wave per hub row (blocks 0 .. n_hub - 1): the lanes add the row's segments lane-strided, a butterfly adds the lanes
+// (fixed order); the last block adds the segments' loss terms the same way.  (The first version gave a row to ONE
+// thread: the 977 segments of a 5e5-degree hub were 977 dependent loads, 148 us.)
 template <int D>
-__global__ __launch_bounds__(MDE_BLOCK) void k_hub_finish(int n_hub, int n_seg, const int32_t* __restrict__ hub_rows,
-                                                          const int32_t* __restrict__ hub_first,
-                                                          const double* __restrict__ partial, int row_lo, float grad_scale,
-                                                          float* __restrict__ grad, double loss_scale, float* __restrict__ loss_out,
-                                                          double* __restrict__ loss_d) {
-  __shared__ double smem[8];
-  if (blockIdx.x + 1 < gridDim.x) {
-    const int i = blockIdx.x * MDE_BLOCK + threadIdx.x;
-    if (i >= n_hub || !grad) return;
+__global__ __launch_bounds__(64) void k_hub_finish(int n_hub, int n_seg, const int32_t* __restrict__ hub_rows,
+                                                   const int32_t* __restrict__ hub_first,
+                                                   const double* __restrict__ partial, int row_lo, float grad_scale,
+                                                   float* __restrict__ grad, double loss_scale, float* __restrict__ loss_out,
+                                                   double* __restrict__ loss_d) {
+  const int lane = threadIdx.x;
+  if ((int)blockIdx.x < n_hub) {
+    if (!grad) return;
+    const int i = blockIdx.x;
     double a[D];
 #pragma unroll
     for (int c = 0; c < D; ++c) a[c] = 0.0;
-    for (int sg = hub_first[i]; sg < hub_first[i + 1]; ++sg) {
+    for (int sg = hub_first[i] + lane; sg < hub_first[i + 1]; sg += 64) {
 #pragma unroll
       for (int c = 0; c < D; ++c) a[c] += partial[(size_t)sg * 8 + c];
     }
-    const int64_t v = (int64_t)row_lo + hub_rows[i];
 #pragma unroll
-    for (int c = 0; c < D; ++c) grad[v * D + c] = (float)a[c] * grad_scale;
+    for (int c = 0; c < D; ++c) a[c] = mde_wave_sum(a[c]);
+    if (lane == 0) {
+      const int64_t v = (int64_t)row_lo + hub_rows[i];
+#pragma unroll
+      for (int c = 0; c < D; ++c) grad[v * D + c] = (float)a[c] * grad_scale;
+    }
     return;
   }
   double t = 0.0;
-  for (int sg = threadIdx.x; sg < n_seg; sg += MDE_BLOCK) t += partial[(size_t)sg * 8 + 4];
-  const double tot = mde_block_sum(t, smem);
+  for (int sg = lane; sg < n_seg; sg += 64) t += partial[(size_t)sg * 8 + 4];
+  const double tot = mde_wave_sum(t);
   // (the ring kernel left its part of the loss in *loss_d in double: the hub rows' part is added before the one rounding)
-  if (threadIdx.x == 0) {
+  if (lane == 0) {
     *loss_d += tot * loss_scale;
     *loss_out = (float)*loss_d;
   }
@@ -1825,9 +1854,9 @@ static int hub_launch_d(const mde_plan* plan, const float* X, const mde_func* f,
   hipLaunchKernelGGL(k_hub_rows<D>, dim3(L.n_hub_segs), dim3(MDE_BLOCK), 0, st, L.hub_rows, L.hub_seg, (int)plan->row_lo, plan->nbr,
                      plan->eid, e0, e1, e0_scalar, e1_scalar, X, fn, inv_p, L.count_all, L.hub_partial);
   MDE_LAUNCH_CHECK();
-  const int nb = (L.n_hub_rows + MDE_BLOCK - 1) / MDE_BLOCK + 1;
+  const int nb = L.n_hub_rows + 1;
   // (the ring kernel's rule: the smaller endpoint adds f -> 2 x the caller's half-weight; count_all: every entry f / 2)
-  hipLaunchKernelGGL(k_hub_finish<D>, dim3(nb), dim3(MDE_BLOCK), 0, st, L.n_hub_rows, L.n_hub_segs, L.hub_rows, L.hub_first,
+  hipLaunchKernelGGL(k_hub_finish<D>, dim3(nb), dim3(64), 0, st, L.n_hub_rows, L.n_hub_segs, L.hub_rows, L.hub_first,
                      L.hub_partial, (int)plan->row_lo, grad_scale, grad, (L.count_all ? 1.0 : 2.0) * loss_scale, loss_out,
                      plan->partials + MDE_PARTIALS_LOSS_D);
   MDE_LAUNCH_CHECK();

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     };
     auto wait_buf = [&](int k) __attribute__((always_inline)) {
 #if MDE_RING_ASMLOAD
-      static_assert(UNIT * PIECES == 4 || UNIT * PIECES == 2 || UNIT * PIECES == 3 || UNIT * PIECES == 8, "operand list of the wait");
+      static_assert(UNIT * PIECES == 4 || UNIT * PIECES == 2 || UNIT * PIECES == 3 || UNIT * PIECES == 8 || UNIT * PIECES == 6, "operand list of the wait");
       constexpr int NEWER = (DEPTH - 1) * UNIT * PIECES;
       if constexpr (UNIT * PIECES == 4)
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(buf[k][0]), "+v"(buf[k][1]), "+v"(buf[k][2]), "+v"(buf[k][3]) : "n"(NEWER) : "memory");
@@ -289,6 +289,9 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         asm volatile("s_waitcnt vmcnt(%3)" : "+v"(buf[k][0]), "+v"(buf[k][1]), "+v"(buf[k][2]) : "n"(NEWER) : "memory");
       else if constexpr (UNIT * PIECES == 2)
         asm volatile("s_waitcnt vmcnt(%2)" : "+v"(buf[k][0]), "+v"(buf[k][1]) : "n"(NEWER) : "memory");
+      else if constexpr (UNIT * PIECES == 6)
+        asm volatile("s_waitcnt vmcnt(%6)" : "+v"(buf[k][0]), "+v"(buf[k][1]), "+v"(buf[k][2]), "+v"(buf[k][3]), "+v"(buf[k][4]),
+                     "+v"(buf[k][5]) : "n"(NEWER) : "memory");
       else
         asm volatile("s_waitcnt vmcnt(%8)" : "+v"(buf[k][0]), "+v"(buf[k][1]), "+v"(buf[k][2]), "+v"(buf[k][3]), "+v"(buf[k][4]),
                      "+v"(buf[k][5]), "+v"(buf[k][6]), "+v"(buf[k][7]) : "n"(NEWER) : "memory");

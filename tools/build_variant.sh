@@ -5,11 +5,11 @@
 set -e
 cd "$(dirname "$0")/.."
 mkdir -p tools/variants/$1
-units="mde_ring mde_ring_k_log1p mde_ring_k_pushpull"
+units="mde_ring mde_ring_k_log1p mde_ring_k_pushpull mde_ring_k_penalty mde_ring_k_loss"
 for u in $units; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -Wno-unused-result -ffp-contract=fast $2 -c pymde_amd/csrc/$u.hip -o tools/variants/$1/$u.o &
 done
 wait
-objs=$(ls pymde_amd/csrc/build/*.o | grep -v -e "mde_ring.o" -e "mde_ring_k_log1p.o" -e "mde_ring_k_pushpull.o")
+objs=$(ls pymde_amd/csrc/build/*.o | grep -v -e "mde_ring.o" -e "mde_ring_k_log1p.o" -e "mde_ring_k_pushpull.o" -e "mde_ring_k_penalty.o" -e "mde_ring_k_loss.o")
 vobjs=$(for u in $units; do echo tools/variants/$1/$u.o; done)
 hipcc --offload-arch=gfx950 -shared -fPIC -o tools/variants/$1/libmde_hip.so $objs $vobjs

@@ -27,6 +27,10 @@ def classify(name):
             return {"0": "ring_fp32", "1": "ring_codebook", "2": "ring_bytes"}.get(flags[1])
     if "k_ring_combine" in name:
         return "ring_combine"
+    if "k_hub_rows" in name:
+        return "hub_rows"
+    if "k_hub_finish" in name:
+        return "hub_finish"
     if "k_fused_wide4" in name:
         return "wide4"
     if "k_fused_small" in name:
