@@ -138,6 +138,14 @@ static __device__ int g_ring_ndiag;
 // (value index in the packed word's spare bits, <= 7 / 3 values), 2 = byte index (one byte per entry beside the
 // packed words -- 5 B per half-edge --, a 256-entry value table in the 1 KB behind the ring; round 5: the hop
 // counts of a distance-preserving problem on a graph are tens of distinct integers, which streamed 8 B until now)
+// MDE_RING_FWORDS (round 6): producers publish INDEPENDENTLY -- F[p] = the next chunk of producer p that has not landed --
+// and a consumer takes the minimum of the four words (one ds_read_b128, prefetched a pair ahead like round 5's single
+// word).  Round 5 published in chunk order through ONE word: a producer that has stored chunk j waits until
+// LANDED == j before it writes j + 1 -- a serial chain of two LDS round trips per chunk (~0.14 us), which is what the
+// "staged bytes" bound of the large-table regimes turned out to be.
+#ifndef MDE_RING_FWORDS
+#define MDE_RING_FWORDS 0
+#endif
 #ifdef MDE_RING_EVAL2
 constexpr bool defined_MDE_RING_EVAL2 = true;
 #else
@@ -221,7 +229,12 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
     int* prog = reinterpret_cast<int*>(L + CTRL_PROG);
     int* F = reinterpret_cast<int*>(L + CTRL_F);
     if (tid < 16) prog[tid] = (tid < NCW) ? j_lo : MDE_RING_DONE;
+#if MDE_RING_FWORDS
+    static_assert(NPROD == 4 && MDE_RING_UNIT == 1, "MDE_RING_FWORDS: four producers, one chunk per step");
+    if (tid >= 16 && tid < 16 + NPROD) F[tid - 16] = (j_lo + (tid - 16) < j_hi) ? j_lo + (tid - 16) : MDE_RING_DONE;
+#else
     if (tid == 16) F[0] = j_lo;  // LANDED: every chunk below this is in its ring slot
+#endif
     if (CB && tid >= 32 && tid < 32 + MDE_RING_CB_VALUES)
       reinterpret_cast<float*>(L + CTRL_CB)[tid - 32] = a0[tid - 32] * Fn::kParamScale;
     if (BX && tid >= 64 && tid < 64 + MDE_RING_BX_VALUES)
@@ -397,6 +410,11 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
           // read ONE word (a v_readfirstlane) where they took a minimum over the producers' four.  The chunk below
           // belongs to the producer next door, which got its slot earlier: the wait is short.
           // (LANDED == j, once seen, holds until this wave publishes: the value read with the slot poll will do)
+#if MDE_RING_FWORDS
+          // my next chunk that has not landed (past the end of my chunks: DONE) -- nobody to wait for
+          (void)landed;
+          ring_ctrl_store_counted(L, CTRL_F + 4u * (uint32_t)p, (j + NPROD < j_hi) ? j + NPROD : MDE_RING_DONE);
+#else
           while (landed != j && !(dbg & 8)) {
             landed = __builtin_amdgcn_readfirstlane(ring_ctrl_load((uint32_t)CTRL_F + 0u * (uint32_t)lane));
 #if MDE_RING_ABLATE
@@ -405,6 +423,7 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
             if (landed != j) __builtin_amdgcn_s_sleep(0);
           }
           ring_ctrl_store_counted(L, CTRL_F, jl + 1);
+#endif
 #if MDE_RING_ABLATE
           if (dbg & 512) pr_write += RING_CLK() - td0;
 #endif
@@ -598,17 +617,36 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
       // old, i.e. merely conservative (F only grows); when they are not enough the wave polls as before.
       typedef __attribute__((address_space(3))) const volatile int* lds_cvint;
       const uint32_t f_addr = (uint32_t)CTRL_F + 0u * (uint32_t)lane;  // (a VGPR for the inline-asm poll)
+#if MDE_RING_FWORDS
+      typedef int ring_i4 __attribute__((ext_vector_type(4)));
+      typedef __attribute__((address_space(3))) const volatile ring_i4* lds_cvint4;
+      auto min4 = [](const ring_i4& v) __attribute__((always_inline)) { return min(min(v.x, v.y), min(v.z, v.w)); };
+      ring_i4 fl_pre = *(lds_cvint4)(L + CTRL_F);
+#else
       int fl_pre = *(lds_cvint)(L + CTRL_F);
+#endif
       auto wait_pair = [&](int u, int q) __attribute__((always_inline)) {
         const int need = __builtin_amdgcn_readlane((int)hv[u], 4 * q + 1);
         if (__builtin_expect(need >= ready && !(dbg & 1), 0)) {
+#if MDE_RING_FWORDS
+          ready = __builtin_amdgcn_readfirstlane(min4(fl_pre));
+#else
           ready = __builtin_amdgcn_readfirstlane(fl_pre);
+#endif
           if (__builtin_expect(need >= ready, 0)) {
 #if MDE_RING_ABLATE
             const unsigned long long tp0 = RING_CLK();
 #endif
             for (;;) {
+#if MDE_RING_FWORDS
+              {
+                ring_i4 fv;
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(fv) : "v"(f_addr) : "memory");
+                ready = __builtin_amdgcn_readfirstlane(min4(fv));
+              }
+#else
               ready = __builtin_amdgcn_readfirstlane(ring_ctrl_load(f_addr));
+#endif
 #if MDE_RING_ABLATE
               ++cs_trips;
               if (cs_trips > MDE_RING_SPINMAX) {
@@ -635,7 +673,11 @@ __global__ __launch_bounds__(MDE_RING_BS) void k_fused_ring(
         }
       };
       // (issued right behind a pair's operand reads and its release)
+#if MDE_RING_FWORDS
+      auto prefetch_landed = [&]() __attribute__((always_inline)) { fl_pre = *(lds_cvint4)(L + CTRL_F); };
+#else
       auto prefetch_landed = [&]() __attribute__((always_inline)) { fl_pre = *(lds_cvint)(L + CTRL_F); };
+#endif
       // (m never decreases along a stream; past its end the headers are copies of the last block and
       // the value published is merely too old)
       // (the lane that holds the header word stores it: no v_readlane / v_mov round trip through the scalar unit)
