@@ -723,6 +723,17 @@ static int launch_wide(FusedArgs& A, const Fn& fn) {
     if (d4 <= 4) return launch_wide4_gk<4, 1, IND, Fn>(A, fn);
     if (d4 <= 8) return launch_wide4_gk<8, 1, IND, Fn>(A, fn);
     if (d4 <= 16) return launch_wide4_gk<16, 1, IND, Fn>(A, fn);
+    // Round 6: FOUR float4s per lane where the row is wide enough -- 8 lanes cooperate on a 512-byte row instead of
+    // 32, a wave step takes 8 half-edges instead of 2 and the cross-lane sum of |x_v - x_u|^2 is 3 steps instead of 5:
+    // config 5 (d = 128, uniform graph) 3.13 -> 2.93 ms (6.5 -> 7.0 of the 7.4 TB/s random-row ceiling), neighbours within
+    // 1000 / 100 rows 2.36 -> 1.66 / 1.84 -> 1.20 ms (`profiles/r06_d128_locality.txt`).  MDE_WIDE_K4=1: one float4 per lane.
+    static const int k4 = getenv("MDE_WIDE_K4") ? atoi(getenv("MDE_WIDE_K4")) : 4;
+    if (k4 >= 4 && d4 > 8) {
+      if (d4 <= 16) return launch_wide4_gk<4, 4, IND, Fn>(A, fn);
+      if (d4 <= 32) return launch_wide4_gk<8, 4, IND, Fn>(A, fn);
+      if (d4 <= 64) return launch_wide4_gk<16, 4, IND, Fn>(A, fn);
+      if (d4 <= 128) return launch_wide4_gk<32, 4, IND, Fn>(A, fn);
+    }
     if (d4 <= 32) return launch_wide4_gk<32, 1, IND, Fn>(A, fn);
     if (d4 <= 64) return launch_wide4_gk<64, 1, IND, Fn>(A, fn);
     if (d4 <= 128) return launch_wide4_gk<64, 2, IND, Fn>(A, fn);

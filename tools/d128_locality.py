@@ -7,10 +7,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pymde_amd
 from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
 dev = torch.device("cuda", 0)
-n, deg, d = 500_000, 40, 128
+d = int(os.environ.get("LOC_D", "128"))
+n, deg = 500_000 * 128 // d if d > 128 else 500_000, 40
+n = min(n, 500_000)
 g = torch.Generator(device=dev); g.manual_seed(0)
 X = torch.randn(n, d, device=dev, generator=g)
 src = torch.arange(n, device=dev).repeat_interleave(deg)
+print("d =", d, "n =", n)
 for window in (0, 100_000, 10_000, 1_000, 100):
     if window == 0:
         dst = torch.randint(0, n - 1, (n * deg,), device=dev, generator=g); dst += (dst >= src).long()
