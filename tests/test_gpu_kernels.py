@@ -849,6 +849,40 @@ def test_ring_layout_peeled_and_dealt_rows_against_oracle(monkeypatch, d, mode):
         assert_grad_close(total[:n * d].view(n, d).cpu().numpy(), wgrad)
 
 
+def test_ring_layout_peeled_and_dealt_rows_on_a_dense_graph(monkeypatch):
+    """The same round-6 layouts on a DENSE graph (1300 half-edges per row on average: the layout builder orders the
+    entries by column first, and rebuilds its per-position slot array behind that sort): hub rows above 1500
+    half-edges peeled, blocks dealt by degree; Huber loss on a byte-index stream; against the oracle, bitwise twice."""
+    import pymde_amd
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    monkeypatch.setenv("MDE_PANEL", "1")
+    monkeypatch.setenv("MDE_RING_HUB", "1500")
+    monkeypatch.setenv("MDE_RING_PERMUTE", "1")
+    rng = np.random.default_rng(9)
+    n, p, d = 3000, 2_000_000, 2
+    i = np.minimum((n * rng.random(p) ** 1.5).astype(np.int64), n - 1)      # degrees fall along the vertex order
+    j = (i + 1 + rng.integers(0, n - 1, p)) % n
+    key = np.unique(np.minimum(i, j).astype(np.int64) * n + np.maximum(i, j))
+    edges = np.stack([key // n, key % n], 1)
+    p = len(edges)
+    dev_ = (1.0 + rng.integers(0, 30, p)).astype(np.float32)
+    X = (rng.standard_normal((n, d)) * 3).astype(np.float32)
+    f = pymde_amd.losses.Huber(torch.tensor(dev_, device=DEV), 1.0)
+    plan = EdgePlan(n, torch.tensor(edges, device=DEV))
+    b = Binding(plan, f)
+    Xd = torch.tensor(X, device=DEV)
+    buf = torch.zeros(n * d + 1, device=DEV)
+    fused_evaluate(b, Xd, buf[:n * d].view(n, d), buf[n * d:])
+    info = plan.ring_info()
+    assert b.struct(d).layout == 1 and info["permuted"] and info["hub_rows"] > 0, info
+    wE, wgrad = oracle.average_distortion(edges, X, oracle.func("L_HUBER", dev_, None, (1.0,)))
+    assert float(buf[n * d]) == pytest.approx(wE, rel=2e-5)
+    assert_grad_close(buf[:n * d].view(n, d).cpu().numpy(), wgrad)
+    buf2 = torch.zeros_like(buf)
+    fused_evaluate(b, Xd, buf2[:n * d].view(n, d), buf2[n * d:])
+    assert torch.equal(buf2, buf)
+
+
 @pytest.mark.parametrize("d", [2, 3])
 def test_ring_kernel_every_public_function(monkeypatch, d):
     """Every public penalty and loss has a compile-time functor on the ring kernel since round 5 (the units
