@@ -217,6 +217,18 @@ int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in
  * [10] row blocks PERMUTED (rows dealt to the blocks by degree; every entry adds f / 2), [11] hub rows PEELED off to
  * the CSR hub kernel, [12] their half-edges, [13] their segments, [14], [15] reserved (0). */
 int mde_plan_ring_info(const mde_plan* plan, int64_t* info_host);
+/* Processing order of the plan's rows for the general-d kernel (d = 128, 256, 512; round 6).  The reference evaluates
+ * the edges in the caller's order whatever the numbering of the items [ref: pymde/average_distortion.py:62-106]; here
+ * the rows of X gathered at the same time share the caches only when neighbours are close in the order the rows are
+ * evaluated in.  The call runs a breadth-first search over the plan's rows and sorts them by (level, row id); nothing
+ * is renumbered -- X, the gradient and the plan arrays keep the caller's numbering, results are identical with and
+ * without an order.  mode 1: keep the order when the mean distance between the positions of an edge's two ends at
+ * least halves; 2: keep it regardless; 0: drop it.  mde_average_distortion calls it with mode 1 on a plan's first
+ * evaluation at such a d (env MDE_ROW_ORDER=0 / 2 overrides).  info_host (may be NULL): 4 HOST doubles --
+ * [0] an order is in use, [1] mean |v - u| over the local half-edges in the caller's numbering, [2] the same in the
+ * order built (0: the search was abandoned -- a level held more than an eighth of the rows, or more than 256
+ * components), [3] breadth-first levels.  SYNC; one launch and one 4-byte read-back per level. */
+int mde_plan_row_order(mde_plan* plan, int32_t mode, void* stream, double* info_host);
 /* dst[0] (DEVICE double) <- the loss the plan's last mde_average_distortion wrote to loss_out, in double, before the
  * rounding to float.  A solve whose rows are sharded across ranks sums the ranks' shares in double and rounds once,
  * like the single-GPU kernel does (the reference's line search branches on the last bit of the loss).  ASYNC. */

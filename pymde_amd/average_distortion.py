@@ -130,6 +130,18 @@ class EdgePlan(object):
         out["built"], out["permuted"] = bool(out["built"]), bool(out["permuted"])
         return out
 
+    def row_order(self, mode=1):
+        """Build (mode 1: keep if it helps, 2: keep regardless) or drop (0) the breadth-first processing order of the
+        rows that the general-d kernel walks (``mde_plan_row_order``); returns a dict with ``in_use``, the mean distance
+        between the positions of an edge's two ends before and after, and the number of levels.  Evaluations at
+        d = 128 / 256 / 512 call it with mode 1 by themselves; results never depend on it."""
+        lib = _lib.load()
+        info = (ctypes.c_double * 4)()
+        with torch.cuda.device(self.device):
+            _lib.check(lib.mde_plan_row_order(self._handle, int(mode), _lib.stream_ptr(self.device), info))
+        return {"in_use": bool(info[0]), "mean_distance_before": float(info[1]),
+                "mean_distance_after": float(info[2]), "levels": int(info[3])}
+
     def csr(self):
         """(rowptr, nbr, eid) as int32 tensors (copies; for tests and debugging)."""
         lib = _lib.load()

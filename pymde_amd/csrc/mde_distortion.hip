@@ -564,6 +564,270 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4(
   if (threadIdx.x == 0) loss_partials[blockIdx.x] = bs;
 }
 
+// ---------------------------------------------------------------- general-d fused kernel, pipelined form (round 6)
+// Rows of exactly GL x 4 float4s (d = 128 / 256 / 512 with GL = 8 / 16 / 32).  Same lane layout as k_fused_wide4<GL, 4>
+// (GL lanes share a half-edge, 64 / GL half-edges per wave step); what changes is everything around the arithmetic:
+//  * the row gathers of step s + 1 are in flight while step s is evaluated (two register buffers, the loop unrolled
+//    by two; the meta words -- neighbour id, parameters -- run two steps ahead, the next row's first meta words and
+//    row pointers a whole row ahead): a wave never sits behind its own loads with nothing issued;
+//  * |x_v - x_u|^2 with packed fp32 math (v_pk_add_f32 / v_pk_fma_f32: 16 instructions instead of 32), the sum over
+//    the lanes of a group with DPP adds instead of LDS permutes;
+//  * the E partial gradient rows of a wave are added by a TRANSPOSING reduction (v_permlane32_swap / v_permlane16_swap:
+//    one swap + one add folds two registers into one whose halves hold the two sums): 12 swaps + 16 adds for the 16
+//    floats of a lane instead of 48 LDS permutes + 48 adds, and every lane ends up owning one float4 of the row;
+//  * XCD-aware row order: the rows are cut into chunks of 2^chunk_log rows, chunk c belongs to XCD c % 8 (block b runs
+//    on XCD b % 8), and the waves of an XCD walk ITS chunks in order -- the rows an XCD works on at any moment are a
+//    band of ~1000 consecutive rows, so on a graph with locality (neighbours within a window of the vertex order)
+//    the band's neighbours stay in that XCD's 4 MB L2 instead of being fetched by all eight.
+// Summation order inside a row: fixed by the row's own half-edge positions (steps of E from the row's first entry),
+// so a vertex-range shard produces the bits of the single process.
+typedef float wide_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned wide_u2 __attribute__((ext_vector_type(2)));
+template <int GL>
+__device__ __forceinline__ float wide_group_sum(float v) {
+  static_assert(GL == 8 || GL == 16 || GL == 32, "group widths of the pipelined kernel");
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  if constexpr (GL >= 16) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
+  if constexpr (GL >= 32) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+// a <- the xor-32 sums of a in lanes 0..31 and of b in lanes 32..63
+__device__ __forceinline__ float wide_fold32(float a, float b) {
+  const wide_u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+// a <- the xor-16 sums of a in rows 0, 2 and of b in rows 1, 3 (rows of 16 lanes)
+__device__ __forceinline__ float wide_fold16(float a, float b) {
+  const wide_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+template <int GL, bool INDIRECT, class Fn>
+__global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
+    int nrows, int row_lo, int chunk_log, const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ nbr,
+    const int32_t* __restrict__ eid, const float* __restrict__ a0, const float* __restrict__ a1, int a0_scalar,
+    int a1_scalar, const wide_f4* __restrict__ X4, wide_f4* __restrict__ grad4, double* __restrict__ loss_partials,
+    Fn fn, float inv_p, float grad_scale) {
+  __shared__ double smem[8];
+  constexpr int E = 64 / GL;   // half-edges per wave step
+  constexpr int d4 = GL * 4;   // float4s per row
+  constexpr int WPB = MDE_BLOCK / 64;
+  const int lane = threadIdx.x & 63;
+  const int lig = lane & (GL - 1);
+  const int sub = lane / GL;
+  const int xcd = blockIdx.x & 7;
+  const int wpx = (gridDim.x >> 3) * WPB;  // waves per XCD (the grid is a multiple of 8 blocks)
+  const int cmask = (1 << chunk_log) - 1;
+  float loss = 0.0f;
+  const float a0s = a0_scalar ? a0[0] : 0.0f;
+  const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
+
+  // position of the i-th row of this XCD's sequence in the processing order, or -1 behind the end; the row at a
+  // position is order[position] when the plan carries a processing order (mde_plan_row_order), the position itself
+  // otherwise
+  auto pos_of = [&](int i) __attribute__((always_inline)) -> int {
+    const int q = ((((i >> chunk_log) << 3) + xcd) << chunk_log) + (i & cmask);
+    return q < nrows ? q : -1;
+  };
+  auto row_at = [&](int q) __attribute__((always_inline)) -> int {
+    return (q >= 0 && order) ? order[q] : q;
+  };
+  auto row_of = [&](int i) __attribute__((always_inline)) -> int { return row_at(pos_of(i)); };
+  struct Meta {
+    int u;
+    float p0, p1;
+  };
+  auto load_meta = [&](int h, int end) __attribute__((always_inline)) -> Meta {
+    Meta m;
+    int hh = h < end ? h : end - 1;
+    hh = hh < 0 ? 0 : hh;
+    m.u = nbr[hh];
+    m.p1 = a1s;
+    if constexpr (INDIRECT) {
+      const int k = eid[hh];
+      m.p0 = a0[k];
+      m.p1 = a1[k];
+    } else {
+      m.p0 = a0_scalar ? a0s : a0[hh];
+      if (a1 && !a1_scalar) m.p1 = a1[hh];
+    }
+    return m;
+  };
+  auto load_rows = [&](wide_f4 (&x)[4], int64_t u) __attribute__((always_inline)) {
+    const wide_f4* p = X4 + u * d4 + lig;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = p[j * GL];
+  };
+
+  int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * WPB + (int)(threadIdx.x >> 6));
+  int r = row_of(i);
+  int beg = 0, end = 0, r_n = -1, beg_n = 0, end_n = 0, r_nn = -1, beg_nn = 0, end_nn = 0, r_n3 = -1;
+  Meta mA = {0, 0.f, 0.f}, mB = mA, m0n = mA, m1n = mA;
+  wide_f4 xv[4], bufA[4], bufB[4];
+  if (r >= 0) {
+    beg = rowptr[r];
+    end = rowptr[r + 1];
+    mA = load_meta(beg + sub, end);
+    mB = load_meta(beg + E + sub, end);
+    r_n = row_of(i + wpx);
+    if (r_n >= 0) {
+      beg_n = rowptr[r_n];
+      end_n = rowptr[r_n + 1];
+      m0n = load_meta(beg_n + sub, end_n);
+      m1n = load_meta(beg_n + E + sub, end_n);
+      r_nn = row_of(i + 2 * wpx);
+      if (r_nn >= 0) {
+        beg_nn = rowptr[r_nn];
+        end_nn = rowptr[r_nn + 1];
+        r_n3 = row_of(i + 3 * wpx);
+      }
+    }
+    load_rows(xv, (int64_t)row_lo + r);
+    load_rows(bufA, mA.u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xv[j] = -xv[j];
+      asm volatile("" : "+v"(xv[j]));
+    }
+  }
+  // The wave's rows form ONE software pipeline: at the top of a row bufA already holds (or is about to receive) the
+  // gathers of the row's first step -- issued by the previous row's last step --, its first two meta words are in
+  // registers, and so are the row pointers and the first two meta words of the row after it and the row pointers of
+  // the row after that.
+  while (r >= 0) {
+    const int64_t v = (int64_t)row_lo + r;
+    // (an empty row runs one step with every lane dead -- clamped positions, nothing added: no special case for the
+    // compiler's load bookkeeping to be conservative about)
+    const int nsteps = end > beg ? (end - beg + E - 1) / E : 1;
+    // three rows ahead: the row pointers; four rows ahead: which row that is (scalar loads; they are back by the
+    // time the row's end rotates them in)
+    i += wpx;
+    int beg_n3 = 0, end_n3 = 0;
+    if (r_n3 >= 0) {
+      beg_n3 = rowptr[r_n3];
+      end_n3 = rowptr[r_n3 + 1];
+    }
+    const int r_n4 = r_n3 >= 0 ? row_of(i + 3 * wpx) : -1;
+    // the next row's x_v, a row ahead like everything else of it; the first two meta words of the row after next
+    // (loaded here, not at the row's end: the copy into the registers the next trip reads would otherwise wait for
+    // loads that have only just gone out; behind the last row beg_nn = end_nn = 0: position 0)
+    wide_f4 xvn[4];
+    load_rows(xvn, (int64_t)row_lo + (r_n >= 0 ? r_n : r));
+    const Meta m0nn = load_meta(beg_nn + sub, end_nn);
+    const Meta m1nn = load_meta(beg_nn + E + sub, end_nn);
+    wide_f2 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = wide_f2{0.f, 0.f};
+
+    // one step: x holds the gathered rows of E half-edges (one per group of GL lanes).
+    // (xv holds -x_v: dd = x_u - x_v is then a packed ADD -- hipcc has no packed form for a subtraction of two
+    // register pairs --, the accumulators collect -g (x_v - x_u) and the sign goes into the scale of the final
+    // store: negation is exact, every intermediate is the negative of the plain form's, bit for bit)
+    auto step = [&](wide_f4 (&x)[4], const Meta& m, bool live) __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+      wide_f2 dd[8], s2 = {0.f, 0.f}, t2 = {0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dd[2 * j] = wide_f2{xv[j].x, xv[j].y} + wide_f2{x[j].x, x[j].y};
+        dd[2 * j + 1] = wide_f2{xv[j].z, xv[j].w} + wide_f2{x[j].z, x[j].w};
+        s2 = dd[2 * j] * dd[2 * j] + s2;
+        t2 = dd[2 * j + 1] * dd[2 * j + 1] + t2;
+      }
+      s2 += t2;
+      const float ss = wide_group_sum<GL>(s2.x + s2.y);
+      float f, gd;
+      fn.eval(ss, m.p0, m.p1, f, gd);
+      float g = mde_fix_g(gd * inv_p);
+      if (!live) {
+        g = 0.0f;
+        f = 0.0f;
+      }
+      if (lig == 0) loss += f;
+      const wide_f2 g2 = {g, g};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = g2 * dd[j] + acc[j];
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    int h = beg;
+    int k = 0;
+    do {
+      // (every load below is issued on every trip -- clamped positions behind the row's end --: a branch around a
+      // gather makes the compiler's vmcnt bookkeeping wait for EVERYTHING at the next use.  Meta words go out before
+      // the gathers that follow them: vmcnt counts in order -- both of a trip's at its top, so that the rotation at
+      // its bottom finds them behind gathers that step B has already waited for.)
+      const Meta mC = load_meta(h + 2 * E + sub, end);
+      const Meta mD = load_meta(h + 3 * E + sub, end);
+      load_rows(bufB, mB.u);
+      step(bufA, mA, h + sub < end);
+      const bool last = k + 2 >= nsteps;
+      load_rows(bufA, last ? m0n.u : mC.u);   // behind the row's last step: the NEXT row's first gathers
+      if (k + 1 < nsteps) step(bufB, mB, h + E + sub < end);
+      mA = mC;
+      mB = mD;
+      h += 2 * E;
+      k += 2;
+    } while (k < nsteps);
+    mA = m0n;
+    mB = m1n;
+    m0n = m0nn;
+    m1n = m1nn;
+    if (grad4) {
+      // transposing reduction over the E groups of the wave (lanes with equal lig)
+      const float gsc = -grad_scale;
+      float e[16];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        e[2 * j] = acc[j].x;
+        e[2 * j + 1] = acc[j].y;
+      }
+      // xor 32: element k with k + 8 -> lanes < 32 keep k, lanes >= 32 keep k + 8
+      float e8[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e8[k] = wide_fold32(e[k], e[k + 8]);
+      if constexpr (GL == 32) {
+        // lane (b5, lig): float4s 2 b5 and 2 b5 + 1 of the row
+        const int j0 = (lane >> 5) * 2;
+        grad4[v * d4 + lig + j0 * GL] = wide_f4{e8[0], e8[1], e8[2], e8[3]} * gsc;
+        grad4[v * d4 + lig + (j0 + 1) * GL] = wide_f4{e8[4], e8[5], e8[6], e8[7]} * gsc;
+      } else {
+        // xor 16: element k with k + 4 -> rows 0, 2 keep k, rows 1, 3 keep k + 4
+        float e4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e4[k] = wide_fold16(e8[k], e8[k + 4]);
+        if constexpr (GL == 8) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            e4[k] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e4[k]), 0x128, 0xF, 0xF, true));  // row_ror:8
+        }
+        // lane (b5, b4, .): float4 number b4 + 2 b5 of the row; at GL = 8 the lanes with bit 3 set hold a copy
+        const int j = (lane >> 4) & 3;
+        if (GL == 16 || (lane & 8) == 0) grad4[v * d4 + lig + j * GL] = wide_f4{e4[0], e4[1], e4[2], e4[3]} * gsc;
+      }
+    }
+    // xv <- -x_v of the next row (see step()); the asm keeps hipcc from folding the sign back into a subtraction
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xv[j] = -xvn[j];
+      asm volatile("" : "+v"(xv[j]));
+    }
+    r = r_n;
+    beg = beg_n;
+    end = end_n;
+    r_n = r_nn;
+    beg_n = beg_nn;
+    end_n = end_nn;
+    r_nn = r_n3;
+    beg_nn = beg_n3;
+    end_nn = end_n3;
+    r_n3 = r_n4;
+  }
+  const double bs = mde_block_sum((double)loss, smem);
+  if (threadIdx.x == 0) loss_partials[blockIdx.x] = bs;
+}
+
 // loss = scale * sum(partials[0..nb)) in a fixed order (one block)
 __global__ void k_finalize_loss(double* __restrict__ partials, int nb, double scale,
                                 float* __restrict__ loss_out) {
@@ -714,11 +978,43 @@ static int launch_wide4_gk(FusedArgs& A, const Fn& fn) {
   MDE_LAUNCH_CHECK();
   return MDE_OK;
 }
+template <int GL, bool IND, class Fn>
+static int launch_wide4p(FusedArgs& A, const Fn& fn) {
+  const mde_plan* P = A.plan;
+  const int nrows = (int)(mde_plan_row_hi(P) - mde_plan_row_lo(P));
+  int nb = mde_grid((int64_t)nrows * 64, MDE_BLOCK, 2048);
+  nb = (nb + 7) & ~7;  // (the row order is per XCD: block b runs on XCD b % 8)
+  A.nblocks = nb;
+  // chunks of up to 2048 rows, at least 64 chunks (8 per XCD) so that short row ranges still fill every XCD
+  const int chunk_env = getenv("MDE_WIDE_CHUNK") ? atoi(getenv("MDE_WIDE_CHUNK")) : 11;  // (read per call: tests switch it)
+  int chunk_log = chunk_env;
+  while (chunk_log > 0 && ((int64_t)64 << chunk_log) > nrows) --chunk_log;
+  // graphs whose locality is hidden by the vertex numbering: a breadth-first processing order, built once per plan
+  // and kept only when it brings the endpoints of an edge closer together (mde_plan.hip: mde_plan_row_order)
+  const int order_env = getenv("MDE_ROW_ORDER") ? atoi(getenv("MDE_ROW_ORDER")) : 1;
+  if (order_env && P->order_state == 0) {
+    const int rc = mde_plan_row_order(const_cast<mde_plan*>(P), order_env, A.st, nullptr);
+    if (rc != MDE_OK) return rc;
+  }
+  hipLaunchKernelGGL((k_fused_wide4p<GL, IND, Fn>), dim3(nb), dim3(MDE_BLOCK), 0, A.st, nrows,
+                     (int)mde_plan_row_lo(P), chunk_log, P->order, mde_plan_rowptr(P), mde_plan_nbr(P), mde_plan_eid(P),
+                     A.a0, A.a1, A.a0_scalar, A.a1_scalar, reinterpret_cast<const wide_f4*>(A.X),
+                     reinterpret_cast<wide_f4*>(A.grad), A.partials, fn, A.inv_p, A.grad_scale);
+  MDE_LAUNCH_CHECK();
+  return MDE_OK;
+}
 template <bool IND, class Fn>
 static int launch_wide(FusedArgs& A, const Fn& fn) {
   const int d = A.d;
   if ((d & 3) == 0 && ((reinterpret_cast<uintptr_t>(A.X) | reinterpret_cast<uintptr_t>(A.grad)) & 15) == 0) {
     const int d4 = d >> 2;
+    // Round 6: rows of exactly 8 / 16 / 32 x 4 float4s (d = 128, 256, 512) take the pipelined kernel (MDE_WIDE_P=0: off)
+    const int wide_p = getenv("MDE_WIDE_P") ? atoi(getenv("MDE_WIDE_P")) : 1;
+    if (wide_p) {
+      if (d4 == 32) return launch_wide4p<8, IND, Fn>(A, fn);
+      if (d4 == 64) return launch_wide4p<16, IND, Fn>(A, fn);
+      if (d4 == 128) return launch_wide4p<32, IND, Fn>(A, fn);
+    }
     if (d4 <= 2) return launch_wide4_gk<2, 1, IND, Fn>(A, fn);
     if (d4 <= 4) return launch_wide4_gk<4, 1, IND, Fn>(A, fn);
     if (d4 <= 8) return launch_wide4_gk<8, 1, IND, Fn>(A, fn);

@@ -56,6 +56,14 @@ struct mde_plan {
   float* flat_rec = nullptr;   // [n_tiles][2][8] boundary runs of a tile: row, ends?, sum[<= 4]
   int64_t n_tiles = 0;
   int has_empty = 0;           // some row has no half-edge (its gradient row is zero-filled)
+  // Processing order of the rows for the general-d kernel (round 6, mde_plan_row_order): order[q] = local row
+  // evaluated q-th.  Rows sorted by breadth-first level (ties by row id), kept only when it brings the two ends of
+  // an edge closer together than the caller's numbering does.  Results do not depend on it (a row's sum is the
+  // row's own business); which rows are in the caches at the same time does.
+  int32_t* order = nullptr;
+  int order_state = 0;         // 0 not tried, 1 adopted, -1 tried and rejected
+  double order_before = 0.0, order_after = 0.0;  // mean |position(v) - position(u)| over the local half-edges
+  int order_levels = 0;
 };
 
 #define MDE_FLAT_U 4                    // wave iterations per tile

@@ -69,6 +69,7 @@ extern "C" int mde_plan_destroy(mde_plan* plan) {
   if (plan->partials) (void)hipFree(plan->partials);
   if (plan->hrow) (void)hipFree(plan->hrow);
   if (plan->flat_rec) (void)hipFree(plan->flat_rec);
+  if (plan->order) (void)hipFree(plan->order);
   mde_ring_release(plan);
   delete plan;
   return MDE_OK;
@@ -373,6 +374,261 @@ extern "C" int mde_plan_create(int64_t n, int64_t p, const int64_t* edges, int64
   cleanup();
 #undef PLAN_HIP
   *out = plan;
+  return MDE_OK;
+}
+
+// ---------------------------------------------------------------- processing order of the rows (round 6)
+// The general-d kernel (mde_distortion.hip: k_fused_wide4p) gathers a 512-byte row of X per half-edge at d = 128; what
+// it costs depends on where those rows come from.  When the caller's vertex numbering hides the graph's locality (a
+// k-NN graph whose items arrive in arbitrary order), the rows a chip works on at the same moment reference neighbours
+// all over the table and every gather goes to HBM.  mde_plan_row_order builds a PROCESSING order instead of moving any
+// data: a breadth-first search over the local rows (components one after the other, from the lowest unvisited row),
+// rows sorted by (level, row id) -- the neighbours of a row then sit in its own level or the two next to it, so the
+// rows evaluated together share their neighbours through L2 / Infinity Cache.  The CSR arrays, X and the gradient
+// keep the caller's numbering; the kernel only asks "which row is q-th".  Kept when the mean distance between the
+// positions of an edge's two ends at least halves (mode 1), always (mode 2).
+//
+// One launch + one 4-byte read-back per level (a band graph of 500k rows and window 100 has ~5000 levels: ~0.1 s, once
+// per plan); abandoned when a level holds more than an eighth of the rows (the graph expands like a random one: no
+// order helps), after 256 components or 20000 levels (~0.5 s).
+#define MDE_ORDER_UNSEEN (-1)
+#define MDE_ORDER_ISOLATED 0x7ffffff0
+__global__ void k_order_init(int32_t nloc, const int32_t* __restrict__ rowptr, int32_t* __restrict__ level,
+                             uint32_t* __restrict__ iota) {
+  for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < nloc; r += (int64_t)gridDim.x * blockDim.x) {
+    level[r] = rowptr[r] == rowptr[r + 1] ? MDE_ORDER_ISOLATED : MDE_ORDER_UNSEEN;
+    iota[r] = (uint32_t)r;
+  }
+}
+// state[0] = cursor (every row below it has been seen), state[1] = the row found or -1; that row gets `lvl`
+__global__ void k_order_next(int32_t nloc, int32_t* __restrict__ level, int32_t lvl, int32_t* __restrict__ state,
+                             int32_t* __restrict__ frontier) {
+  __shared__ int found;
+  int32_t c = state[0];
+  for (;;) {
+    if (threadIdx.x == 0) found = 0x7fffffff;
+    __syncthreads();
+    const int32_t r = c + (int32_t)threadIdx.x;
+    if (r < nloc && level[r] == MDE_ORDER_UNSEEN) atomicMin(&found, r);
+    __syncthreads();
+    const int f = found;
+    __syncthreads();
+    if (f != 0x7fffffff) {
+      if (threadIdx.x == 0) {
+        level[f] = lvl;
+        frontier[0] = f;
+        state[0] = f + 1;
+        state[1] = f;
+      }
+      return;
+    }
+    c += (int32_t)blockDim.x;
+    if (c >= nloc) {
+      if (threadIdx.x == 0) {
+        state[0] = nloc;
+        state[1] = -1;
+      }
+      return;
+    }
+  }
+}
+// one wave per frontier row: unseen local neighbours get `next_level` and join the next frontier
+__global__ __launch_bounds__(MDE_BLOCK) void k_order_expand(int32_t m, const int32_t* __restrict__ frontier,
+                                                            int32_t next_level, const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ nbr, int64_t row_lo, int32_t nloc,
+                                                            int32_t* __restrict__ level, int32_t* __restrict__ out,
+                                                            int32_t* __restrict__ count) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * MDE_BLOCK) >> 6;
+  for (int64_t w = w0; w < m; w += nw) {
+    const int32_t v = frontier[w];
+    const int32_t beg = rowptr[v], end = rowptr[v + 1];
+    for (int32_t h0 = beg; h0 < end; h0 += 64) {
+      const int32_t h = h0 + lane;
+      bool won = false;
+      int32_t u = 0;
+      if (h < end) {
+        const int64_t ug = (int64_t)nbr[h] - row_lo;
+        if (ug >= 0 && ug < nloc) {
+          u = (int32_t)ug;
+          if (level[u] == MDE_ORDER_UNSEEN) won = atomicCAS(&level[u], MDE_ORDER_UNSEEN, next_level) == MDE_ORDER_UNSEEN;
+        }
+      }
+      const unsigned long long mask = __ballot(won);
+      if (mask) {
+        int32_t base = 0;
+        if (lane == 0) base = atomicAdd(count, (int32_t)__popcll(mask));
+        base = __shfl(base, 0, 64);
+        if (won) out[base + (int32_t)__popcll(mask & ((1ull << lane) - 1ull))] = u;
+      }
+    }
+  }
+}
+__global__ void k_order_rank(int32_t nloc, const uint32_t* __restrict__ order, int32_t* __restrict__ rank) {
+  for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < nloc; q += (int64_t)gridDim.x * blockDim.x)
+    rank[order[q]] = (int32_t)q;
+}
+// sums[0] += sum |v - u|, sums[1] += sum |rank[v] - rank[u]| over the half-edges with both ends local (exact: integers)
+__global__ __launch_bounds__(MDE_BLOCK) void k_order_metric(int32_t nloc, int64_t row_lo, const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ nbr, const int32_t* __restrict__ rank,
+                                                            unsigned long long* __restrict__ sums) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w0 = ((int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * MDE_BLOCK) >> 6;
+  unsigned long long a = 0, b = 0, c = 0;
+  for (int64_t v = w0; v < nloc; v += nw) {
+    const int32_t beg = rowptr[v], end = rowptr[v + 1];
+    const int32_t rv = rank ? rank[v] : 0;
+    for (int32_t h = beg + lane; h < end; h += 64) {
+      const int64_t u = (int64_t)nbr[h] - row_lo;
+      if (u >= 0 && u < nloc) {
+        a += (unsigned long long)(u > v ? u - v : v - u);
+        if (rank) {
+          const int32_t ru = rank[u];
+          b += (unsigned long long)(ru > rv ? ru - rv : rv - ru);
+        }
+        c += 1;
+      }
+    }
+  }
+  a = mde_wave_sum(a);
+  b = mde_wave_sum(b);
+  c = mde_wave_sum(c);
+  if (lane == 0 && c) {
+    atomicAdd(&sums[0], a);
+    atomicAdd(&sums[1], b);
+    atomicAdd(&sums[2], c);
+  }
+}
+
+extern "C" int mde_plan_row_order(mde_plan* plan, int32_t mode, void* stream, double* info_host) {
+  if (!plan) return MDE_E_INVALID;
+  hipStream_t st = mde_stream(stream);
+  auto report = [&]() {
+    if (info_host) {
+      info_host[0] = plan->order_state == 1 ? 1.0 : 0.0;
+      info_host[1] = plan->order_before;
+      info_host[2] = plan->order_after;
+      info_host[3] = (double)plan->order_levels;
+    }
+  };
+  if (mode == 0) {
+    if (plan->order) {
+      MDE_HIP(hipStreamSynchronize(st));
+      (void)hipFree(plan->order);
+      plan->order = nullptr;
+    }
+    plan->order_state = -1;
+    report();
+    return MDE_OK;
+  }
+  if (plan->order_state != 0) {
+    report();
+    return MDE_OK;
+  }
+  plan->order_state = -1;
+  const int64_t nloc64 = plan->row_hi - plan->row_lo;
+  // (a table of a few thousand rows sits in every L2 whatever the order)
+  if (nloc64 < 8192 || plan->H <= 0) {
+    report();
+    return MDE_OK;
+  }
+  const int32_t nloc = (int32_t)nloc64;
+  int32_t *level = nullptr, *fa = nullptr, *fb = nullptr, *state = nullptr, *rank = nullptr;
+  uint32_t *iota = nullptr, *keys2 = nullptr, *ord = nullptr;
+  unsigned long long* sums = nullptr;
+  void* tmp = nullptr;
+  auto cleanup = [&]() {
+    for (void* q : {(void*)level, (void*)fa, (void*)fb, (void*)state, (void*)rank, (void*)iota, (void*)keys2, (void*)sums, tmp})
+      if (q) (void)hipFree(q);
+  };
+#define ORD_HIP(call)                                             \
+  do {                                                            \
+    hipError_t e__ = (call);                                      \
+    if (e__ != hipSuccess) {                                      \
+      cleanup();                                                  \
+      if (ord) (void)hipFree(ord);                                \
+      return mde_hip_fail(e__, #call, __FILE__, __LINE__);        \
+    }                                                             \
+  } while (0)
+  const size_t nb4 = (size_t)nloc * sizeof(int32_t);
+  ORD_HIP(hipMalloc(&level, nb4));
+  ORD_HIP(hipMalloc(&fa, nb4));
+  ORD_HIP(hipMalloc(&fb, nb4));
+  ORD_HIP(hipMalloc(&iota, nb4));
+  ORD_HIP(hipMalloc(&state, 4 * sizeof(int32_t)));
+  ORD_HIP(hipMalloc(&sums, 4 * sizeof(unsigned long long)));
+  ORD_HIP(hipMemsetAsync(state, 0, 4 * sizeof(int32_t), st));
+  ORD_HIP(hipMemsetAsync(sums, 0, 4 * sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_order_init, dim3(mde_grid(nloc, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, nloc, plan->rowptr, level, iota);
+  ORD_HIP(hipGetLastError());
+  int32_t lvl = 0, components = 0, hstate[4] = {0, 0, 0, 0};
+  bool abandoned = false;
+  int64_t launches = 0;
+  for (;;) {
+    // the lowest row nobody has seen starts the next component
+    hipLaunchKernelGGL(k_order_next, dim3(1), dim3(1024), 0, st, nloc, level, lvl, state, fa);
+    ORD_HIP(hipGetLastError());
+    ORD_HIP(hipMemcpyAsync(hstate, state, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    ORD_HIP(hipStreamSynchronize(st));
+    if (hstate[1] < 0) break;
+    if (++components > 256) {
+      abandoned = true;
+      break;
+    }
+    int32_t m = 1;
+    int32_t *cur = fa, *nxt = fb;
+    while (m > 0) {
+      ORD_HIP(hipMemsetAsync(state + 2, 0, sizeof(int32_t), st));
+      hipLaunchKernelGGL(k_order_expand, dim3(mde_grid((int64_t)m * 64, MDE_BLOCK, 2048)), dim3(MDE_BLOCK), 0, st, m, cur,
+                         lvl + 1, plan->rowptr, plan->nbr, plan->row_lo, nloc, level, nxt, state + 2);
+      ORD_HIP(hipGetLastError());
+      ORD_HIP(hipMemcpyAsync(&m, state + 2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      ORD_HIP(hipStreamSynchronize(st));
+      ++lvl;
+      if (m > nloc / 8 || ++launches > 20000) {
+        abandoned = true;
+        break;
+      }
+      int32_t* t = cur;
+      cur = nxt;
+      nxt = t;
+    }
+    if (abandoned) break;
+    // (lvl is now one past the component's last level: the next component starts there, in fa[0] again)
+  }
+  plan->order_levels = lvl;
+  if (!abandoned) {
+    // order = rows sorted by (level, row id): a stable sort of the levels with the row ids as values
+    size_t tmp_bytes = 0;
+    ORD_HIP(hipMalloc(&keys2, nb4));
+    ORD_HIP(hipMalloc(&ord, nb4));
+    ORD_HIP(hipMalloc(&rank, nb4));
+    ORD_HIP(mde_sort_pairs_u32(nullptr, tmp_bytes, reinterpret_cast<uint32_t*>(level), keys2, iota, ord, nloc, 0, 31, st));
+    ORD_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16));
+    ORD_HIP(mde_sort_pairs_u32(tmp, tmp_bytes, reinterpret_cast<uint32_t*>(level), keys2, iota, ord, nloc, 0, 31, st));
+    hipLaunchKernelGGL(k_order_rank, dim3(mde_grid(nloc, MDE_BLOCK)), dim3(MDE_BLOCK), 0, st, nloc, ord, rank);
+    ORD_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_order_metric, dim3(mde_grid((int64_t)nloc * 64, MDE_BLOCK, 2048)), dim3(MDE_BLOCK), 0, st, nloc,
+                     plan->row_lo, plan->rowptr, plan->nbr, rank, sums);
+  ORD_HIP(hipGetLastError());
+  unsigned long long hs[4] = {0, 0, 0, 0};
+  ORD_HIP(hipMemcpyAsync(hs, sums, sizeof(hs), hipMemcpyDeviceToHost, st));
+  ORD_HIP(hipStreamSynchronize(st));
+  const double cnt = hs[2] ? (double)hs[2] : 1.0;
+  plan->order_before = (double)hs[0] / cnt;
+  plan->order_after = abandoned ? 0.0 : (double)hs[1] / cnt;
+  if (!abandoned && (mode >= 2 || plan->order_after <= 0.5 * plan->order_before)) {
+    plan->order = reinterpret_cast<int32_t*>(ord);
+    plan->order_state = 1;
+    ord = nullptr;
+  }
+  cleanup();
+  if (ord) (void)hipFree(ord);
+#undef ORD_HIP
+  report();
   return MDE_OK;
 }
 

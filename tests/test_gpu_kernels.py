@@ -1050,3 +1050,110 @@ np.save(sys.argv[1], np.concatenate([Xt.grad.cpu().numpy().ravel(), [float(E)]])
     wE, wgrad = oracle.average_distortion(e, X, oracle.func("LOG1P", w, None, (1.5,)))
     assert outs["default"][-1] == pytest.approx(wE, rel=1e-5)
     assert_grad_close(outs["default"][:-1].reshape(n, d), wgrad)
+
+
+# ---------------------------------------------------------------- general-d kernel, pipelined form + processing order (round 6)
+def _band_graph(rng, n, deg, window, shuffle):
+    src = np.repeat(np.arange(n), deg)
+    dst = (src + rng.integers(1, window + 1, n * deg)) % n
+    e = np.stack([np.minimum(src, dst), np.maximum(src, dst)], 1)
+    e = np.unique(e, axis=0)
+    if shuffle:
+        perm = rng.permutation(n)
+        e = perm[e]
+        e = np.stack([e.min(1), e.max(1)], 1)
+    return e
+
+
+@pytest.mark.parametrize("d", [128, 256, 512])
+def test_pipelined_wide_kernel_on_ragged_graphs(d, monkeypatch):
+    """k_fused_wide4p (rows of exactly 8 / 16 / 32 x 4 float4s): empty rows, rows of one to three half-edges, a hub,
+    odd and even step counts -- against the oracle, against the unpipelined kernel (MDE_WIDE_P=0), three runs bitwise."""
+    import pymde_amd
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    rng = np.random.default_rng(d)
+    n, p = 6007, 90000
+    i = rng.integers(0, n, p)
+    j = rng.integers(0, n, p)
+    i[: p // 10] = 3                                   # a hub
+    keep = (i != j) & (i % 7 != 5) & (j % 7 != 5)      # a seventh of the rows is empty
+    e = np.unique(np.stack([np.minimum(i, j), np.maximum(i, j)], 1)[keep], axis=0)
+    pp = e.shape[0]
+    X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    w = rng.uniform(0.5, 2.0, pp).astype(np.float32)
+    fd = oracle.func("LOG1P", w, None, (1.5,))
+    wE, wgrad = oracle.average_distortion(e, X, fd)
+    et = torch.tensor(e, device=DEV)
+    Xt = torch.tensor(X, device=DEV)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MDE_WIDE_P", mode)
+        b = Binding(EdgePlan(n, et), pymde_amd.penalties.Log1p(torch.tensor(w, device=DEV)))
+        runs = []
+        for _ in range(3):
+            buf = torch.zeros(n * d + 1, device=DEV)
+            fused_evaluate(b, Xt, buf[:n * d].view(n, d), buf[n * d:])
+            runs.append(buf)
+        assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2])
+        g = runs[0][:n * d].view(n, d).cpu().numpy()
+        assert float(runs[0][n * d]) == pytest.approx(wE, rel=LOSS_RTOL)
+        assert_grad_close(g, wgrad)
+        assert np.all(g[np.arange(n) % 7 == 5] == 0.0)
+        outs[mode] = g
+    # the two kernels add a row's half-edges in different groupings: equal to rounding, not bit for bit
+    assert_grad_close(outs["1"], outs["0"])
+
+
+@pytest.mark.parametrize("window,shuffle", [(60, True), (60, False), (0, True)])
+def test_row_processing_order(window, shuffle, monkeypatch):
+    """mde_plan_row_order: on a band graph under a random renumbering the breadth-first order is adopted and brings
+    the ends of an edge together; on the same graph as given, and on a random graph, it is not.  Whatever it does, the
+    gradient is the gradient BIT FOR BIT (a row's sum does not depend on when the row is evaluated), and forcing an
+    order (mode 2) on a vertex-range shard gives the single plan's rows."""
+    import pymde_amd
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    rng = np.random.default_rng(7)
+    n, d, deg = 30011, 128, 12
+    if window:
+        e = _band_graph(rng, n, deg, window, shuffle)
+    else:
+        i = rng.integers(0, n, n * deg)
+        j = (i + 1 + rng.integers(0, n - 1, n * deg)) % n
+        e = np.unique(np.stack([np.minimum(i, j), np.maximum(i, j)], 1), axis=0)
+    pp = e.shape[0]
+    X = (rng.standard_normal((n, d)) / np.sqrt(d)).astype(np.float32)
+    w = rng.uniform(0.5, 2.0, pp).astype(np.float32)
+    et, Xt, wt = torch.tensor(e, device=DEV), torch.tensor(X, device=DEV), torch.tensor(w, device=DEV)
+
+    def run(plan):
+        b = Binding(plan, pymde_amd.penalties.Log1p(wt))
+        buf = torch.zeros(n * d + 1, device=DEV)
+        fused_evaluate(b, Xt, buf[:n * d].view(n, d), buf[n * d:])
+        return buf
+
+    monkeypatch.setenv("MDE_ROW_ORDER", "0")
+    plain = EdgePlan(n, et)
+    ref = run(plain)
+    assert not plain.row_order(0)["in_use"]
+    monkeypatch.delenv("MDE_ROW_ORDER")
+    plan = EdgePlan(n, et)
+    out = run(plan)                       # (the first evaluation at d = 128 builds the order)
+    info = plan.row_order(1)
+    if window and shuffle:
+        assert info["in_use"] and info["mean_distance_after"] < 4 * window < info["mean_distance_before"] / 10
+    else:
+        assert not info["in_use"]
+    assert torch.equal(out[:n * d], ref[:n * d])
+    assert float(out[n * d]) == pytest.approx(float(ref[n * d]), rel=1e-6)
+    wE, wgrad = oracle.average_distortion(e, X, oracle.func("LOG1P", w, None, (1.5,)))
+    assert float(out[n * d]) == pytest.approx(wE, rel=LOSS_RTOL)
+    assert_grad_close(out[:n * d].view(n, d).cpu().numpy(), wgrad)
+    # a forced order on two vertex-range shards: the rows of the single plan, bit for bit
+    lo = 0
+    for hi in (n // 3, n):
+        shard = EdgePlan(n, et, row_lo=lo, row_hi=hi)
+        # (a random graph's search is abandoned -- its third level holds most of the rows --: nothing to force)
+        assert shard.row_order(2)["in_use"] == (bool(window) and hi - lo >= 8192)
+        part = run(shard)
+        assert torch.equal(part[lo * d:hi * d], ref[lo * d:hi * d])
+        lo = hi

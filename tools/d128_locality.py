@@ -22,9 +22,15 @@ for window in (0, 100_000, 10_000, 1_000, 100):
         dst = (src + off) % n
     edges = torch.stack([torch.minimum(src, dst), torch.maximum(src, dst)], 1).contiguous()
     edges = torch.unique(edges, dim=0)
+    if os.environ.get("LOC_SHUFFLE"):
+        # the same graph under a random renumbering of its vertices: the locality is still there, the numbering hides it
+        perm = torch.randperm(n, device=dev, generator=g)
+        edges = perm[edges]
+        edges = torch.stack([edges.min(1).values, edges.max(1).values], 1).contiguous()
     p = edges.shape[0]
     w = 1.0 + (torch.rand(p, device=dev, generator=g) < 0.3).float()
-    b = Binding(EdgePlan(n, edges), pymde_amd.penalties.Log1p(w))
+    plan = EdgePlan(n, edges)
+    b = Binding(plan, pymde_amd.penalties.Log1p(w))
     buf = torch.zeros(n * d + 1, device=dev)
     for _ in range(3): fused_evaluate(b, X, buf[:n * d].view(n, d), buf[n * d:])
     a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -32,6 +38,10 @@ for window in (0, 100_000, 10_000, 1_000, 100):
     for _ in range(10): fused_evaluate(b, X, buf[:n * d].view(n, d), buf[n * d:])
     e.record(); torch.cuda.synchronize()
     ms = a.elapsed_time(e) / 10
-    print("window %7s: %8d edges  %.3f ms per evaluation  %.2f ns per edge  row gathers %.2f TB/s" % (
-        window or "uniform", p, ms, 1e6 * ms / p, 2.0 * p * d * 4 / (ms * 1e-3) / 1e12))
-    del b, edges
+    import time
+    t0 = time.time(); info = plan.row_order(1); t1 = time.time()   # (already built by the first evaluation: a query)
+    print("window %7s: %8d edges  %.3f ms per evaluation  %.2f ns per edge  row gathers %.2f TB/s   order: %s" % (
+        window or "uniform", p, ms, 1e6 * ms / p, 2.0 * p * d * 4 / (ms * 1e-3) / 1e12,
+        "in use (mean distance %.0f -> %.0f, %d levels)" % (info["mean_distance_before"], info["mean_distance_after"], info["levels"])
+        if info["in_use"] else "none (mean distance %.0f, built: %.0f, %d levels)" % (info["mean_distance_before"], info["mean_distance_after"], info["levels"])))
+    del b, edges, plan
