@@ -565,7 +565,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4(
 }
 
 // ---------------------------------------------------------------- general-d fused kernel, pipelined form (round 6)
-// Rows of exactly GL x 4 float4s (d = 128 / 256 / 512 with GL = 8 / 16 / 32).  Same lane layout as k_fused_wide4<GL, 4>
+// Rows of exactly GL x 4 float4s (d = 32 / 64 / 128 / 256 / 512 with GL = 2 / 4 / 8 / 16 / 32).  Same lane layout as k_fused_wide4<GL, 4>
 // (GL lanes share a half-edge, 64 / GL half-edges per wave step); what changes is everything around the arithmetic:
 //  * the row gathers of step s + 1 are in flight while step s is evaluated (two register buffers, the loop unrolled
 //    by two; the meta words -- neighbour id, parameters -- run two steps ahead, the next row's first meta words and
@@ -585,10 +585,10 @@ typedef float wide_f2 __attribute__((ext_vector_type(2)));
 typedef unsigned wide_u2 __attribute__((ext_vector_type(2)));
 template <int GL>
 __device__ __forceinline__ float wide_group_sum(float v) {
-  static_assert(GL == 8 || GL == 16 || GL == 32, "group widths of the pipelined kernel");
+  static_assert(GL == 2 || GL == 4 || GL == 8 || GL == 16 || GL == 32, "group widths of the pipelined kernel");
   v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
-  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
-  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  if constexpr (GL >= 4) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  if constexpr (GL >= 8) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
   if constexpr (GL >= 16) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
   if constexpr (GL >= 32) v += __shfl_xor(v, 16, 64);
   return v;
@@ -797,14 +797,26 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
         float e4[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) e4[k] = wide_fold16(e8[k], e8[k + 4]);
-        if constexpr (GL == 8) {
+        if constexpr (GL <= 8) {
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             e4[k] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e4[k]), 0x128, 0xF, 0xF, true));  // row_ror:8
         }
-        // lane (b5, b4, .): float4 number b4 + 2 b5 of the row; at GL = 8 the lanes with bit 3 set hold a copy
+        if constexpr (GL <= 4) {
+          // (period 8 now: one more rotation by 4 adds the other residue)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            e4[k] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e4[k]), 0x124, 0xF, 0xF, true));  // row_ror:4
+        }
+        if constexpr (GL == 2) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            e4[k] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e4[k]), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+        }
+        // lane (b5, b4, .): float4 number b4 + 2 b5 of the row; below GL = 16 the lanes with (lane & 15) >= GL hold
+        // copies
         const int j = (lane >> 4) & 3;
-        if (GL == 16 || (lane & 8) == 0) grad4[v * d4 + lig + j * GL] = wide_f4{e4[0], e4[1], e4[2], e4[3]} * gsc;
+        if ((lane & 15) < GL) grad4[v * d4 + lig + j * GL] = wide_f4{e4[0], e4[1], e4[2], e4[3]} * gsc;
       }
     }
     // xv <- -x_v of the next row (see step()); the asm keeps hipcc from folding the sign back into a subtraction
@@ -1008,9 +1020,11 @@ static int launch_wide(FusedArgs& A, const Fn& fn) {
   const int d = A.d;
   if ((d & 3) == 0 && ((reinterpret_cast<uintptr_t>(A.X) | reinterpret_cast<uintptr_t>(A.grad)) & 15) == 0) {
     const int d4 = d >> 2;
-    // Round 6: rows of exactly 8 / 16 / 32 x 4 float4s (d = 128, 256, 512) take the pipelined kernel (MDE_WIDE_P=0: off)
+    // Round 6: rows of exactly 2 / 4 / 8 / 16 / 32 x 4 float4s (d = 32, 64, 128, 256, 512) take the pipelined kernel (MDE_WIDE_P=0: off)
     const int wide_p = getenv("MDE_WIDE_P") ? atoi(getenv("MDE_WIDE_P")) : 1;
     if (wide_p) {
+      if (d4 == 8) return launch_wide4p<2, IND, Fn>(A, fn);
+      if (d4 == 16) return launch_wide4p<4, IND, Fn>(A, fn);
       if (d4 == 32) return launch_wide4p<8, IND, Fn>(A, fn);
       if (d4 == 64) return launch_wide4p<16, IND, Fn>(A, fn);
       if (d4 == 128) return launch_wide4p<32, IND, Fn>(A, fn);

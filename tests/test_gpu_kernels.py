@@ -1065,9 +1065,9 @@ def _band_graph(rng, n, deg, window, shuffle):
     return e
 
 
-@pytest.mark.parametrize("d", [128, 256, 512])
+@pytest.mark.parametrize("d", [32, 64, 128, 256, 512])
 def test_pipelined_wide_kernel_on_ragged_graphs(d, monkeypatch):
-    """k_fused_wide4p (rows of exactly 8 / 16 / 32 x 4 float4s): empty rows, rows of one to three half-edges, a hub,
+    """k_fused_wide4p (rows of exactly 2 / 4 / 8 / 16 / 32 x 4 float4s): empty rows, rows of one to three half-edges, a hub,
     odd and even step counts -- against the oracle, against the unpipelined kernel (MDE_WIDE_P=0), three runs bitwise."""
     import pymde_amd
     from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
