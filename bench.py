@@ -627,7 +627,7 @@ def run_config5(args, device):
                    "standardized_tangent_ms": t_tan, "standardized_retract_ms": t_ret},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (k["kernel_ms"] * 1e-3) / 1e9,
                      "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": k["roofline_frac"], "traffic": None,
-                     "kernel": "k_fused_wide4<32,1> (CSR, one half wave per 512-byte row, 16-byte loads)",
+                     "kernel": "k_fused_wide4p<8> (CSR, 8 lanes x four float4s per 512-byte row, 8 half-edges per wave step, gathers of the next step in flight, XCD-aware row chunks)",
                      "kernel_ms": k["kernel_ms"], "alg_bytes_per_launch": alg_bytes,
                      "note": "the 37.6 B/edge figure assumes every row is read once; a uniform-random graph "
                              "at d = 128 has no reuse to exploit (each half-edge needs its own 512-byte row: "
@@ -747,7 +747,7 @@ def run_config5_embed(args, device):
                                "moves), Standardized, L-BFGS memory 10, X0 = Standardized().initialization" % (n, p),
                    "parallelism": "single GPU", "edges_per_s_per_iter": p * n_it / dt,
                    "average_distortions": [float(v) for v in st.average_distortions],
-                   "component_ms": {"average_distortion fwd+bwd (k_fused_wide4)": t_eval,
+                   "component_ms": {"average_distortion fwd+bwd (k_fused_wide4p)": t_eval,
                                     "Standardized tangent projection": t_tan,
                                     "Standardized retraction": t_ret},
                    "vector_bytes": vec_bytes,
