@@ -523,7 +523,8 @@ extern "C" int mde_plan_row_order(mde_plan* plan, int32_t mode, void* stream, do
     report();
     return MDE_OK;
   }
-  if (plan->order_state != 0) {
+  // (built before, or tried and rejected: nothing to do -- except that mode 2 overrides an earlier rejection)
+  if (plan->order_state == 1 || (plan->order_state == -1 && mode < 2)) {
     report();
     return MDE_OK;
   }

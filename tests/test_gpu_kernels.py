@@ -1143,6 +1143,11 @@ def test_row_processing_order(window, shuffle, monkeypatch):
         assert info["in_use"] and info["mean_distance_after"] < 4 * window < info["mean_distance_before"] / 10
     else:
         assert not info["in_use"]
+        if window:
+            # rejected (the graph as given is as local as the search makes it): mode 2 overrides, the bits stay
+            assert plan.row_order(2)["in_use"]
+            assert torch.equal(run(plan)[:n * d], ref[:n * d])
+            assert not plan.row_order(0)["in_use"]
     assert torch.equal(out[:n * d], ref[:n * d])
     assert float(out[n * d]) == pytest.approx(float(ref[n * d]), rel=1e-6)
     wE, wgrad = oracle.average_distortion(e, X, oracle.func("LOG1P", w, None, (1.5,)))
