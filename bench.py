@@ -61,9 +61,13 @@ KERNEL_SOURCES = ["pymde_amd/csrc/mde_ring.h", "pymde_amd/csrc/mde_ring_kernel.h
                   "pymde_amd/csrc/mde_functions.h"]
 
 
-def source_sha():
+# the general-d kernel (config 5's PMC record, profiles/r06_pmc_traffic_c5.json)
+WIDE_SOURCES = ["pymde_amd/csrc/mde_distortion.hip", "pymde_amd/csrc/mde_functions.h"]
+
+
+def source_sha(files=None):
     h = hashlib.sha256()
-    for f in KERNEL_SOURCES:
+    for f in (files or KERNEL_SOURCES):
         with open(os.path.join(ROOT, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -79,7 +83,10 @@ def pmc_traffic(key, tag=""):
         rec = json.load(open(path))
     except Exception:
         return None, None
-    if rec.get("source_sha") != source_sha():
+    if key == "wide4":
+        if rec.get("source_sha_wide") != source_sha(WIDE_SOURCES):
+            return None, "profiles/%s is from another kernel source (stale): ignored" % name
+    elif rec.get("source_sha") != source_sha():
         return None, "profiles/%s is from another kernel source (stale): ignored" % name
     b = rec.get("bytes_per_launch", {})
     v = b.get(key)
@@ -615,6 +622,7 @@ def run_config5(args, device):
     Y = X.clone()
     t_ret, _ = time_launches(lambda: c.project_onto_constraint(Y, inplace=True), 20, device)
     k = res["Log1p"]
+    traffic, traffic_src = pmc_traffic("wide4", "_c5")
     return {
         "metric": "edges/sec/iter (avg_distortion fwd+bwd), n=500k |E|=20M d=128",
         "value": k["value"], "unit": "edges/s/iter", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -626,7 +634,8 @@ def run_config5(args, device):
                    "parallelism": "single GPU", "functions": res,
                    "standardized_tangent_ms": t_tan, "standardized_retract_ms": t_ret},
         "roofline": {"bound": "hbm", "achieved": alg_bytes / (k["kernel_ms"] * 1e-3) / 1e9,
-                     "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": k["roofline_frac"], "traffic": None,
+                     "peak": HBM_PEAK_BPS / 1e9, "unit": "GB/s", "frac": k["roofline_frac"], "traffic": traffic,
+                     "traffic_source": traffic_src,
                      "kernel": "k_fused_wide4p<8> (CSR, 8 lanes x four float4s per 512-byte row, 8 half-edges per wave step, gathers of the next step in flight, XCD-aware row chunks)",
                      "kernel_ms": k["kernel_ms"], "alg_bytes_per_launch": alg_bytes,
                      "note": "the 37.6 B/edge figure assumes every row is read once; a uniform-random graph "

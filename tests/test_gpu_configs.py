@@ -308,6 +308,53 @@ def test_config5_full_size_against_oracle():
         assert_grad_close(buf[:n * d].view(n, d).cpu().numpy(), wgrad)
 
 
+def test_config5_size_band_graph_renumbered_against_oracle(monkeypatch):
+    """configs[4]'s shape on a graph WITH locality that the numbering hides: n = 500k, d = 128, neighbours within 100
+    rows of a hidden order, vertices renumbered at random.  The plan adopts a breadth-first processing order on its
+    first evaluation (`mde_plan_row_order`); the gradient equals the one computed without any order BIT FOR BIT, three
+    evaluations agree bitwise, and both agree with the oracle at full size (~16.5M edges)."""
+    import pymde_amd
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    dev = torch.device(DEV, 0)
+    n, d, deg, window = 500_000, 128, 40, 100
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0)
+    src = torch.arange(n, device=dev).repeat_interleave(deg)
+    dst = (src + torch.randint(1, window + 1, (n * deg,), device=dev, generator=gen)) % n
+    perm = torch.randperm(n, device=dev, generator=gen)
+    e = perm[torch.stack([src, dst], 1)]
+    edges = torch.unique(torch.stack([e.min(1).values, e.max(1).values], 1), dim=0).contiguous()
+    p = edges.shape[0]
+    w = 1.0 + (torch.rand(p, device=dev, generator=gen) < 0.3).float()
+    torch.manual_seed(0)
+    X = pymde_amd.Standardized().initialization(n, d, device=dev)
+    f = pymde_amd.penalties.Log1p(w)
+
+    def run(plan):
+        buf = torch.zeros(n * d + 1, device=dev)
+        fused_evaluate(Binding(plan, f), X, buf[:n * d].view(n, d), buf[n * d:])
+        return buf
+
+    monkeypatch.setenv("MDE_ROW_ORDER", "0")
+    plain = EdgePlan(n, edges)
+    ref = run(plain)
+    assert not plain.row_order(0)["in_use"]
+    monkeypatch.delenv("MDE_ROW_ORDER")
+    plan = EdgePlan(n, edges)
+    outs = [run(plan) for _ in range(3)]
+    info = plan.row_order(1)
+    assert info["in_use"] and info["mean_distance_after"] < 4 * window and info["mean_distance_before"] > n / 10
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0][:n * d], ref[:n * d])
+    L = oracle.lib()
+    L.oracle_set_num_threads(min(8, L.oracle_num_threads()))
+    wE, wgrad = oracle.average_distortion(edges.cpu().numpy(), X.cpu().numpy(),
+                                          oracle.func("LOG1P", w.cpu().numpy(), None, (1.5,)))
+    for out in (outs[0], ref):
+        assert float(out[n * d]) == pytest.approx(wE, rel=1e-5)
+    assert_grad_close(outs[0][:n * d].view(n, d).cpu().numpy(), wgrad)
+
+
 def _ring_full_size_case(n, deg, d, make_f, oracle_func, runs=3, graph="uniform"):
     """>= 5e7 half-edge entries through the LDS-ring kernel: against the OpenMP oracle at the kernel
     tolerances, `runs` evaluations bitwise equal (a race in the ring protocol shows up as a few rows that

@@ -49,7 +49,8 @@ def main():
                 a[0] += float(r["Counter_Value"])
                 a[1] += 1
     import bench
-    rec = {"source_sha": bench.source_sha(), "counters_per_launch": {}, "bytes_per_launch": {}}
+    rec = {"source_sha": bench.source_sha(), "source_sha_wide": bench.source_sha(bench.WIDE_SOURCES),
+           "counters_per_launch": {}, "bytes_per_launch": {}}
     for k, cs in acc.items():
         mean = {c: v[0] / max(v[1], 1) for c, v in cs.items()}
         rec["counters_per_launch"][k] = mean

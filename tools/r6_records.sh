@@ -16,6 +16,7 @@ pmc ""
 pmc _4b --variant 4b
 pmc _d3 --dim 3
 pmc _n2m --n 2000000
+pmc _c5 --config 5
 python bench.py 2>/dev/null | tail -1 > $O/bench_line.json
 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $O/bench_line_driver_command.json
 python bench.py --no-cpu-baseline --survey-seed 2>/dev/null | tail -1 > $O/survey_seed_bench_line.json
