@@ -353,9 +353,9 @@ def run_config4(args, world, rank, device):
     from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
 
     n, d = args.n, args.dim
-    edges, w, X = make_workload_survey(device, n=n, d=d) if args.survey_seed else make_workload(device, n=n, d=d, graph=args.graph)
+    edges, w, X = make_workload_survey(device, n=n, d=d) if args.survey_seed else make_workload(device, n=n, deg=args.degree, d=d, graph=args.graph)
     p = edges.shape[0]
-    headline_shape = n == N_ITEMS and d == DIM and args.graph == "uniform"
+    headline_shape = n == N_ITEMS and d == DIM and args.graph == "uniform" and args.degree == OUT_DEGREE
     if args.variant == "4b":
         # the last third of the edges repulsive (w = -1), PushAndPull(Log1p, Log)
         w = w.clone()
@@ -488,10 +488,10 @@ def run_config4(args, world, rank, device):
         "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "BASELINE configs[3] / SURVEY 8d config %s%s: n=%d, |E|=%d %s edges "
-                               "(out-degree 50), d=%d, %s; %s" % (args.variant, "" if headline_shape else " at ANOTHER SHAPE (secondary record)",
+                               "(out-degree %d), d=%d, %s; %s" % (args.variant, "" if headline_shape else " at ANOTHER SHAPE (secondary record)",
                                                                    n, p, {"uniform": "uniform-random", "hub": "uniform-random + one hub of degree 5e5",
                                                                           "powerlaw": "preferential-attachment (copy model)",
-                                                                          "clusters": "planted-cluster"}[args.graph], d, fname,
+                                                                          "clusters": "planted-cluster"}[args.graph], args.degree, d, fname,
                                "the survey's exact tensors: numpy default_rng(0) edges and weights, torch.manual_seed(0) "
                                "CPU randn X, built on the host and uploaded (--survey-seed)" if args.survey_seed else
                                "seeded on the device with torch.Generator(0) (the survey's recipe uses numpy "
@@ -1039,6 +1039,7 @@ def main():
     ap.add_argument("--no-codebook", action="store_true",
                     help="stream the weights as fp32 (8 B/half-edge) even though they take 2 values")
     ap.add_argument("--n", type=int, default=N_ITEMS)
+    ap.add_argument("--degree", type=int, default=OUT_DEGREE, help="out-degree of the synthetic graph (secondary records)")
     ap.add_argument("--dim", type=int, default=DIM, choices=(1, 2, 3, 4),
                     help="config 4 only: embedding dimension (secondary records; the headline is d = 2)")
     ap.add_argument("--graph", default="uniform", choices=("uniform", "hub", "powerlaw", "clusters"),

@@ -703,6 +703,18 @@ static double ring_time_us(double iters_per_wave, int NC, int Q, int nwg) {
 static double csr_time_us(const mde_plan* plan, int d) {
   return (double)plan->H * ((int64_t)plan->n * d * 4 >= (6 << 20) ? 1.3e-5 : 0.6e-5);
 }
+// The regime between the MNIST-sized problems and the benchmark shape (round 6, late): the table sits in L2 and there
+// are fewer than 16 M half-edges -- rounds 3-6 kept the CSR kernels there without asking.  tools/r6_midsize2.sh, ring
+// forced against auto, d = 2, ms per evaluation: n = 150k at degree 50 0.0935 -> 0.0356, 100k 0.0604 -> 0.0273, 50k
+// 0.0357 -> 0.0187; at degree 20 150k 0.0402 -> 0.0241, 100k 0.0312 -> 0.0214, 50k 0.0186 -> 0.0164, 20k 0.0162 -> 0.0151:
+// the ring's iterations cost what they cost at config 4, in front of ~11 us of fixed cost (two launches, a prologue
+// that fills 61 KB of LDS per workgroup, the groups' partial rows), the CSR kernels' 0.6e-5 us per half-edge sit on ~7.
+// d = 2 and 3 only: d = 1 and 4 run the run-time functor on the ring kernel (2.7 x the compile-time kinds).
+static bool mid_regime(const mde_plan* plan, int d) {
+  return (int64_t)plan->n * d * 4 < (6 << 20) && plan->H < ((int64_t)16 << 20);
+}
+#define MDE_RING_FIXED_US 11.0
+#define MDE_CSR_FIXED_US 7.0
 
 // Decide the block height and the column groups for dimension d; false when the layout is not
 // worthwhile (the caller keeps the CSR kernel).
@@ -766,7 +778,8 @@ static bool choose_sizes(const mde_plan* plan, int d, RingSizes* z) {
     // costs: either the table overflows L2 (the CSR kernel's gathers go to HBM), or there are enough
     // half-edges that 64 B of L2 traffic per 8-byte gather is what the CSR kernel spends its time on
     // (40k nodes, 100M half-edges: 0.60 -> 0.30 ms per evaluation)
-    if ((int64_t)plan->n * d * 4 < (6 << 20) && plan->H < ((int64_t)16 << 20)) return false;
+    // Round 6: in that regime the cost model is asked too, with both sides' fixed costs (below); d = 1 and 4 stay
+    if (mid_regime(plan, d) && d != 2 && d != 3) return false;
   }
   const int S = ring_slots_for(d, (int)pr);
   if (S < 6) return false;
@@ -780,6 +793,9 @@ static bool choose_sizes(const mde_plan* plan, int d, RingSizes* z) {
   if (mode != 1) {
     const double its = 1.4 * (double)plan->H / ((double)nrb * Q * MDE_RING_NCW * 64.0);
     if (ring_time_us(its, (int)nc, Q, (int)(nrb * Q)) > 0.75 * csr_time_us(plan, d)) return false;
+    if (mid_regime(plan, d) &&
+        ring_time_us(its, (int)nc, Q, (int)(nrb * Q)) + MDE_RING_FIXED_US > 0.7 * (csr_time_us(plan, d) + MDE_CSR_FIXED_US))
+      return false;
   }
   z->qmax = qmax;
   z->R = (int)pr;
@@ -1227,7 +1243,8 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     // threshold let through, and 4 x padding says as much.
     const double t_ring = ring_time_us((double)total_iters / (double)nseg, z.NC, z.Q, z.NRB * z.Q) +
                           (double)rp.hub_half_edges * 1.3e-5;
-    if ((double)Hp > 4.0 * (double)H_ring || t_ring > 0.9 * csr_time_us(plan, d)) {
+    const bool mid_bad = mid_regime(plan, d) && t_ring + MDE_RING_FIXED_US > 0.85 * (csr_time_us(plan, d) + MDE_CSR_FIXED_US);
+    if ((double)Hp > 4.0 * (double)H_ring || t_ring > 0.9 * csr_time_us(plan, d) || mid_bad) {
       drop_caps();
       release(true);
       return 0;
