@@ -183,6 +183,12 @@ int mde_plan_expand(const mde_plan* plan, const float* in_edge, float* out_half,
  * Per-edge parameters for layout 1 are permuted with mde_plan_expand_layout and flagged with
  * mde_func.layout = 1.  Negative return: error. */
 int mde_plan_layout(mde_plan* plan, int32_t d, void* stream);
+/* Tell the plan which distortion function its next layout decision is for (mde_func.kind / kind_neg): for problems
+ * whose table fits L2 and that have fewer than 16 M half-edges the choice between the two layouts is close, and the
+ * ring kernel pays for an expensive function (PushAndPull, Log, the run-time functor of private kinds) where the CSR
+ * kernels hide it behind their gathers.  Optional (default: a Log1p-class function); call it before mde_plan_layout.
+ * Never changes a result, only which kernel computes it. */
+int mde_plan_function_hint(mde_plan* plan, int32_t kind, int32_t kind_neg);
 /* Entries of a per-half-edge parameter array in `layout` (layout 1 stores whole 64-entry wave
  * iterations, padded where a stream ends or its chunk window closes, so it is larger than
  * mde_plan_half_edges). */

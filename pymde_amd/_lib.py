@@ -61,6 +61,7 @@ SYMBOLS = {
     "mde_plan_layout_half_edges": (c_i64, [c_vp, c_i32]),
     "mde_plan_ring_info": (c_i32, [c_vp, ctypes.POINTER(c_i64)]),
     "mde_plan_row_order": (c_i32, [c_vp, c_i32, c_vp, ctypes.POINTER(ctypes.c_double)]),
+    "mde_plan_function_hint": (c_i32, [c_vp, c_i32, c_i32]),
     "mde_plan_loss_double": (c_i32, [c_vp, c_vp, c_vp]),
     "mde_center_step_begin": (c_i32, [c_i64, c_i32, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp]),
     "mde_center_step_end": (c_i32, [c_i64, c_i32, c_vp, c_vp, ctypes.c_double, c_vp]),

@@ -195,6 +195,8 @@ class Binding(object):
         if self._struct is None or key != self._key:
             plan = self.plan
             with torch.cuda.device(plan.device):
+                # (which function the layout decision is for: the close calls of mid-size problems depend on it)
+                _lib.check(lib.mde_plan_function_hint(plan.handle, int(spec.kind), int(spec.kind_neg)))
                 layout = lib.mde_plan_layout(plan.handle, int(d), _lib.stream_ptr(plan.device))
             if layout < 0:
                 _lib.check(layout)

@@ -9,6 +9,7 @@
 struct mde_ring_layout {
   int d = 0;                    // embedding dimension the sizes were chosen for
   int rejected_d = 0;           // dimension for which the ring layout was tried and given up (too much padding)
+  float cost_scale = 1.0f;      // what an iteration of the coming function costs relative to Log1p (mde_plan_function_hint)
   int rows_per_block = 0, n_row_blocks = 0;
   int col_groups = 1;           // Q: workgroups per row block, each walking 1/Q of the chunks
   int chunk_cols = 0, n_chunks = 0;

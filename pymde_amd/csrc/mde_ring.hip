@@ -715,6 +715,30 @@ static bool mid_regime(const mde_plan* plan, int d) {
 }
 #define MDE_RING_FIXED_US 11.0
 #define MDE_CSR_FIXED_US 7.0
+// ... and the ring kernel's iterations cost what the FUNCTION costs (profiles/r05_function_sweep.txt, ms per step at
+// config-4 size: Quadratic 0.157 .. Huber 0.178, Logistic / Power / Log / SoftFractional 0.20-0.23, PushAndPull 0.2065,
+// the run-time functor 0.44), while the CSR kernels' gathers hide most of it: a neighbour-preserving problem of 100k
+// items (3.9 M half-edges, PushAndPull(Log1p, LogRatio)) runs 0.0296 ms on the CSR kernel and 0.0329 on the ring, at
+// 200k items 0.0509 against 0.0432 (tools/r6_pn_scale.py).  mde_plan_function_hint tells the plan which function is
+// coming; the scale multiplies the ring's estimate in the mid regime only.
+static double function_cost_scale(int kind, int kind_neg) {
+  if (kind_neg != MDE_F_NONE) return 1.3;
+  switch (kind) {
+    case MDE_F_LOG1P: case MDE_F_QUADRATIC: case MDE_F_LINEAR: case MDE_F_CUBIC: case MDE_F_INVPOWER: case MDE_F_HUBER:
+    case MDE_F_L_QUADRATIC: case MDE_F_L_WEIGHTED_QUADRATIC: case MDE_F_L_ABSOLUTE: case MDE_F_L_HUBER: case MDE_F_L_CUBIC:
+      return 1.05;
+    case MDE_F_LOGISTIC: case MDE_F_POWER: case MDE_F_LOG: case MDE_F_SIGMOID: case MDE_F_HINGE: case MDE_F_LOGRATIO:
+    case MDE_F_L_POWER: case MDE_F_L_LOGISTIC: case MDE_F_L_FRACTIONAL: case MDE_F_L_SOFT_FRACTIONAL:
+      return 1.35;
+    default:
+      return 2.7;  // private kinds: the run-time functor
+  }
+}
+extern "C" int mde_plan_function_hint(mde_plan* plan, int32_t kind, int32_t kind_neg) {
+  if (!plan) return MDE_E_INVALID;
+  plan->ring.cost_scale = (float)function_cost_scale(kind, kind_neg);
+  return MDE_OK;
+}
 
 // Decide the block height and the column groups for dimension d; false when the layout is not
 // worthwhile (the caller keeps the CSR kernel).
@@ -794,7 +818,8 @@ static bool choose_sizes(const mde_plan* plan, int d, RingSizes* z) {
     const double its = 1.4 * (double)plan->H / ((double)nrb * Q * MDE_RING_NCW * 64.0);
     if (ring_time_us(its, (int)nc, Q, (int)(nrb * Q)) > 0.75 * csr_time_us(plan, d)) return false;
     if (mid_regime(plan, d) &&
-        ring_time_us(its, (int)nc, Q, (int)(nrb * Q)) + MDE_RING_FIXED_US > 0.7 * (csr_time_us(plan, d) + MDE_CSR_FIXED_US))
+        plan->ring.cost_scale * ring_time_us(its, (int)nc, Q, (int)(nrb * Q)) + MDE_RING_FIXED_US >
+            0.7 * (csr_time_us(plan, d) + MDE_CSR_FIXED_US))
       return false;
   }
   z->qmax = qmax;
@@ -1243,7 +1268,8 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     // threshold let through, and 4 x padding says as much.
     const double t_ring = ring_time_us((double)total_iters / (double)nseg, z.NC, z.Q, z.NRB * z.Q) +
                           (double)rp.hub_half_edges * 1.3e-5;
-    const bool mid_bad = mid_regime(plan, d) && t_ring + MDE_RING_FIXED_US > 0.85 * (csr_time_us(plan, d) + MDE_CSR_FIXED_US);
+    const bool mid_bad = mid_regime(plan, d) &&
+                         plan->ring.cost_scale * t_ring + MDE_RING_FIXED_US > 0.85 * (csr_time_us(plan, d) + MDE_CSR_FIXED_US);
     if ((double)Hp > 4.0 * (double)H_ring || t_ring > 0.9 * csr_time_us(plan, d) || mid_bad) {
       drop_caps();
       release(true);
