@@ -565,7 +565,8 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4(
 }
 
 // ---------------------------------------------------------------- general-d fused kernel, pipelined form (round 6)
-// Rows of exactly GL x 4 float4s (d = 32 / 64 / 128 / 256 / 512 with GL = 2 / 4 / 8 / 16 / 32).  Same lane layout as k_fused_wide4<GL, 4>
+// Rows of d4 = d / 4 float4s, GL lanes x K4 float4s per half-edge with GL * (K4 - 1) < d4 <= GL * K4 (GL = 1 .. 32, K4 = 2 .. 4:
+// every d = 8 .. 512 that is a multiple of 4; d = 128 is <8, 4>).  Same lane layout as k_fused_wide4<GL, K4>
 // (GL lanes share a half-edge, 64 / GL half-edges per wave step); what changes is everything around the arithmetic:
 //  * the row gathers of step s + 1 are in flight while step s is evaluated (two register buffers, the loop unrolled
 //    by two; the meta words -- neighbour id, parameters -- run two steps ahead, the next row's first meta words and
@@ -585,8 +586,8 @@ typedef float wide_f2 __attribute__((ext_vector_type(2)));
 typedef unsigned wide_u2 __attribute__((ext_vector_type(2)));
 template <int GL>
 __device__ __forceinline__ float wide_group_sum(float v) {
-  static_assert(GL == 2 || GL == 4 || GL == 8 || GL == 16 || GL == 32, "group widths of the pipelined kernel");
-  v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  static_assert(GL == 1 || GL == 2 || GL == 4 || GL == 8 || GL == 16 || GL == 32, "group widths of the pipelined kernel");
+  if constexpr (GL >= 2) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
   if constexpr (GL >= 4) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
   if constexpr (GL >= 8) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));  // row_half_mirror
   if constexpr (GL >= 16) v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xF, 0xF, true));  // row_mirror
@@ -603,16 +604,17 @@ __device__ __forceinline__ float wide_fold16(float a, float b) {
   const wide_u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r.x) + __uint_as_float(r.y);
 }
-template <int GL, bool INDIRECT, class Fn>
+template <int GL, int K4, bool INDIRECT, class Fn>
 __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
-    int nrows, int row_lo, int chunk_log, const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
+    int nrows, int row_lo, int d4, int chunk_log, const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ nbr,
     const int32_t* __restrict__ eid, const float* __restrict__ a0, const float* __restrict__ a1, int a0_scalar,
     int a1_scalar, const wide_f4* __restrict__ X4, wide_f4* __restrict__ grad4, double* __restrict__ loss_partials,
     Fn fn, float inv_p, float grad_scale) {
   __shared__ double smem[8];
   constexpr int E = 64 / GL;   // half-edges per wave step
-  constexpr int d4 = GL * 4;   // float4s per row
+  // d4 = float4s per row, GL * (K4 - 1) < d4 <= GL * K4: the lanes whose LAST float4 lies behind the row's end load the
+  // row's last float4 again (a valid address) and have that difference multiplied by zero
   constexpr int WPB = MDE_BLOCK / 64;
   const int lane = threadIdx.x & 63;
   const int lig = lane & (GL - 1);
@@ -623,6 +625,9 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
   float loss = 0.0f;
   const float a0s = a0_scalar ? a0[0] : 0.0f;
   const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
+  const bool tail_dead = lig + (K4 - 1) * GL >= d4;
+  const int c_tail = tail_dead ? d4 - 1 : lig + (K4 - 1) * GL;  // column (float4) of the lane's last load
+  const float keep = tail_dead ? 0.0f : 1.0f;
 
   // position of the i-th row of this XCD's sequence in the processing order, or -1 behind the end; the row at a
   // position is order[position] when the plan carries a processing order (mde_plan_row_order), the position itself
@@ -655,17 +660,18 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
     }
     return m;
   };
-  auto load_rows = [&](wide_f4 (&x)[4], int64_t u) __attribute__((always_inline)) {
-    const wide_f4* p = X4 + u * d4 + lig;
+  auto load_rows = [&](wide_f4 (&x)[K4], int64_t u) __attribute__((always_inline)) {
+    const wide_f4* p = X4 + u * d4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) x[j] = p[j * GL];
+    for (int j = 0; j < K4 - 1; ++j) x[j] = p[lig + j * GL];
+    x[K4 - 1] = p[c_tail];
   };
 
   int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * WPB + (int)(threadIdx.x >> 6));
   int r = row_of(i);
   int beg = 0, end = 0, r_n = -1, beg_n = 0, end_n = 0, r_nn = -1, beg_nn = 0, end_nn = 0, r_n3 = -1;
   Meta mA = {0, 0.f, 0.f}, mB = mA, m0n = mA, m1n = mA;
-  wide_f4 xv[4], bufA[4], bufB[4];
+  wide_f4 xv[K4], bufA[K4], bufB[K4];
   if (r >= 0) {
     beg = rowptr[r];
     end = rowptr[r + 1];
@@ -687,7 +693,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
     load_rows(xv, (int64_t)row_lo + r);
     load_rows(bufA, mA.u);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < K4; ++j) {
       xv[j] = -xv[j];
       asm volatile("" : "+v"(xv[j]));
     }
@@ -713,25 +719,30 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
     // the next row's x_v, a row ahead like everything else of it; the first two meta words of the row after next
     // (loaded here, not at the row's end: the copy into the registers the next trip reads would otherwise wait for
     // loads that have only just gone out; behind the last row beg_nn = end_nn = 0: position 0)
-    wide_f4 xvn[4];
+    wide_f4 xvn[K4];
     load_rows(xvn, (int64_t)row_lo + (r_n >= 0 ? r_n : r));
     const Meta m0nn = load_meta(beg_nn + sub, end_nn);
     const Meta m1nn = load_meta(beg_nn + E + sub, end_nn);
-    wide_f2 acc[8];
+    wide_f2 acc[2 * K4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = wide_f2{0.f, 0.f};
+    for (int j = 0; j < 2 * K4; ++j) acc[j] = wide_f2{0.f, 0.f};
 
     // one step: x holds the gathered rows of E half-edges (one per group of GL lanes).
     // (xv holds -x_v: dd = x_u - x_v is then a packed ADD -- hipcc has no packed form for a subtraction of two
     // register pairs --, the accumulators collect -g (x_v - x_u) and the sign goes into the scale of the final
     // store: negation is exact, every intermediate is the negative of the plain form's, bit for bit)
-    auto step = [&](wide_f4 (&x)[4], const Meta& m, bool live) __attribute__((always_inline)) {
+    auto step = [&](wide_f4 (&x)[K4], const Meta& m, bool live) __attribute__((always_inline)) {
       __builtin_amdgcn_sched_barrier(0);
-      wide_f2 dd[8], s2 = {0.f, 0.f}, t2 = {0.f, 0.f};
+      wide_f2 dd[2 * K4], s2 = {0.f, 0.f}, t2 = {0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < K4; ++j) {
         dd[2 * j] = wide_f2{xv[j].x, xv[j].y} + wide_f2{x[j].x, x[j].y};
         dd[2 * j + 1] = wide_f2{xv[j].z, xv[j].w} + wide_f2{x[j].z, x[j].w};
+        if (j == K4 - 1) {
+          // (x 1 where the row is exactly GL x K4 float4s wide: exact)
+          dd[2 * j] *= wide_f2{keep, keep};
+          dd[2 * j + 1] *= wide_f2{keep, keep};
+        }
         s2 = dd[2 * j] * dd[2 * j] + s2;
         t2 = dd[2 * j + 1] * dd[2 * j + 1] + t2;
       }
@@ -747,7 +758,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
       if (lig == 0) loss += f;
       const wide_f2 g2 = {g, g};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = g2 * dd[j] + acc[j];
+      for (int j = 0; j < 2 * K4; ++j) acc[j] = g2 * dd[j] + acc[j];
       __builtin_amdgcn_sched_barrier(0);
     };
 
@@ -780,8 +791,8 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
       float e[16];
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        e[2 * j] = acc[j].x;
-        e[2 * j + 1] = acc[j].y;
+        e[2 * j] = j < 2 * K4 ? acc[j < 2 * K4 ? j : 0].x : 0.0f;
+        e[2 * j + 1] = j < 2 * K4 ? acc[j < 2 * K4 ? j : 0].y : 0.0f;
       }
       // xor 32: element k with k + 8 -> lanes < 32 keep k, lanes >= 32 keep k + 8
       float e8[8];
@@ -790,8 +801,9 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
       if constexpr (GL == 32) {
         // lane (b5, lig): float4s 2 b5 and 2 b5 + 1 of the row
         const int j0 = (lane >> 5) * 2;
-        grad4[v * d4 + lig + j0 * GL] = wide_f4{e8[0], e8[1], e8[2], e8[3]} * gsc;
-        grad4[v * d4 + lig + (j0 + 1) * GL] = wide_f4{e8[4], e8[5], e8[6], e8[7]} * gsc;
+        if (j0 < K4 && lig + j0 * GL < d4) grad4[v * d4 + lig + j0 * GL] = wide_f4{e8[0], e8[1], e8[2], e8[3]} * gsc;
+        if (j0 + 1 < K4 && lig + (j0 + 1) * GL < d4)
+          grad4[v * d4 + lig + (j0 + 1) * GL] = wide_f4{e8[4], e8[5], e8[6], e8[7]} * gsc;
       } else {
         // xor 16: element k with k + 4 -> rows 0, 2 keep k, rows 1, 3 keep k + 4
         float e4[4];
@@ -808,20 +820,26 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
           for (int k = 0; k < 4; ++k)
             e4[k] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e4[k]), 0x124, 0xF, 0xF, true));  // row_ror:4
         }
-        if constexpr (GL == 2) {
+        if constexpr (GL <= 2) {
 #pragma unroll
           for (int k = 0; k < 4; ++k)
             e4[k] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e4[k]), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
         }
+        if constexpr (GL == 1) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            e4[k] += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(e4[k]), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+        }
         // lane (b5, b4, .): float4 number b4 + 2 b5 of the row; below GL = 16 the lanes with (lane & 15) >= GL hold
         // copies
         const int j = (lane >> 4) & 3;
-        if ((lane & 15) < GL) grad4[v * d4 + lig + j * GL] = wide_f4{e4[0], e4[1], e4[2], e4[3]} * gsc;
+        if ((lane & 15) < GL && j < K4 && lig + j * GL < d4)
+          grad4[v * d4 + lig + j * GL] = wide_f4{e4[0], e4[1], e4[2], e4[3]} * gsc;
       }
     }
     // xv <- -x_v of the next row (see step()); the asm keeps hipcc from folding the sign back into a subtraction
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < K4; ++j) {
       xv[j] = -xvn[j];
       asm volatile("" : "+v"(xv[j]));
     }
@@ -990,7 +1008,7 @@ static int launch_wide4_gk(FusedArgs& A, const Fn& fn) {
   MDE_LAUNCH_CHECK();
   return MDE_OK;
 }
-template <int GL, bool IND, class Fn>
+template <int GL, int K4, bool IND, class Fn>
 static int launch_wide4p(FusedArgs& A, const Fn& fn) {
   const mde_plan* P = A.plan;
   const int nrows = (int)(mde_plan_row_hi(P) - mde_plan_row_lo(P));
@@ -1008,8 +1026,8 @@ static int launch_wide4p(FusedArgs& A, const Fn& fn) {
     const int rc = mde_plan_row_order(const_cast<mde_plan*>(P), order_env, A.st, nullptr);
     if (rc != MDE_OK) return rc;
   }
-  hipLaunchKernelGGL((k_fused_wide4p<GL, IND, Fn>), dim3(nb), dim3(MDE_BLOCK), 0, A.st, nrows,
-                     (int)mde_plan_row_lo(P), chunk_log, P->order, mde_plan_rowptr(P), mde_plan_nbr(P), mde_plan_eid(P),
+  hipLaunchKernelGGL((k_fused_wide4p<GL, K4, IND, Fn>), dim3(nb), dim3(MDE_BLOCK), 0, A.st, nrows,
+                     (int)mde_plan_row_lo(P), A.d / 4, chunk_log, P->order, mde_plan_rowptr(P), mde_plan_nbr(P), mde_plan_eid(P),
                      A.a0, A.a1, A.a0_scalar, A.a1_scalar, reinterpret_cast<const wide_f4*>(A.X),
                      reinterpret_cast<wide_f4*>(A.grad), A.partials, fn, A.inv_p, A.grad_scale);
   MDE_LAUNCH_CHECK();
@@ -1020,14 +1038,24 @@ static int launch_wide(FusedArgs& A, const Fn& fn) {
   const int d = A.d;
   if ((d & 3) == 0 && ((reinterpret_cast<uintptr_t>(A.X) | reinterpret_cast<uintptr_t>(A.grad)) & 15) == 0) {
     const int d4 = d >> 2;
-    // Round 6: rows of exactly 2 / 4 / 8 / 16 / 32 x 4 float4s (d = 32, 64, 128, 256, 512) take the pipelined kernel (MDE_WIDE_P=0: off)
+    // Round 6: every d = 8 .. 512 that is a multiple of 4 takes the pipelined kernel (MDE_WIDE_P=0: off)
     const int wide_p = getenv("MDE_WIDE_P") ? atoi(getenv("MDE_WIDE_P")) : 1;
-    if (wide_p) {
-      if (d4 == 8) return launch_wide4p<2, IND, Fn>(A, fn);
-      if (d4 == 16) return launch_wide4p<4, IND, Fn>(A, fn);
-      if (d4 == 32) return launch_wide4p<8, IND, Fn>(A, fn);
-      if (d4 == 64) return launch_wide4p<16, IND, Fn>(A, fn);
-      if (d4 == 128) return launch_wide4p<32, IND, Fn>(A, fn);
+    if (wide_p && d4 >= 2 && d4 <= 128) {
+      // GL lanes x K4 float4s cover the row: GL * (K4 - 1) < d4 <= GL * K4 (the lanes of the last float4 that lie
+      // behind the row's end are masked)
+      if (d4 == 2) return launch_wide4p<1, 2, IND, Fn>(A, fn);
+      if (d4 == 3) return launch_wide4p<1, 3, IND, Fn>(A, fn);
+      if (d4 == 4) return launch_wide4p<1, 4, IND, Fn>(A, fn);
+      if (d4 <= 6) return launch_wide4p<2, 3, IND, Fn>(A, fn);
+      if (d4 <= 8) return launch_wide4p<2, 4, IND, Fn>(A, fn);
+      if (d4 <= 12) return launch_wide4p<4, 3, IND, Fn>(A, fn);
+      if (d4 <= 16) return launch_wide4p<4, 4, IND, Fn>(A, fn);
+      if (d4 <= 24) return launch_wide4p<8, 3, IND, Fn>(A, fn);
+      if (d4 <= 32) return launch_wide4p<8, 4, IND, Fn>(A, fn);
+      if (d4 <= 48) return launch_wide4p<16, 3, IND, Fn>(A, fn);
+      if (d4 <= 64) return launch_wide4p<16, 4, IND, Fn>(A, fn);
+      if (d4 <= 96) return launch_wide4p<32, 3, IND, Fn>(A, fn);
+      return launch_wide4p<32, 4, IND, Fn>(A, fn);
     }
     if (d4 <= 2) return launch_wide4_gk<2, 1, IND, Fn>(A, fn);
     if (d4 <= 4) return launch_wide4_gk<4, 1, IND, Fn>(A, fn);
