@@ -223,7 +223,7 @@ int mde_plan_expand_layout(const mde_plan* plan, int32_t layout, const float* in
  * [10] row blocks PERMUTED (rows dealt to the blocks by degree; every entry adds f / 2), [11] hub rows PEELED off to
  * the CSR hub kernel, [12] their half-edges, [13] their segments, [14], [15] reserved (0). */
 int mde_plan_ring_info(const mde_plan* plan, int64_t* info_host);
-/* Processing order of the plan's rows for the general-d kernel (d = 8 .. 512, multiples of 4; round 6).  The reference evaluates
+/* Processing order of the plan's rows for the general-d kernel (d = 5 .. 512; round 6).  The reference evaluates
  * the edges in the caller's order whatever the numbering of the items [ref: pymde/average_distortion.py:62-106]; here
  * the rows of X gathered at the same time share the caches only when neighbours are close in the order the rows are
  * evaluated in.  The call runs a breadth-first search over the plan's rows and sorts them by (level, row id); nothing

@@ -565,8 +565,8 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4(
 }
 
 // ---------------------------------------------------------------- general-d fused kernel, pipelined form (round 6)
-// Rows of d4 = d / 4 float4s, GL lanes x K4 float4s per half-edge with GL * (K4 - 1) < d4 <= GL * K4 (GL = 1 .. 32, K4 = 2 .. 4:
-// every d = 8 .. 512 that is a multiple of 4; d = 128 is <8, 4>).  Same lane layout as k_fused_wide4<GL, K4>
+// Rows of ncol = ceil(d / 4) float4 columns, GL lanes x K4 float4s per half-edge with GL * (K4 - 1) < ncol <= GL * K4 (GL = 1 .. 32,
+// K4 = 2 .. 4: every d = 5 .. 512; d = 128 is <8, 4>).  Same lane layout as k_fused_wide4<GL, K4>
 // (GL lanes share a half-edge, 64 / GL half-edges per wave step); what changes is everything around the arithmetic:
 //  * the row gathers of step s + 1 are in flight while step s is evaluated (two register buffers, the loop unrolled
 //    by two; the meta words -- neighbour id, parameters -- run two steps ahead, the next row's first meta words and
@@ -584,6 +584,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4(
 // so a vertex-range shard produces the bits of the single process.
 typedef float wide_f2 __attribute__((ext_vector_type(2)));
 typedef unsigned wide_u2 __attribute__((ext_vector_type(2)));
+typedef wide_f4 wide_f4u __attribute__((aligned(4)));  // a float4 at any float of a row (unaligned access mode)
 template <int GL>
 __device__ __forceinline__ float wide_group_sum(float v) {
   static_assert(GL == 1 || GL == 2 || GL == 4 || GL == 8 || GL == 16 || GL == 32, "group widths of the pipelined kernel");
@@ -606,15 +607,13 @@ __device__ __forceinline__ float wide_fold16(float a, float b) {
 }
 template <int GL, int K4, bool INDIRECT, class Fn>
 __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
-    int nrows, int row_lo, int d4, int chunk_log, const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
+    int nrows, int row_lo, int d, int chunk_log, const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ nbr,
     const int32_t* __restrict__ eid, const float* __restrict__ a0, const float* __restrict__ a1, int a0_scalar,
-    int a1_scalar, const wide_f4* __restrict__ X4, wide_f4* __restrict__ grad4, double* __restrict__ loss_partials,
+    int a1_scalar, const float* __restrict__ X, float* __restrict__ grad, double* __restrict__ loss_partials,
     Fn fn, float inv_p, float grad_scale) {
   __shared__ double smem[8];
   constexpr int E = 64 / GL;   // half-edges per wave step
-  // d4 = float4s per row, GL * (K4 - 1) < d4 <= GL * K4: the lanes whose LAST float4 lies behind the row's end load the
-  // row's last float4 again (a valid address) and have that difference multiplied by zero
   constexpr int WPB = MDE_BLOCK / 64;
   const int lane = threadIdx.x & 63;
   const int lig = lane & (GL - 1);
@@ -625,9 +624,20 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
   float loss = 0.0f;
   const float a0s = a0_scalar ? a0[0] : 0.0f;
   const float a1s = (a1 && a1_scalar) ? a1[0] : 0.0f;
-  const bool tail_dead = lig + (K4 - 1) * GL >= d4;
-  const int c_tail = tail_dead ? d4 - 1 : lig + (K4 - 1) * GL;  // column (float4) of the lane's last load
-  const float keep = tail_dead ? 0.0f : 1.0f;
+  // Columns: float4 number c covers the floats [4 c, 4 c + 4) of a row, except the row's LAST column when d is not a
+  // multiple of 4: that one covers [d - 4, d) -- shifted back so that it stays inside the row -- and only its last
+  // d % 4 components count.  Rows start at multiples of d floats, so the 16-byte accesses are 4-byte aligned only
+  // (the hardware's unaligned access mode; wide_f4u below).  A lane's columns are lig + j GL, j < K4, with
+  // GL (K4 - 1) < ncol <= GL K4: only its last column can be the row's last, or lie behind it (then it loads the
+  // row's last column again and every component is masked).
+  const int ncol = (d + 3) >> 2, rem = d & 3;
+  const int c_mine = lig + (K4 - 1) * GL;
+  const bool tail_dead = c_mine >= ncol;
+  const bool tail_part = rem != 0 && c_mine == ncol - 1;
+  const int off_tail = (tail_dead || tail_part) ? (rem ? d - 4 : 4 * (ncol - 1)) : 4 * c_mine;
+  const int first_kept = tail_dead ? 4 : (tail_part ? 4 - rem : 0);  // components below it are masked
+  const wide_f2 keep_lo = {first_kept <= 0 ? 1.0f : 0.0f, first_kept <= 1 ? 1.0f : 0.0f};
+  const wide_f2 keep_hi = {first_kept <= 2 ? 1.0f : 0.0f, first_kept <= 3 ? 1.0f : 0.0f};
 
   // position of the i-th row of this XCD's sequence in the processing order, or -1 behind the end; the row at a
   // position is order[position] when the plan carries a processing order (mde_plan_row_order), the position itself
@@ -661,10 +671,26 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
     return m;
   };
   auto load_rows = [&](wide_f4 (&x)[K4], int64_t u) __attribute__((always_inline)) {
-    const wide_f4* p = X4 + u * d4;
+    const float* p = X + u * d;
 #pragma unroll
-    for (int j = 0; j < K4 - 1; ++j) x[j] = p[lig + j * GL];
-    x[K4 - 1] = p[c_tail];
+    for (int j = 0; j < K4 - 1; ++j) x[j] = *reinterpret_cast<const wide_f4u*>(p + 4 * (lig + j * GL));
+    x[K4 - 1] = *reinterpret_cast<const wide_f4u*>(p + off_tail);
+  };
+  // the lane's column j of gradient row v (j >= K4, or a column behind the row's end: nothing; the row's last column
+  // when d is not a multiple of 4: its last d % 4 components, one by one -- the float4 would overlap the column before)
+  auto store_col = [&](int64_t v, int j, wide_f4 val) __attribute__((always_inline)) {
+    float* g = grad + v * d;
+    if (j < K4 - 1) {
+      *reinterpret_cast<wide_f4u*>(g + 4 * (lig + j * GL)) = val;
+    } else if (j == K4 - 1 && !tail_dead) {
+      if (!tail_part) {
+        *reinterpret_cast<wide_f4u*>(g + off_tail) = val;
+      } else {
+        if (rem >= 3) g[d - 3] = val.y;
+        if (rem >= 2) g[d - 2] = val.z;
+        g[d - 1] = val.w;
+      }
+    }
   };
 
   int i = __builtin_amdgcn_readfirstlane((int)(blockIdx.x >> 3) * WPB + (int)(threadIdx.x >> 6));
@@ -740,8 +766,8 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
         dd[2 * j + 1] = wide_f2{xv[j].z, xv[j].w} + wide_f2{x[j].z, x[j].w};
         if (j == K4 - 1) {
           // (x 1 where the row is exactly GL x K4 float4s wide: exact)
-          dd[2 * j] *= wide_f2{keep, keep};
-          dd[2 * j + 1] *= wide_f2{keep, keep};
+          dd[2 * j] *= keep_lo;
+          dd[2 * j + 1] *= keep_hi;
         }
         s2 = dd[2 * j] * dd[2 * j] + s2;
         t2 = dd[2 * j + 1] * dd[2 * j + 1] + t2;
@@ -785,7 +811,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
     mB = m1n;
     m0n = m0nn;
     m1n = m1nn;
-    if (grad4) {
+    if (grad) {
       // transposing reduction over the E groups of the wave (lanes with equal lig)
       const float gsc = -grad_scale;
       float e[16];
@@ -801,9 +827,8 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
       if constexpr (GL == 32) {
         // lane (b5, lig): float4s 2 b5 and 2 b5 + 1 of the row
         const int j0 = (lane >> 5) * 2;
-        if (j0 < K4 && lig + j0 * GL < d4) grad4[v * d4 + lig + j0 * GL] = wide_f4{e8[0], e8[1], e8[2], e8[3]} * gsc;
-        if (j0 + 1 < K4 && lig + (j0 + 1) * GL < d4)
-          grad4[v * d4 + lig + (j0 + 1) * GL] = wide_f4{e8[4], e8[5], e8[6], e8[7]} * gsc;
+        store_col(v, j0, wide_f4{e8[0], e8[1], e8[2], e8[3]} * gsc);
+        store_col(v, j0 + 1, wide_f4{e8[4], e8[5], e8[6], e8[7]} * gsc);
       } else {
         // xor 16: element k with k + 4 -> rows 0, 2 keep k, rows 1, 3 keep k + 4
         float e4[4];
@@ -833,8 +858,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_fused_wide4p(
         // lane (b5, b4, .): float4 number b4 + 2 b5 of the row; below GL = 16 the lanes with (lane & 15) >= GL hold
         // copies
         const int j = (lane >> 4) & 3;
-        if ((lane & 15) < GL && j < K4 && lig + j * GL < d4)
-          grad4[v * d4 + lig + j * GL] = wide_f4{e4[0], e4[1], e4[2], e4[3]} * gsc;
+        if ((lane & 15) < GL) store_col(v, j, wide_f4{e4[0], e4[1], e4[2], e4[3]} * gsc);
       }
     }
     // xv <- -x_v of the next row (see step()); the asm keeps hipcc from folding the sign back into a subtraction
@@ -1027,20 +1051,20 @@ static int launch_wide4p(FusedArgs& A, const Fn& fn) {
     if (rc != MDE_OK) return rc;
   }
   hipLaunchKernelGGL((k_fused_wide4p<GL, K4, IND, Fn>), dim3(nb), dim3(MDE_BLOCK), 0, A.st, nrows,
-                     (int)mde_plan_row_lo(P), A.d / 4, chunk_log, P->order, mde_plan_rowptr(P), mde_plan_nbr(P), mde_plan_eid(P),
-                     A.a0, A.a1, A.a0_scalar, A.a1_scalar, reinterpret_cast<const wide_f4*>(A.X),
-                     reinterpret_cast<wide_f4*>(A.grad), A.partials, fn, A.inv_p, A.grad_scale);
+                     (int)mde_plan_row_lo(P), A.d, chunk_log, P->order, mde_plan_rowptr(P), mde_plan_nbr(P), mde_plan_eid(P),
+                     A.a0, A.a1, A.a0_scalar, A.a1_scalar, A.X, A.grad, A.partials, fn, A.inv_p, A.grad_scale);
   MDE_LAUNCH_CHECK();
   return MDE_OK;
 }
 template <bool IND, class Fn>
 static int launch_wide(FusedArgs& A, const Fn& fn) {
   const int d = A.d;
-  if ((d & 3) == 0 && ((reinterpret_cast<uintptr_t>(A.X) | reinterpret_cast<uintptr_t>(A.grad)) & 15) == 0) {
-    const int d4 = d >> 2;
-    // Round 6: every d = 8 .. 512 that is a multiple of 4 takes the pipelined kernel (MDE_WIDE_P=0: off)
+  {
+    // Round 6: every d = 5 .. 512 takes the pipelined kernel (MDE_WIDE_P=0: off).  Its 16-byte accesses start at any
+    // float of a row (4-byte aligned; the hardware's unaligned access mode), so d need not be a multiple of 4.
+    const int d4 = (d + 3) >> 2;  // float4 columns of a row
     const int wide_p = getenv("MDE_WIDE_P") ? atoi(getenv("MDE_WIDE_P")) : 1;
-    if (wide_p && d4 >= 2 && d4 <= 128) {
+    if (wide_p && d >= 5 && d4 <= 128) {
       // GL lanes x K4 float4s cover the row: GL * (K4 - 1) < d4 <= GL * K4 (the lanes of the last float4 that lie
       // behind the row's end are masked)
       if (d4 == 2) return launch_wide4p<1, 2, IND, Fn>(A, fn);
@@ -1057,6 +1081,9 @@ static int launch_wide(FusedArgs& A, const Fn& fn) {
       if (d4 <= 96) return launch_wide4p<32, 3, IND, Fn>(A, fn);
       return launch_wide4p<32, 4, IND, Fn>(A, fn);
     }
+  }
+  if ((d & 3) == 0 && ((reinterpret_cast<uintptr_t>(A.X) | reinterpret_cast<uintptr_t>(A.grad)) & 15) == 0) {
+    const int d4 = d >> 2;
     if (d4 <= 2) return launch_wide4_gk<2, 1, IND, Fn>(A, fn);
     if (d4 <= 4) return launch_wide4_gk<4, 1, IND, Fn>(A, fn);
     if (d4 <= 8) return launch_wide4_gk<8, 1, IND, Fn>(A, fn);

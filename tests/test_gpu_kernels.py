@@ -1065,9 +1065,10 @@ def _band_graph(rng, n, deg, window, shuffle):
     return e
 
 
-@pytest.mark.parametrize("d", [8, 12, 16, 20, 24, 32, 40, 48, 64, 96, 100, 128, 200, 256, 388, 512])
+@pytest.mark.parametrize("d", [5, 6, 7, 8, 9, 10, 11, 12, 13, 16, 17, 20, 24, 31, 32, 33, 40, 48, 50, 64, 96, 99, 100, 101,
+                               127, 128, 129, 200, 255, 256, 257, 388, 511, 512])
 def test_pipelined_wide_kernel_on_ragged_graphs(d, monkeypatch):
-    """k_fused_wide4p (every d = 8 .. 512 that is a multiple of 4: 1 .. 32 lanes x 2 .. 4 float4s per half-edge, the last float4 masked where the row ends inside it): empty rows, rows of one to three half-edges, a hub,
+    """k_fused_wide4p (every d = 5 .. 512: 1 .. 32 lanes x 2 .. 4 float4s per half-edge at any float of a row -- 4-byte aligned 16-byte accesses --, the row's last column shifted back and masked where d is not a multiple of 4): empty rows, rows of one to three half-edges, a hub,
     odd and even step counts -- against the oracle, against the unpipelined kernel (MDE_WIDE_P=0), three runs bitwise."""
     import pymde_amd
     from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate

@@ -8,7 +8,7 @@ from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(1)
 worst = 0.0
-for d in (8, 12, 16, 20, 24, 32, 48, 64, 100, 128, 256, 388, 512):
+for d in (5, 6, 7, 9, 10, 11, 13, 17, 31, 33, 50, 99, 101, 127, 129, 255, 257, 511, 8, 12, 16, 64, 128, 512):
     for n, p in ((1, 0), (37, 50), (1000, 3000), (20011, 400000)):
         if n < 2: continue
         X = torch.randn(n, d, device=dev, generator=g)
