@@ -1,4 +1,4 @@
-// mde_mfma.hip -- the Standardized projections at embedding widths 32, 64, 128: exact-f32 matrix
+// mde_mfma.hip -- the Standardized projections at embedding widths 5 .. 128 (register tiles of 32, 64, 128 columns): exact-f32 matrix
 // core kernels (v_mfma_f32_32x32x2_f32 runs at the f32 vector rate, 64 FLOP/clk/SIMD; at d = 128 the
 // d x d Gram matrix and the n x d by d x d product are ~16 GFLOP each for n = 500k, i.e. as long
 // on the matrix pipe as their operands take to stream from HBM -- the kernels below keep both busy).
@@ -22,26 +22,46 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// W consecutive floats at p (p is 4 W-byte aligned when W is 1, 2, 4)
-template <int W>
-__device__ __forceinline__ void ldw(const float* p, float (&v)[W]) {
-  if constexpr (W == 4) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-  } else if constexpr (W == 2) {
-    const float2 t = *reinterpret_cast<const float2*>(p);
-    v[0] = t.x; v[1] = t.y;
+// Round 6: the kernels take ANY width d <= 32 W (W = 1, 2, 4: d <= 32, 64, 128) -- rows are d floats apart, the columns
+// d .. 32 W - 1 are zero in registers and never stored; the d x d matrices (Gram, M) and the column means are compact.
+// Rows then start at any float: the vector accesses below are 4-byte aligned only (gfx950 runs global accesses in
+// unaligned mode; hipcc keeps the wide instructions for these types).  Until then every other width ran the round-1
+// generic kernels: Standardized at n = 500k took 8.0 / 6.6 ms per tangent projection / retraction at d = 100 against
+// 0.52 / 0.64 at d = 128 (tools/r6_proj_sweep.py).
+typedef float mf4 __attribute__((ext_vector_type(4)));
+typedef float mf2 __attribute__((ext_vector_type(2)));
+typedef mf4 mf4u __attribute__((aligned(4)));
+typedef mf2 mf2u __attribute__((aligned(4)));
+
+// W consecutive floats at p = columns col0 .. col0 + W - 1 of a row with `valid` columns; pad[] beyond the row's end
+template <int W, bool EXACT>
+__device__ __forceinline__ void ldw(const float* p, int col0, int valid, const float (&pad)[W], float (&v)[W]) {
+  if (EXACT || col0 + W <= valid) {
+    if constexpr (W == 4) {
+      const mf4 t = *reinterpret_cast<const mf4u*>(p);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else if constexpr (W == 2) {
+      const mf2 t = *reinterpret_cast<const mf2u*>(p);
+      v[0] = t.x; v[1] = t.y;
+    } else {
+#pragma unroll
+      for (int q = 0; q < W; ++q) v[q] = p[q];
+    }
   } else {
 #pragma unroll
-    for (int q = 0; q < W; ++q) v[q] = p[q];
+    for (int q = 0; q < W; ++q) v[q] = col0 + q < valid ? p[q] : pad[q];
   }
 }
 
 // ---------------------------------------------------------------- column sums (means)
-template <int W>
-__global__ __launch_bounds__(MDE_BLOCK) void k_colsum_rows(int64_t n, const float* __restrict__ Z, int64_t rows_per_wg,
-                                                           double* __restrict__ partial /* [gridDim.x][32 W] */) {
+template <int W, bool EXACT>
+__global__ __launch_bounds__(MDE_BLOCK) void k_colsum_rows(int64_t n, int d_, const float* __restrict__ Z, int64_t rows_per_wg,
+                                                           double* __restrict__ partial /* [gridDim.x][d] */) {
   constexpr int D = 32 * W;
+  const int d = EXACT ? D : d_;  // (EXACT: the width is the register tile's -- rounds 3-5's kernels, no guards)
+  float zero[W];
+#pragma unroll
+  for (int q = 0; q < W; ++q) zero[q] = 0.0f;
   __shared__ double red[MDE_BLOCK / 64][64][W];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, kk = lane >> 5, c = lane & 31;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
@@ -56,7 +76,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_colsum_rows(int64_t n, const floa
     for (int u = 0; u < U; ++u) {
       const int64_t rr = r + 8 * u + kk;
       if (rr < r1) {
-        ldw<W>(Z + rr * D + W * c, a[u]);
+        ldw<W, EXACT>(Z + rr * d + W * c, W * c, d, zero, a[u]);
       } else {
 #pragma unroll
         for (int q = 0; q < W; ++q) a[u][q] = 0.0f;
@@ -74,7 +94,7 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_colsum_rows(int64_t n, const floa
     const int cc = i / W, q = i % W;
     double s = 0.0;
     for (int w = 0; w < MDE_BLOCK / 64; ++w) s += red[w][cc][q] + red[w][32 + cc][q];
-    partial[(int64_t)blockIdx.x * D + i] = s;
+    if (i < d) partial[(int64_t)blockIdx.x * d + i] = s;
   }
 }
 
@@ -83,13 +103,14 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_colsum_rows(int64_t n, const floa
 // B-side registers -- 4 tiles = 64 accumulator registers at d = 128, which leaves room for a second
 // register set of operands in flight and for two or three waves per SIMD; sixteen tiles in one wave
 // spill, eight still do under hipcc.  The B-side rows are then read by W waves: L1 hits.)
-template <int W, bool SAME>
-__global__ __launch_bounds__(MDE_BLOCK, 2) void k_gram_rows(int64_t n, const float* __restrict__ A,
+template <int W, bool SAME, bool EXACT>
+__global__ __launch_bounds__(MDE_BLOCK, 2) void k_gram_rows(int64_t n, int d_, const float* __restrict__ A,
                                                          const float* __restrict__ B,
                                                          const double* __restrict__ mean, int64_t rows_per_wg,
-                                                         double* __restrict__ partial /* [gridDim.x][D * D] */) {
+                                                         double* __restrict__ partial /* [gridDim.x][d * d] */) {
   static_assert(W == 1 || W == 2 || W == 4, "A-side halves of equal size");
   constexpr int D = 32 * W;
+  const int d = EXACT ? D : d_;
   constexpr int NH = W;                       // parts of the A-side registers: one register per wave
   constexpr int QH = W / NH;                  // A-side registers per part
   constexpr int NRG = (MDE_BLOCK / 64) / NH;  // wave groups interleaving the row pairs
@@ -101,9 +122,9 @@ __global__ __launch_bounds__(MDE_BLOCK, 2) void k_gram_rows(int64_t n, const flo
   const int64_t r1 = r0 + rows_per_wg < n ? r0 + rows_per_wg : n;
   float mub[W], mua[QH];
 #pragma unroll
-  for (int p = 0; p < W; ++p) mub[p] = mean ? (float)mean[W * c + p] : 0.0f;
+  for (int p = 0; p < W; ++p) mub[p] = (mean && W * c + p < d) ? (float)mean[W * c + p] : 0.0f;
 #pragma unroll
-  for (int q = 0; q < QH; ++q) mua[q] = mean ? (float)mean[W * c + q0 + q] : 0.0f;
+  for (int q = 0; q < QH; ++q) mua[q] = (mean && W * c + q0 + q < d) ? (float)mean[W * c + q0 + q] : 0.0f;
   f32x16 acc[QH][W];
 #pragma unroll
   for (int q = 0; q < QH; ++q)
@@ -113,8 +134,9 @@ __global__ __launch_bounds__(MDE_BLOCK, 2) void k_gram_rows(int64_t n, const flo
       for (int v = 0; v < 16; ++v) acc[q][p][v] = 0.0f;
   // Two register sets: the loads of the next batch of row pairs are in flight while the MFMAs of this
   // one run.  (A == B: the A-side values are loaded again -- an L1 hit -- rather than picked out of the
-  // B-side registers with a wave-dependent register index.)
-  constexpr int U = 8;
+  // B-side registers with a wave-dependent register index.)  (Padded widths: the guarded loads need registers of
+  // their own -- batches of four row pairs instead of eight keep the 128-column tile out of scratch memory.)
+  constexpr int U = EXACT ? 8 : 4;
   const float* Aq = A + W * c + q0;
   const float* Bq = B + W * c;
   auto load = [&](int64_t r, float (&a)[U][QH], float (&b)[U][W]) __attribute__((always_inline)) {
@@ -122,8 +144,8 @@ __global__ __launch_bounds__(MDE_BLOCK, 2) void k_gram_rows(int64_t n, const flo
     for (int u = 0; u < U; ++u) {
       const int64_t rr = r + 2 * NRG * u + kk;
       if (rr < r1) {
-        ldw<W>(Bq + rr * D, b[u]);
-        ldw<QH>(Aq + rr * D, a[u]);
+        ldw<W, EXACT>(Bq + rr * d, W * c, d, mub, b[u]);   // (padding = the mean: centred to zero below)
+        ldw<QH, EXACT>(Aq + rr * d, W * c + q0, d, mua, a[u]);
       } else {
 #pragma unroll
         for (int p = 0; p < W; ++p) b[u][p] = mub[p];  // (centred to zero below)
@@ -175,12 +197,13 @@ __global__ __launch_bounds__(MDE_BLOCK, 2) void k_gram_rows(int64_t n, const flo
     }
     __syncthreads();
   }
-  double* out = partial + (int64_t)blockIdx.x * D * D;
+  double* out = partial + (int64_t)blockIdx.x * d * d;
   for (int idx = threadIdx.x; idx < W * W * 16 * 64; idx += MDE_BLOCK) {
     const int l = idx & 63, v = (idx >> 6) & 15, t = idx >> 10;
     const int q = t / W, p = t % W;
     const int i = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5);
-    out[(W * i + q) * D + W * (l & 31) + p] = (double)red[idx];
+    const int row = W * i + q, col = W * (l & 31) + p;
+    if (row < d && col < d) out[row * d + col] = (double)red[idx];
   }
 }
 
@@ -205,15 +228,19 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_sum_chunks(int64_t m, int nc, con
 }
 
 // ---------------------------------------------------------------- right-multiplication
-template <int W>
-__global__ __launch_bounds__(MDE_BLOCK) void k_rmul_rows(int64_t n, const float* A, const double* __restrict__ M,
+template <int W, bool EXACT>
+__global__ __launch_bounds__(MDE_BLOCK) void k_rmul_rows(int64_t n, int d_, const float* A, const double* __restrict__ M,
                                                          const double* __restrict__ mean, float alpha,
                                                          const float* base, float* out) {
   constexpr int D = 32 * W, KH = D / 2;
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // [D][D] fp32 copy of M, then [D] column means
+  const int d = EXACT ? D : d_;
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [D][D] fp32 copy of M (zero beyond d), then [D] column means
   float* smean = sm + D * D;
-  for (int i = threadIdx.x; i < D * D; i += MDE_BLOCK) sm[i] = (float)M[i];
-  for (int i = threadIdx.x; i < D; i += MDE_BLOCK) smean[i] = mean ? (float)mean[i] : 0.0f;
+  for (int i = threadIdx.x; i < D * D; i += MDE_BLOCK) {
+    const int r = i / D, c = i % D;
+    sm[i] = (r < d && c < d) ? (float)M[r * d + c] : 0.0f;
+  }
+  for (int i = threadIdx.x; i < D; i += MDE_BLOCK) smean[i] = (mean && i < d) ? (float)mean[i] : 0.0f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, rn = lane & 31;
   const float* smh = sm + (size_t)h * KH * D + rn;
@@ -221,12 +248,19 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_rmul_rows(int64_t n, const float*
   const int64_t tstep = (int64_t)gridDim.x * (MDE_BLOCK / 64);
   // my half of my row (inner indices h KH .. h KH + KH - 1), as float4 loads along the row; the
   // next tile's rows are requested before this tile's MFMAs start
-  float4 nx[KH / 4];
+  mf4 nx[KH / 4];
   auto fetch = [&](int64_t tile) __attribute__((always_inline)) {
     const int64_t row = tile * 32 + rn;
-    const float* ap = A + (row < n ? row : 0) * D + h * KH;
+    const float* ap = A + (row < n ? row : 0) * d + h * KH;
 #pragma unroll
-    for (int t = 0; t < KH / 4; ++t) nx[t] = *reinterpret_cast<const float4*>(ap + 4 * t);
+    for (int t = 0; t < KH / 4; ++t) {
+      const int c0 = h * KH + 4 * t;
+      if (EXACT || c0 + 4 <= d) {
+        nx[t] = *reinterpret_cast<const mf4u*>(ap + 4 * t);
+      } else {
+        nx[t] = mf4{c0 < d ? ap[4 * t] : 0.0f, c0 + 1 < d ? ap[4 * t + 1] : 0.0f, c0 + 2 < d ? ap[4 * t + 2] : 0.0f, 0.0f};
+      }
+    }
   };
   int64_t tile = (int64_t)blockIdx.x * (MDE_BLOCK / 64) + wave;
   if (tile < ntiles) fetch(tile);
@@ -258,13 +292,17 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_rmul_rows(int64_t n, const float*
       if (ok) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int64_t o = row * D + jt * 32 + 8 * g + 4 * h;
-          float4 r = make_float4(alpha * acc[4 * g], alpha * acc[4 * g + 1], alpha * acc[4 * g + 2], alpha * acc[4 * g + 3]);
-          if (base) {
-            const float4 bq = *reinterpret_cast<const float4*>(base + o);
-            r.x += bq.x; r.y += bq.y; r.z += bq.z; r.w += bq.w;
+          const int c0 = jt * 32 + 8 * g + 4 * h;
+          const int64_t o = row * d + c0;
+          mf4 r = {alpha * acc[4 * g], alpha * acc[4 * g + 1], alpha * acc[4 * g + 2], alpha * acc[4 * g + 3]};
+          if (EXACT || c0 + 4 <= d) {
+            if (base) r += *reinterpret_cast<const mf4u*>(base + o);
+            *reinterpret_cast<mf4u*>(out + o) = r;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 3; ++e)
+              if (c0 + e < d) out[o + e] = r[e] + (base ? base[o + e] : 0.0f);
           }
-          *reinterpret_cast<float4*>(out + o) = r;
         }
       }
     }
@@ -281,7 +319,8 @@ static bool g_mfma_off() {
   return v != 0;
 }
 // widths these kernels take (square d x d problems)
-bool mde_mfma_width_ok(int d) { return !g_mfma_off() && (d == 32 || d == 64 || d == 128); }
+bool mde_mfma_width_ok(int d) { return !g_mfma_off() && d >= 5 && d <= 128; }
+static int width_class(int d) { return d <= 32 ? 1 : (d <= 64 ? 2 : 4); }
 
 // mean[c] = column mean of Z (partial: >= 1024 * d doubles)
 int mde_mfma_colmean(int64_t n, int d, const float* Z, double* partial, double* mean, hipStream_t st) {
@@ -290,8 +329,15 @@ int mde_mfma_colmean(int64_t n, int d, const float* Z, double* partial, double* 
   if (nwg < 1) nwg = 1;
   const int64_t rpw = ((n + nwg - 1) / nwg + 7) & ~(int64_t)7;
   nwg = (n + rpw - 1) / rpw;
-#define CS(W_) hipLaunchKernelGGL(k_colsum_rows<W_>, dim3((unsigned)nwg), dim3(MDE_BLOCK), 0, st, n, Z, rpw, partial)
-  if (d == 32) CS(1); else if (d == 64) CS(2); else CS(4);
+#define CS(W_)                                                                                                            \
+  do {                                                                                                                    \
+    if (d == 32 * W_)                                                                                                     \
+      hipLaunchKernelGGL((k_colsum_rows<W_, true>), dim3((unsigned)nwg), dim3(MDE_BLOCK), 0, st, n, d, Z, rpw, partial);   \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((k_colsum_rows<W_, false>), dim3((unsigned)nwg), dim3(MDE_BLOCK), 0, st, n, d, Z, rpw, partial);  \
+  } while (0)
+  const int wc = width_class(d);
+  if (wc == 1) CS(1); else if (wc == 2) CS(2); else CS(4);
 #undef CS
   MDE_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sum_chunks, dim3((d + 31) / 32), dim3(MDE_BLOCK), 0, st, (int64_t)d, (int)nwg, partial,
@@ -314,12 +360,17 @@ int mde_mfma_gram(int64_t n, int d, const float* A, const float* B, const double
   const bool same = (A == B);
 #define GR(W_)                                                                                                   \
   do {                                                                                                           \
-    if (same)                                                                                                    \
-      hipLaunchKernelGGL((k_gram_rows<W_, true>), dim3((unsigned)nwg), dim3(MDE_BLOCK), 0, st, n, A, B, mean, rpw, partial); \
+    if (same && d == 32 * W_)                                                                                    \
+      hipLaunchKernelGGL((k_gram_rows<W_, true, true>), dim3((unsigned)nwg), dim3(MDE_BLOCK), 0, st, n, d, A, B, mean, rpw, partial); \
+    else if (same)                                                                                               \
+      hipLaunchKernelGGL((k_gram_rows<W_, true, false>), dim3((unsigned)nwg), dim3(MDE_BLOCK), 0, st, n, d, A, B, mean, rpw, partial); \
+    else if (d == 32 * W_)                                                                                       \
+      hipLaunchKernelGGL((k_gram_rows<W_, false, true>), dim3((unsigned)nwg), dim3(MDE_BLOCK), 0, st, n, d, A, B, mean, rpw, partial); \
     else                                                                                                         \
-      hipLaunchKernelGGL((k_gram_rows<W_, false>), dim3((unsigned)nwg), dim3(MDE_BLOCK), 0, st, n, A, B, mean, rpw, partial); \
+      hipLaunchKernelGGL((k_gram_rows<W_, false, false>), dim3((unsigned)nwg), dim3(MDE_BLOCK), 0, st, n, d, A, B, mean, rpw, partial); \
   } while (0)
-  if (d == 32) GR(1); else if (d == 64) GR(2); else GR(4);
+  const int wc = width_class(d);
+  if (wc == 1) GR(1); else if (wc == 2) GR(2); else GR(4);
 #undef GR
   MDE_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_sum_chunks, dim3((unsigned)((m + 31) / 32)), dim3(MDE_BLOCK), 0, st, m, (int)nwg, partial, 1.0, out);
@@ -330,21 +381,30 @@ int mde_mfma_gram(int64_t n, int d, const float* A, const float* B, const double
 // out = base + alpha (A - mean) M  (M: d x d doubles; base may be null; out may alias A or base)
 int mde_mfma_rmul(int64_t n, int d, const float* A, const double* M, const double* mean, float alpha, const float* base,
                   float* out, hipStream_t st) {
-  const size_t lds = ((size_t)d * d + d) * sizeof(float);
+  const int wc = width_class(d), D = 32 * wc;
+  const size_t lds = ((size_t)D * D + D) * sizeof(float);
   int64_t nb = ((n + 31) / 32 + 3) / 4;
   const int64_t cap = (lds > 40960) ? 512 : 1024;  // two (three) workgroups per CU fit their copy of M
   if (nb > cap) nb = cap;
-  if (d == 128) {
+  if (wc == 4) {
     // 64.5 KB of dynamic LDS: above the default cap of a launch
     static bool raised = false;
     if (!raised) {
-      MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rmul_rows<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+      MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rmul_rows<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+      MDE_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rmul_rows<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds));
       raised = true;
     }
   }
-#define RM(W_) hipLaunchKernelGGL(k_rmul_rows<W_>, dim3((unsigned)nb), dim3(MDE_BLOCK), lds, st, n, A, M, mean, alpha, base, out)
-  if (d == 32) RM(1); else if (d == 64) RM(2); else RM(4);
+#define RM(W_)                                                                                                                     \
+  do {                                                                                                                             \
+    if (d == 32 * W_)                                                                                                              \
+      hipLaunchKernelGGL((k_rmul_rows<W_, true>), dim3((unsigned)nb), dim3(MDE_BLOCK), lds, st, n, d, A, M, mean, alpha, base, out);  \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((k_rmul_rows<W_, false>), dim3((unsigned)nb), dim3(MDE_BLOCK), lds, st, n, d, A, M, mean, alpha, base, out); \
+  } while (0)
+  if (wc == 1) RM(1); else if (wc == 2) RM(2); else RM(4);
 #undef RM
   MDE_LAUNCH_CHECK();
   return MDE_OK;
