@@ -491,8 +491,11 @@ typedef struct mde_turn_desc {
   int64_t read_bytes;
   const float* host_loss;
   const int32_t* host_status;
-  const double* host_board;  /* >= 25 doubles: the last kernel of an iteration writes its sequence number behind
-                                the 24 mirrored board entries, and mde_turn_wait polls that word */
+  const double* host_board;  /* >= 80 doubles of pinned memory: the last kernel of an iteration writes the 24 mirrored board
+                                entries, its sequence number behind them (mde_turn_wait polls that word), and -- in the
+                                first 64-byte-aligned 32 doubles at or behind host_board + 32 -- the record again as four
+                                lines of seven values + the sequence number, which is what mde_turn_wait reads: a line and
+                                its tag reach host memory together, the lines in any order */
   double seq;                /* (library state: sequence number of the iteration enqueued last) */
   double pre_id;             /* (library state: > 0 the L-BFGS step of the iteration after it is queued behind it, -1 that step has run and is pending) */
 } mde_turn_desc;

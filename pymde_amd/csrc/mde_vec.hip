@@ -171,18 +171,31 @@ struct MdeGate {
 __device__ __forceinline__ bool mde_gate_closed(const MdeGate& g) {
   return g.word != nullptr && __hip_atomic_load(g.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != g.value;
 }
+// Where the TAGGED copy of the record lives: four 64-byte lines behind the plain mirror, each seven payload doubles
+// and the sequence number -- [loss, status, board[0..24)] -- written by ONE store instruction of one wave, so that a
+// line and its tag arrive together whatever the order the lines reach host memory in.  (Round 6: the plain form --
+// data, system-scope fences, then the sequence word in a line of its own -- let the host read a record ONE
+// ITERATION OLD about once in thirty cold-started solves: the sequence word can pass the data lines on the way to
+// host memory (the solves' iterates were unaffected -- the device decides the trial from device memory -- but the
+// recorded loss and step size of that iteration were the previous one's, and the bit-for-bit test of the turn calls
+// against the call-by-call loop failed now and then).)
+#define MDE_MIRROR_TAG_LINES 4
+__host__ __device__ __forceinline__ double* mde_mirror_tagged(const double* host_board) {
+  return reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(host_board + 32) + 63) & ~(uintptr_t)63);
+}
 __device__ __forceinline__ void mde_mirror_write(const MdeMirror& m) {
   if (!m.host) return;
+  __shared__ double s_pay[7 * MDE_MIRROR_TAG_LINES];
   __threadfence_block();
   __syncthreads();  // the statistics rows written by this block are visible to it
   double* hb = reinterpret_cast<double*>(m.host + m.head_bytes);
   if (threadIdx.x < 24 && !(m.gate && threadIdx.x == 8)) {  // (slot 8: the verdict below, when there is one)
     const volatile double* b = m.board;
-    hb[threadIdx.x] = b[threadIdx.x];
+    s_pay[2 + threadIdx.x] = b[threadIdx.x];
   }
-  if (threadIdx.x == 32) *reinterpret_cast<float*>(m.host) = *reinterpret_cast<const volatile float*>(m.loss_dev);
-  if (threadIdx.x == 33)
-    *reinterpret_cast<int32_t*>(m.host + 4) = m.status ? *reinterpret_cast<const volatile int32_t*>(m.status) : 0;
+  if (threadIdx.x >= 24 && threadIdx.x < 26) s_pay[2 + threadIdx.x] = 0.0;  // (spare payload slots)
+  if (threadIdx.x == 32) s_pay[0] = (double)*reinterpret_cast<const volatile float*>(m.loss_dev);
+  if (threadIdx.x == 33) s_pay[1] = m.status ? (double)*reinterpret_cast<const volatile int32_t*>(m.status) : 0.0;
   if (m.gate && threadIdx.x == 34) {
     // [ref: lbfgs.py:88-110, first pass of the bracketing loop at t = 1: finite, Armijo, curvature]
     // (separately rounded product and sum: the value the host-side search computes)
@@ -195,8 +208,18 @@ __device__ __forceinline__ void mde_mirror_write(const MdeMirror& m) {
     const int st = m.status ? __hip_atomic_load(m.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     const bool bad = !(fabs(f_new) <= 1.7976931348623157e308) || nonfinite != 0.0;
     const bool accept = !bad && !(f_new > __dadd_rn(m.f0, __dmul_rn(m.c1, gtd0))) && (fabs(gtd_new) <= -__dmul_rn(m.c2, gtd0));
-    hb[8] = accept ? 1.0 : 0.0;
+    s_pay[2 + 8] = accept ? 1.0 : 0.0;
     *m.gate = (accept && st == 0) ? m.gate_value : 0u;
+  }
+  __syncthreads();
+  // the plain mirror (what rounds 3-5 read; kept for whoever looks at the pinned buffer directly)
+  if (threadIdx.x < 24) hb[threadIdx.x] = s_pay[2 + threadIdx.x];
+  if (threadIdx.x == 32) *reinterpret_cast<float*>(m.host) = (float)s_pay[0];
+  if (threadIdx.x == 33) *reinterpret_cast<int32_t*>(m.host + 4) = (int32_t)s_pay[1];
+  // the tagged lines: the second wave's lanes 0..31 write 32 consecutive doubles, slot 7 of every line the tag
+  if (threadIdx.x >= 64 && threadIdx.x < 64 + 8 * MDE_MIRROR_TAG_LINES) {
+    const int t = (int)threadIdx.x - 64;
+    mde_mirror_tagged(hb)[t] = (t & 7) == 7 ? m.seq : s_pay[(t >> 3) * 7 + (t & 7)];
   }
   // the sequence word goes out behind the data: every writer fences to system scope, then one thread
   // publishes (the host polls it instead of waiting for the stream's completion signal)
@@ -2732,14 +2755,43 @@ extern "C" int mde_turn_wait(mde_turn_desc* T, int32_t cur, double f0, int32_t a
     }
     std::atomic_thread_fence(std::memory_order_acquire);
   }
-  const double f_new = (double)*T->host_loss;
-  const double* hb = T->host_board;
+  // The record is read from the TAGGED lines (mde_mirror_write): every 64-byte line carries the sequence number in
+  // its last slot and arrives whole, so a line whose tag is this iteration's holds this iteration's values.  A line
+  // that is still on its way is waited for; should one never arrive (it cannot once the stream is idle) that is an error.
+  double pay[7 * MDE_MIRROR_TAG_LINES];
+  {
+    const volatile double* tg = mde_mirror_tagged(T->host_board);
+    hipStream_t st = mde_stream(stream);
+    bool synced = false;
+    for (unsigned spins = 0;; ++spins) {
+      bool ok = true;
+      for (int l = 0; l < MDE_MIRROR_TAG_LINES; ++l) ok = ok && tg[8 * l + 7] == T->seq;
+      if (ok) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (int l = 0; l < MDE_MIRROR_TAG_LINES; ++l)
+          for (int q = 0; q < 7; ++q) pay[7 * l + q] = tg[8 * l + q];
+        // (a line rewritten between the tag check and the copy is impossible: the next iteration is not enqueued yet)
+        break;
+      }
+      if ((spins & 4095u) == 4095u) {
+        if (synced) {
+          mde_set_error("mde_turn_wait: the iteration's record never reached the host mirror");
+          return MDE_E_HIP;
+        }
+        MDE_HIP(hipStreamSynchronize(st));
+        synced = true;
+      }
+    }
+  }
+  const double f_new = pay[0];
+  const double* hb = pay + 2;  // board[0..24)
+  const int32_t status_word = (int32_t)pay[1];
   for (int q = 0; q < 8; ++q) {
     out[4 + q] = hb[q];
     out[12 + q] = hb[16 + q];
   }
   out[0] = f_new;
-  out[3] = (double)*T->host_status;
+  out[3] = (double)status_word;
   // the first pass of the bracketing loop at t = 1 (lbfgs.py:88-110): not bad, Armijo, curvature -- decided
   // by the iteration's last kernel (mde_mirror_write) from f0 as passed when it was enqueued; the gate of a
   // pre-enqueued L-BFGS step followed THAT verdict, so it is the one to go by
@@ -2747,7 +2799,7 @@ extern "C" int mde_turn_wait(mde_turn_desc* T, int32_t cur, double f0, int32_t a
   const bool accept = hb[8] != 0.0;
   out[1] = accept ? 1.0 : 0.0;
   out[2] = 0.0;
-  const bool step_done = accept && *T->host_status == 0 && T->pre_id > 0.0;  // (its gate opened)
+  const bool step_done = accept && status_word == 0 && T->pre_id > 0.0;  // (its gate opened)
   T->pre_id = 0.0;
   out[20] = 0.0;
   if (step_done && !allow_next) {
@@ -2757,7 +2809,7 @@ extern "C" int mde_turn_wait(mde_turn_desc* T, int32_t cur, double f0, int32_t a
     T->pre_id = -1.0;
     out[20] = 1.0;
   }
-  if (accept && allow_next && *T->host_status == 0) {
+  if (accept && allow_next && status_word == 0) {
     // (hb[1]: |g|^2 at the accepted point -- the next iteration goes on to another one iff it is above eps)
     const bool allow_pre = eps_pre >= 0.0 && std::sqrt(hb[1]) > eps_pre;
     const int rc = turn_enqueue_impl(T, 1 - cur, 1.0f, f_new, c1, c2, allow_pre, step_done, stream);

@@ -431,9 +431,12 @@ def test_sphere_constraint_against_reference_golden_and_oracle(golden_sphere):
 
 
 @pytest.mark.parametrize("n,d", [(2, 2), (10, 3), (100, 3), (1000, 2), (1000, 3), (1000, 250), (5000, 128),
-                                 (3000, 64), (777, 96), (600000, 2), (350001, 3)])
+                                 (3000, 64), (777, 96), (600000, 2), (350001, 3),
+                                 (4001, 5), (4001, 7), (4001, 10), (4001, 31), (4001, 33), (4001, 50), (4001, 65), (4001, 100),
+                                 (4001, 127), (3001, 129), (3001, 200), (3001, 256), (2001, 300), (2001, 512)])
 def test_proj_standardized_property(n, d):
-    # pymde/test_util.py:20-71 (shapes incl. (1000, 250)); d = 64/96/128 take the f32 MFMA Gram; the two
+    # pymde/test_util.py:20-71 (shapes incl. (1000, 250)); d = 5 .. 128 take the f32 MFMA Gram (register tiles of
+    # 32 / 64 / 128 columns, padded), d = 129 .. 512 its column blocks of 128 (round 6); the two
     # tall shapes are vectors of more than 2^20 floats (many trips per thread of the reducing kernels)
     from pymde_amd import util
     torch.manual_seed(0)
@@ -479,6 +482,32 @@ def test_centering_and_vector_statistics_on_long_vectors(n, d):
     ref = [float((g64 * d64).sum()), float((g64 * g64).sum()), float(g64.abs().sum()), float(g64.abs().max()), 0.0,
            float((d64 * d64).sum()), float(d64.abs().max()), float((x64 * x64).sum())]
     np.testing.assert_allclose(b[:8], ref, rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize("n,d", [(4001, 5), (4001, 8), (4001, 24), (4001, 50), (4001, 100), (3001, 128), (3001, 130),
+                                 (3001, 200), (3001, 256), (2001, 384)])
+def test_standardized_tangent_projection_across_widths(n, d):
+    """Z - X (Z^T X) / n [ref: constraints.py:186-192] at widths that take the padded / blocked MFMA kernels (round 6),
+    against a float64 evaluation; in place and not."""
+    import pymde_amd
+    std = pymde_amd.Standardized()
+    torch.manual_seed(d)
+    X = std.initialization(n, d, device=DEV)
+    Z = torch.randn((n, d), device=DEV)
+    want = (Z.double() - X.double() @ (Z.double().T @ X.double()) / n)
+    got = std.project_onto_tangent_space(X, Z, inplace=False)
+    err = float((got.double() - want).abs().max())
+    assert err <= 2e-5 * max(1.0, float(want.abs().max())), (d, err)
+    Zc = Z.clone()
+    got2 = std.project_onto_tangent_space(X, Zc, inplace=True)
+    assert torch.equal(got2, got) and got2.data_ptr() == Zc.data_ptr()
+    # the retraction, in place (d > 128: the blocked product reads its rows from a scratch copy)
+    Y = (X + 0.05 * Z).contiguous()
+    P = std.project_onto_constraint(Y.clone(), inplace=True).double()
+    G = (P.T @ P / n).cpu().numpy()
+    np.testing.assert_allclose(G, np.eye(d), rtol=1e-4, atol=3e-5)
+    want_P = oracle.proj_standardized(Y.cpu().numpy(), demean=True)
+    np.testing.assert_allclose(P.cpu().numpy(), want_P, rtol=2e-3, atol=5e-4)
 
 
 def test_standardized_initialization():
