@@ -355,6 +355,42 @@ def test_config5_size_band_graph_renumbered_against_oracle(monkeypatch):
     assert_grad_close(outs[0][:n * d].view(n, d).cpu().numpy(), wgrad)
 
 
+def test_mid_size_problems_ask_the_cost_model():
+    """Between the MNIST-sized problems and the benchmark shape (table in L2, fewer than 16 M half-edges) the layout is
+    chosen by the cost model with both kernels' fixed costs and the FUNCTION's cost on the ring kernel priced (round 6;
+    rounds 3-5 kept the CSR kernels there without asking): n = 100k at out-degree 50 with Log1p takes the LDS-ring
+    layout, the same graph at out-degree 20 with PushAndPull (1.3 x per iteration on the ring) stays on the CSR
+    kernels, a 20k-item problem stays there whatever the function -- and every one of them agrees with the oracle."""
+    import bench
+    import pymde_amd
+    from pymde_amd.average_distortion import Binding, EdgePlan, fused_evaluate
+    dev = torch.device(DEV, 0)
+    pen = pymde_amd.penalties
+    cases = [(100_000, 50, "log1p", True), (100_000, 20, "pushpull", False), (20_000, 20, "log1p", False),
+             (150_000, 20, "log1p", True)]
+    for n, deg, fname, want_ring in cases:
+        for d in (2, 3):
+            edges, w, X = bench.make_workload(dev, n=n, deg=deg, d=d)
+            p = edges.shape[0]
+            if fname == "pushpull":
+                w = w.clone()
+                w[(2 * p) // 3:] = -1.0
+                f = pen.PushAndPull(w, pen.Log1p, pen.Log)
+                fd = oracle.func("LOG1P", w.cpu().numpy(), None, (1.5,), "LOG", (1.0,))
+            else:
+                f = pen.Log1p(w)
+                fd = oracle.func("LOG1P", w.cpu().numpy(), None, (1.5,))
+            plan = EdgePlan(n, edges)
+            b = Binding(plan, f)
+            buf = torch.zeros(n * d + 1, device=dev)
+            fused_evaluate(b, X, buf[:n * d].view(n, d), buf[n * d:])
+            assert plan.ring_info()["built"] == want_ring, (n, deg, fname, d)
+            assert (int(b.struct(d).layout) == 1) == want_ring
+            wE, wgrad = oracle.average_distortion(edges.cpu().numpy(), X.cpu().numpy(), fd)
+            assert float(buf[n * d]) == pytest.approx(wE, rel=1e-5), (n, deg, fname, d)
+            assert_grad_close(buf[:n * d].view(n, d).cpu().numpy(), wgrad)
+
+
 def _ring_full_size_case(n, deg, d, make_f, oracle_func, runs=3, graph="uniform"):
     """>= 5e7 half-edge entries through the LDS-ring kernel: against the OpenMP oracle at the kernel
     tolerances, `runs` evaluations bitwise equal (a race in the ring protocol shows up as a few rows that
