@@ -673,6 +673,48 @@ __global__ __launch_bounds__(MDE_BLOCK) void k_ring_stats(int64_t nit, const uin
   }
 }
 
+// How evenly a workgroup's consumer waves advance along the column sweep (round 6, late).  The ring couples the
+// eight waves of a workgroup: nobody can be more than the ring's slack (~4 chunks) ahead of the slowest.  On a uniform
+// graph every wave finds about the same number of entries in every chunk and the coupling costs nothing; on a graph
+// whose links stay near the diagonal of the vertex order (data sorted by class: 2/3 of the links inside clusters of
+// 1000 consecutive items) each wave's entries sit in the few chunks that hold ITS rows' clusters, the waves take
+// turns instead of working side by side, and the launch takes what ONE wave at a time would: n = 1M, 50M such edges
+// ran 1.28 ms on the ring kernel against 0.66 on the CSR kernels (0.16 for the uniform graph), n = 100k 0.22 against
+// 0.05 (tools/r6_clusters.sh).  crit[wg] = sum over groups of GW chunks of the LARGEST entry count among the
+// workgroup's waves, tot[wg] = all its entries: crit / (tot / NCW) is ~1.1 for a uniform graph (the maximum of eight
+// Poisson counts), up to NCW when the waves' entries never share a chunk group.  One thread per (workgroup, group):
+// sixteen binary searches in the sorted keys.
+__global__ __launch_bounds__(MDE_BLOCK) void k_ring_sweep_balance(int nwg, int ngroups, int GW, int JB,
+                                                                  const uint32_t* __restrict__ keys,
+                                                                  const int32_t* __restrict__ seg,
+                                                                  unsigned long long* __restrict__ crit,
+                                                                  unsigned long long* __restrict__ tot) {
+  const int64_t idx = (int64_t)blockIdx.x * MDE_BLOCK + threadIdx.x;
+  if (idx >= (int64_t)nwg * ngroups) return;
+  const int wg = (int)(idx / ngroups), g = (int)(idx % ngroups);
+  unsigned long long mx = 0, sm = 0;
+  for (int w = 0; w < MDE_RING_NCW; ++w) {
+    const uint32_t s = (uint32_t)wg * MDE_RING_NCW + (uint32_t)w;
+    const int32_t lo = seg[s], hi = seg[s + 1];
+    const uint64_t k0 = ((uint64_t)s << JB) + (uint64_t)g * GW, k1 = k0 + (uint64_t)GW;
+    auto lower = [&](uint64_t key) {
+      int32_t a = lo, b = hi;  // first position in [lo, hi) whose key >= `key`
+      while (a < b) {
+        const int32_t m = a + ((b - a) >> 1);
+        if ((uint64_t)keys[m] < key) a = m + 1; else b = m;
+      }
+      return a;
+    };
+    const unsigned long long c = (unsigned long long)(lower(k1) - lower(k0));
+    mx = c > mx ? c : mx;
+    sm += c;
+  }
+  if (sm) {
+    atomicAdd(&crit[wg], mx);
+    atomicAdd(&tot[wg], sm);
+  }
+}
+
 // MDE_PANEL env: unset / -1 auto, 0 never, 1 whenever the layout is feasible (read at every layout
 // decision, so a test can switch it inside one process)
 static int panel_mode() {
@@ -1266,10 +1308,45 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     // hub rows, which are peeled now, and sparse streams, whose half-filled iterations still beat the CSR kernel's
     // gathers several times over.)  The streams' mean length is priced; a stream far beyond it would be a hub the
     // threshold let through, and 4 x padding says as much.
-    const double t_ring = ring_time_us((double)total_iters / (double)nseg, z.NC, z.Q, z.NRB * z.Q) +
+    // ... and how much of that runs side by side: the slowest workgroup's critical path along the sweep over the
+    // mean stream (k_ring_sweep_balance; ~1.1 on a uniform graph, which the 0.21 us per iteration already contain)
+    double serial = 1.0;
+    {
+      const int nwg = z.NRB * z.Q, GW = 4, ngroups = (z.NC + GW - 1) / GW;
+      unsigned long long* bal = nullptr;
+      e = hipMalloc(&bal, (size_t)2 * nwg * sizeof(unsigned long long));
+      if (e == hipSuccess) e = hipMemsetAsync(bal, 0, (size_t)2 * nwg * sizeof(unsigned long long), st);
+      if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_ring_sweep_balance, dim3((unsigned)(((int64_t)nwg * ngroups + MDE_BLOCK - 1) / MDE_BLOCK)), dim3(MDE_BLOCK),
+                           0, st, nwg, ngroups, GW, z.JB, keys2, seg, bal, bal + nwg);
+        e = hipGetLastError();
+      }
+      std::vector<unsigned long long> hb((size_t)2 * nwg);
+      if (e == hipSuccess) e = hipMemcpyAsync(hb.data(), bal, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (bal) (void)hipFree(bal);
+      if (e != hipSuccess) {
+        drop_caps();
+        return fail(e, "ring layout: sweep balance");
+      }
+      unsigned long long cmax = 0, tsum = 0;
+      for (int i = 0; i < nwg; ++i) {
+        cmax = std::max(cmax, hb[(size_t)i]);
+        tsum += hb[(size_t)nwg + i];
+      }
+      if (tsum > 0) serial = (double)cmax / ((double)tsum / (double)nseg);
+    }
+    const double t_ring = std::max(1.0, serial / 1.15) *
+                              ring_time_us((double)total_iters / (double)nseg, z.NC, z.Q, z.NRB * z.Q) +
                           (double)rp.hub_half_edges * 1.3e-5;
-    const bool mid_bad = mid_regime(plan, d) &&
-                         plan->ring.cost_scale * t_ring + MDE_RING_FIXED_US > 0.85 * (csr_time_us(plan, d) + MDE_CSR_FIXED_US);
+    if (getenv("MDE_RING_STATS"))
+      fprintf(stderr, "[mde ring] sweep balance: critical path of the slowest workgroup / mean stream = %.2f\n", serial);
+    // (mid regime: what the dealt layout and the hub launches add -- the slot map's gathers and a loss term on every
+    // entry ~30 % per iteration, two more launches ~4 us: preferential attachment at n = 100k, out-degree 20 ran
+    // 0.042 ms on the ring against 0.031 on the CSR kernel, tools/r6_midsize_skew.sh)
+    const double mid_ring = plan->ring.cost_scale * (rp.permuted ? 1.3 : 1.0) * t_ring + MDE_RING_FIXED_US +
+                            (rp.hub_half_edges > 0 ? 4.0 : 0.0);
+    const bool mid_bad = mid_regime(plan, d) && mid_ring > 0.85 * (csr_time_us(plan, d) + MDE_CSR_FIXED_US);
     if ((double)Hp > 4.0 * (double)H_ring || t_ring > 0.9 * csr_time_us(plan, d) || mid_bad) {
       drop_caps();
       release(true);
