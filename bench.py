@@ -288,11 +288,13 @@ def cpu_baseline(edges, w, X, p):
 SPINUP_LOG = []
 
 
-def spin_up(fn, device, group=20, tol=0.01, budget_s=0.2, label=None):
+def spin_up(fn, device, group=20, tol=0.01, budget_s=0.8, label=None, min_s=0.3):
     """Run `fn` back to back until the GPU has left its idle clocks: groups of `group` launches, each group timed with
-    one HIP-event pair, until three consecutive groups agree within `tol` or `budget_s` seconds have gone by.  (Round 5's
-    driver line -- `--steps 20` after an idle gap -- was still ramping: its 11 blocks fell from 0.207 to 0.167 ms per
-    step and a 20-launch secondary read 23 % high.)  Untimed; returns the launches it made."""
+    one HIP-event pair, for at least `min_s` seconds AND until three consecutive groups agree within `tol`, or until
+    `budget_s` seconds have gone by.  (Round 5's driver line -- `--steps 20` after an idle gap -- was still ramping: its
+    11 blocks fell from 0.207 to 0.167 ms per step and a 20-launch secondary read 23 % high.  Round 6, first form: no
+    minimum time -- right behind other GPU processes three groups agreed after 37 ms on a plateau below the top clock and
+    the blocks then fell from 0.222 to 0.162.)  Untimed; returns the launches it made."""
     t0 = time.perf_counter()
     times = []
     n = 0
@@ -305,9 +307,10 @@ def spin_up(fn, device, group=20, tol=0.01, budget_s=0.2, label=None):
         b.synchronize()
         n += group
         times.append(a.elapsed_time(b))
-        if len(times) >= 3 and max(times[-3:]) <= (1.0 + tol) * min(times[-3:]):
+        el = time.perf_counter() - t0
+        if el >= min_s and len(times) >= 3 and max(times[-3:]) <= (1.0 + tol) * min(times[-3:]):
             break
-        if time.perf_counter() - t0 > budget_s:
+        if el > budget_s:
             break
     SPINUP_LOG.append({"before": label or "timed launches", "launches": n,
                        "last_groups_ms_per_launch": [round(t / group, 5) for t in times[-3:]]})
