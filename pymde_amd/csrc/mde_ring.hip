@@ -1054,6 +1054,25 @@ static int plan_rows(const mde_plan* plan, const RingSizes& z, hipStream_t st, R
   return MDE_OK;
 }
 
+// A stream that runs out of its region marks itself with 2^25 iterations (k_ring_schedule), which the callers
+// recognise in the SUM of all streams' counts -- 2^25 x 64 entries are past the 32-bit position limit.  The sum is a
+// 32-bit scan: 128 marked streams add up to 2^32 = 0 and the overflow went unseen (round 6: the planted-cluster graph
+// at n = 1M with MDE_RING_ASSIGN=1 marked exactly 1024 streams; the regions were then used as if they had sufficed and
+// the pack kernel faulted).  The counts themselves are looked at: synchronises, and sets *total to -1 when any
+// stream is marked.
+static hipError_t any_stream_bailed(const int32_t* iters, int nseg, hipStream_t st, int32_t* total) {
+  std::vector<int32_t> h((size_t)nseg);
+  hipError_t e = hipMemcpyAsync(h.data(), iters, h.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  for (int i = 0; i < nseg; ++i)
+    if (h[(size_t)i] >= (1 << 25)) {
+      *total = -1;
+      break;
+    }
+  return hipSuccess;
+}
+
 static int build_ring(mde_plan* plan, int d, hipStream_t st) {
   RingSizes z;
   if (!choose_sizes(plan, d, &z)) return 0;
@@ -1267,7 +1286,7 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     e = hipGetLastError();
     if (e == hipSuccess) e = mde_exclusive_sum_i32(tmp, tmp_bytes, iters, iter_base, nseg + 1, st);
     if (e == hipSuccess) e = hipMemcpyAsync(&total_iters, iter_base + nseg, sizeof(int32_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = any_stream_bailed(iters, nseg, st, &total_iters);
     if (e != hipSuccess) {
       drop_caps();
       return fail(e, "ring layout: single-pass schedule");
@@ -1290,7 +1309,7 @@ static int build_ring(mde_plan* plan, int d, hipStream_t st) {
     e = hipGetLastError();
     if (e == hipSuccess) e = mde_exclusive_sum_i32(tmp, tmp_bytes, iters, iter_base, nseg + 1, st);
     if (e == hipSuccess) e = hipMemcpyAsync(&total_iters, iter_base + nseg, sizeof(int32_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = any_stream_bailed(iters, nseg, st, &total_iters);
     if (e != hipSuccess) {
       drop_caps();
       return fail(e, "ring layout: counting pass");
