@@ -17,6 +17,7 @@ gradient recorded at the start of the step; first step t = min(1, 1/|g|_1); ``t 
 resets the memory.
 """
 import ctypes
+import warnings
 import math
 import os
 import time
@@ -119,8 +120,10 @@ class _Engine(object):
         self._stream_obj = torch.cuda.current_stream(dev)
         self._stream = ctypes.c_void_p(self._stream_obj.cuda_stream)
         if int(memory_size) > 63:
-            raise ValueError("memory_size must be at most 63 (the device-resident L-BFGS keeps its "
-                             "pair statistics in one wave); got %d" % int(memory_size))
+            # (the reference has no cap, optim.py:69-82; the device-resident L-BFGS keeps its pair statistics in one
+            # wave.  A solve with the 63 newest pairs instead of more is still the same quasi-Newton method: go on)
+            warnings.warn("pymde_amd keeps at most 63 L-BFGS pairs (memory_size=%d requested): using 63" % int(memory_size))
+            memory_size = 63
         handle = ctypes.c_void_p()
         with torch.cuda.device(dev):  # the history buffer must live on X's GPU, not the current one
             _lib.check(self.lib.mde_lbfgs_create(self.N if history_elements is None else int(history_elements),

@@ -166,9 +166,11 @@ def test_push_and_pull_with_arbitrary_penalties_and_solver_limits():
     E = mde.average_distortion(X)
     E.backward()
     assert torch.isfinite(E) and torch.isfinite(X.grad).all()
-    # the device-resident L-BFGS holds at most 63 pairs: a clear error instead of MDE_E_INVALID
-    with pytest.raises(ValueError, match="memory_size"):
+    # the device-resident L-BFGS holds at most 63 pairs; the reference has no cap (optim.py:69-82): a larger
+    # memory_size is taken as 63 with a warning (round 6; rounds 3-5 raised), and the solve goes on
+    with pytest.warns(UserWarning, match="63 L-BFGS pairs"):
         mde.embed(max_iter=2, memory_size=64)
+    assert torch.isfinite(mde.X).all()
     # a sharded problem evaluates an arbitrary callable too (round 5): distances and f replicated, the scatter
     # over the owned rows, rank 0 carrying the mean -- here rank 0 of 2 without a process group: its own rows
     # of the gradient, and the full value
