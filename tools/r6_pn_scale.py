@@ -11,7 +11,10 @@ for n in [int(a) for a in sys.argv[1:]] or [100_000, 200_000, 400_000]:
         g = torch.Generator(device=dev); g.manual_seed(0)
         nf = 64
         centers = 4.0 * torch.randn((20, nf), device=dev, generator=g)
-        data = centers[torch.randint(0, 20, (n,), device=dev, generator=g)] + torch.randn((n, nf), device=dev, generator=g)
+        lab = torch.randint(0, 20, (n,), device=dev, generator=g)
+        if os.environ.get("PN_SORTED"):
+            lab = torch.sort(lab).values          # items sorted by class: neighbours are near in the vertex order
+        data = centers[lab] + torch.randn((n, nf), device=dev, generator=g)
         t0 = time.perf_counter()
         mde = pymde_amd.preserve_neighbors(data, embedding_dim=d, n_neighbors=15, attractive_penalty=pymde_amd.penalties.Log1p,
                                            repulsive_penalty=pymde_amd.penalties.LogRatio, constraint=pymde_amd.Standardized(), device=dev)
